@@ -1,0 +1,152 @@
+/*
+ * ufd.h -- C ABI of libufacehip.so: the MI355X (gfx950) implementation of infer_server's
+ * per-frame face-detection hot path
+ *     JPEG decode -> Triangle resize + normalize -> UltraFace-RFB forward -> threshold + NMS.
+ *
+ * Every entry point is what a Rust `extern "C"` block in the reference's infer_server crate
+ * would bind to replace one reference interface (cited per function; INTEGRATION.md shows the
+ * binding).  Plain pointers and sizes only; the library never throws or aborts across this
+ * boundary -- every failure is a negative status code plus ufd_last_error().
+ *
+ * Threading: a handle may be used from any thread; calls on one handle are serialised by an
+ * internal lock (the reference has exactly one Inferer task, infer_server.rs:48-50).  Use one
+ * handle per GPU.
+ *
+ * Ownership: input buffers are borrowed for the duration of the call (async form: until
+ * ufd_wait returns); outputs are caller-allocated.
+ */
+#ifndef UFD_H
+#define UFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFD_ABI_VERSION 1
+
+/* ---- status codes (0 = ok; the reference uses anyhow::Result / panics, inferer.rs:23-37) ---- */
+#define UFD_OK 0
+#define UFD_E_ARG (-1)         /* bad argument */
+#define UFD_E_DECODE (-2)      /* corrupt JPEG: frame skipped (reference: expect() panic, inferer.rs:35-36) */
+#define UFD_E_UNSUPPORTED (-3) /* JPEG feature outside the decoder (arithmetic coding, 12-bit, CMYK ...) */
+#define UFD_E_TRUNCATED (-4)   /* more detections than `cap`: `cap` written, *n = true count */
+#define UFD_E_DEVICE (-5)      /* HIP runtime error / no gfx950 device */
+#define UFD_E_WEIGHTS (-6)     /* weight file missing or not an UltraFace-RFB graph */
+#define UFD_E_STATE (-7)       /* async misuse (wait without submit, slot busy, ...) */
+#define UFD_E_TOO_LARGE (-8)   /* frame or batch exceeds the limits given at ufd_create */
+
+/* Bbox + confidence: `(Bbox, f32)` with `Bbox = [f32; 4]` (infer_server/src/nn.rs:12,25).
+ * Relative coordinates [x_top_left, y_top_left, x_bottom_right, y_bottom_right]. */
+typedef struct ufd_det {
+  float x_tl, y_tl, x_br, y_br, conf;
+} ufd_det;
+
+typedef struct ufd_model ufd_model; /* opaque: UltrafaceModel (nn.rs:45-51) resident on one GPU */
+
+/* Arguments of UltrafaceModel::new(variant, max_iou, min_confidence) (nn.rs:55) plus placement. */
+typedef struct ufd_config {
+  uint32_t struct_size;    /* = sizeof(ufd_config) */
+  uint32_t variant;        /* 640 -> UltrafaceVariant::W640H480, 320 -> W320H240 (nn.rs:29-42) */
+  float max_iou;           /* reference passes 0.5 (inferer.rs:23) */
+  float min_confidence;    /* reference passes 0.5 */
+  int32_t device_id;       /* HIP device ordinal */
+  uint32_t max_batch;      /* frames per batched call (>= 1) */
+  uint32_t max_src_width;  /* largest decoded frame accepted; 0 -> 1920 */
+  uint32_t max_src_height; /* 0 -> 1088 */
+  uint32_t host_threads;   /* host entropy-decode workers; 0 -> min(16, hardware threads) */
+  uint32_t flags;          /* UFD_FLAG_* */
+  /* Weights: exactly one source.
+   * (a) weights_path: an UltraFace-RFB .onnx (NULL and no blob -> the reference's cache path
+   *     $XDG_CACHE_HOME|~/.cache /infercam_onnx/ultraface-RFB-{640,320}.onnx, nn.rs:144-156);
+   * (b) weights/weights_floats: packed f32 blob, for each of the 52 convs w[cout][cin/g][k][k]
+   *     then b[cout], BatchNorm folded (273 888 floats); priors (K*4, cx cy w h) optional. */
+  const char* weights_path;
+  const float* weights;
+  size_t weights_floats;
+  const float* priors;
+  size_t priors_floats;
+} ufd_config;
+
+#define UFD_FLAG_KEEP_LAYERS 1u /* keep every conv output resident for ufd_debug_layer_output */
+#define UFD_FLAG_PROFILE 2u     /* record HIP events around every kernel (ufd_profile_read) */
+
+/* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
+int ufd_create(const ufd_config* cfg, ufd_model** out);
+void ufd_destroy(ufd_model* m);
+/* Message for the last failing call on this handle (or on creation when m == NULL). */
+const char* ufd_last_error(const ufd_model* m);
+/* UltrafaceVariant::width_height (nn.rs:36-41) and K (number of priors) of the loaded model. */
+int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32_t* num_priors);
+
+/* InferModel::run(&self, input: &RgbImage) -> Result<Vec<(Bbox, f32)>> (nn.rs:24-26,178-186).
+ * rgb: interleaved RGB8, `pitch` bytes per row (>= 3*w), any w x h up to the create-time limit.
+ * out[cap] receives detections in descending confidence; *n = number found. */
+int ufd_infer_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, ufd_det* out,
+                  uint32_t cap, uint32_t* n);
+
+/* Inferer::run lines inferer.rs:35-37: turbojpeg::decompress_image(jpeg) then infer_faces(&image).
+ * img_w/img_h (optional) receive the JPEG's own frame size. */
+int ufd_infer_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, ufd_det* out, uint32_t cap, uint32_t* n,
+                   uint32_t* img_w, uint32_t* img_h);
+
+/* The same step for `count` (<= max_batch) independent frames in one pass (one GPU worker
+ * replacing the single Inferer task, inferer.rs:29-50).  out: count*cap entries, frame i at
+ * out + i*cap; n[count]; status[count] per-frame status (a corrupt frame is skipped, the
+ * others still run).  Returns UFD_OK if the batch ran (inspect status[]), <0 if nothing ran. */
+int ufd_infer_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                         ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status);
+
+/* Same for `count` equally sized RGB frames laid out back to back (frame stride = h*pitch). */
+int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t count,
+                        ufd_det* out, uint32_t cap, uint32_t* n);
+
+/* Asynchronous form (the 10-slot StaticImage ring of lib.rs:32-37 becomes `slots` in-flight
+ * batches): ufd_submit_jpeg_batch copies/entropy-decodes on host workers and enqueues the GPU
+ * work on the handle's stream, returning a ticket; ufd_wait blocks until that batch is done
+ * and fills the outputs given at submit.  Input and output buffers must stay valid until then. */
+#define UFD_MAX_SLOTS 4
+int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                          ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket);
+int ufd_wait(ufd_model* m, uint32_t ticket);
+
+/* ---- stage taps (parity tests call the path stage by stage through these) ---- */
+/* A1 only: decode on the GPU and copy the interleaved RGB8 frame back (cap_bytes >= h*w*3). */
+int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes,
+                          uint32_t* w, uint32_t* h);
+/* A2-A4 only: resize + normalize on the GPU; out = [3][H][W] f32 of the model size. */
+int ufd_debug_preproc_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, float* out_nchw);
+/* A6 only: `count` pre-normalised inputs [count][3][H][W] -> scores [count][K][2], boxes [count][K][4]. */
+int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, float* scores, float* boxes);
+/* Output of conv `layer` (0..51, post activation; 24 = RFB block output) for frame `frame` of the
+ * last forward; needs UFD_FLAG_KEEP_LAYERS.  *floats = cout*oh*ow. */
+int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats,
+                           size_t* floats);
+/* A7-A10 only: threshold + sort + NMS on caller-provided raw outputs of `count` frames. */
+int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, uint32_t count, ufd_det* out,
+                       uint32_t cap, uint32_t* n);
+
+/* Host half of A1 alone (no GPU needed): marker parse + Huffman decode to quantised DCT
+ * coefficients, int16 natural order, laid out [component][block_row][block_col][64] with block
+ * counts padded to whole MCUs.  *n_i16 = total int16 count. */
+int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, size_t cap_i16, uint32_t* n_i16,
+                                uint32_t* w, uint32_t* h);
+
+/* ---- measurement (bench.py roofline): per-kernel device time from HIP events on the handle's
+ * stream; needs UFD_FLAG_PROFILE.  ufd_profile_reset() zeroes the accumulators. */
+typedef struct ufd_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+  double bytes; /* algorithmic bytes moved by those launches (inputs + outputs + weights) */
+  double flops; /* algorithmic FLOPs of those launches */
+} ufd_kernel_stat;
+int ufd_profile_reset(ufd_model* m);
+int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFD_H */

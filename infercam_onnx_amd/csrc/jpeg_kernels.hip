@@ -1,0 +1,309 @@
+// jpeg_kernels.hip -- device half of row A1 (turbojpeg::decompress_image, inferer.rs:35):
+// dequantisation + accurate integer IDCT (libjpeg "islow"), fancy chroma upsampling and the
+// libjpeg fixed-point YCbCr->RGB conversion, bit-exact with libjpeg-turbo's defaults
+// (tjDecompress2 flags = 0).  Integer/byte work, HBM-bound: 16-byte coalesced coefficient
+// loads staged through LDS, 8-byte row stores, no matrix cores.
+#include "kernels.hpp"
+
+namespace ufd {
+namespace {
+
+constexpr int kBlocksPerWG = 32;  // 32 DCT blocks (4 KiB of coefficients) per 256-thread workgroup
+constexpr int kWsStride = 65;     // padded LDS row so that pass-2 lanes (one block each) hit distinct banks
+
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// libjpeg post-IDCT range-limit table: index (x & 1023) into {128..255, 255 x384, 0 x384, 0..127}
+__device__ __forceinline__ unsigned range_limit(int x) {
+  int i = x & 1023;
+  return i < 128 ? i + 128 : (i < 512 ? 255 : (i < 896 ? 0 : i - 896));
+}
+
+// one 1-D pass of the islow IDCT on 8 inputs (already dequantised / from the workspace)
+__device__ __forceinline__ void idct_1d(const int (&x)[8], int (&o)[8], int shift) {
+  int z2 = x[2], z3 = x[6];
+  int z1 = (z2 + z3) * FIX_0_541196100;
+  int tmp2 = z1 + z3 * (-FIX_1_847759065);
+  int tmp3 = z1 + z2 * FIX_0_765366865;
+  int tmp0 = (x[0] + x[4]) * 8192;
+  int tmp1 = (x[0] - x[4]) * 8192;
+  int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = x[7];
+  tmp1 = x[5];
+  tmp2 = x[3];
+  tmp3 = x[1];
+  z1 = tmp0 + tmp3;
+  z2 = tmp1 + tmp2;
+  z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  int z5 = (z3 + z4) * FIX_1_175875602;
+  tmp0 *= FIX_0_298631336;
+  tmp1 *= FIX_2_053119869;
+  tmp2 *= FIX_3_072711026;
+  tmp3 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223;
+  z2 *= -FIX_2_562915447;
+  z3 *= -FIX_1_961570560;
+  z4 *= -FIX_0_390180644;
+  z3 += z5;
+  z4 += z5;
+  tmp0 += z1 + z3;
+  tmp1 += z2 + z4;
+  tmp2 += z2 + z3;
+  tmp3 += z1 + z4;
+  o[0] = descale(tmp10 + tmp3, shift);
+  o[7] = descale(tmp10 - tmp3, shift);
+  o[1] = descale(tmp11 + tmp2, shift);
+  o[6] = descale(tmp11 - tmp2, shift);
+  o[2] = descale(tmp12 + tmp1, shift);
+  o[5] = descale(tmp12 - tmp1, shift);
+  o[3] = descale(tmp13 + tmp0, shift);
+  o[4] = descale(tmp13 - tmp0, shift);
+}
+
+__global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ descs, const int16_t* __restrict__ coef,
+                                              size_t coef_stride, uint8_t* __restrict__ planes, size_t plane_stride) {
+  __shared__ __attribute__((aligned(16))) int16_t s_in[kBlocksPerWG * 64];
+  __shared__ int s_ws[kBlocksPerWG * kWsStride];
+  const int frame = blockIdx.y;
+  const JpegFrameDesc& d = descs[frame];
+  const uint32_t g0 = blockIdx.x * kBlocksPerWG;
+  const uint32_t total = d.total_blocks;
+  if (g0 >= total) return;  // whole workgroup exits together
+  const int nblk = min((uint32_t)kBlocksPerWG, total - g0);
+  const int tid = threadIdx.x;
+  const int16_t* src = coef + (size_t)frame * coef_stride + (size_t)g0 * 64;
+  if (tid * 8 < nblk * 64) {
+    *reinterpret_cast<uint4*>(&s_in[tid * 8]) = *reinterpret_cast<const uint4*>(src + tid * 8);
+  }
+  __syncthreads();
+  // pass 1: columns.  thread -> (local block, column)
+  {
+    const int lb = tid >> 3, c = tid & 7;
+    if (lb < nblk) {
+      const uint32_t g = g0 + lb;
+      const int comp = (d.ncomp > 1 && g * 64 >= d.coef_off[1]) ? ((g * 64 >= d.coef_off[2]) ? 2 : 1) : 0;
+      const uint16_t* q = d.qt[comp];
+      int x[8], o[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) x[r] = (int)s_in[lb * 64 + r * 8 + c] * (int)q[r * 8 + c];
+      idct_1d(x, o, 11);  // CONST_BITS - PASS1_BITS
+#pragma unroll
+      for (int r = 0; r < 8; r++) s_ws[lb * kWsStride + r * 8 + c] = o[r];
+    }
+  }
+  __syncthreads();
+  // pass 2: rows.  thread -> (row, local block): a wave covers 2 rows x 32 neighbouring blocks
+  {
+    const int lb = tid & 31, r = tid >> 5;
+    if (lb < nblk) {
+      const uint32_t g = g0 + lb;
+      const int comp = (d.ncomp > 1 && g * 64 >= d.coef_off[1]) ? ((g * 64 >= d.coef_off[2]) ? 2 : 1) : 0;
+      const uint32_t local = g - d.coef_off[comp] / 64;
+      const uint32_t wb = d.wblk[comp];
+      const uint32_t by = local / wb, bx = local - by * wb;
+      int x[8], o[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = s_ws[lb * kWsStride + r * 8 + j];
+      idct_1d(x, o, 18);  // CONST_BITS + PASS1_BITS + 3
+      uint2 v;
+      v.x = range_limit(o[0]) | (range_limit(o[1]) << 8) | (range_limit(o[2]) << 16) | (range_limit(o[3]) << 24);
+      v.y = range_limit(o[4]) | (range_limit(o[5]) << 8) | (range_limit(o[6]) << 16) | (range_limit(o[7]) << 24);
+      uint8_t* dst = planes + (size_t)frame * plane_stride + d.plane_off[comp] + (size_t)(by * 8 + r) * (wb * 8) + bx * 8;
+      *reinterpret_cast<uint2*>(dst) = v;
+    }
+  }
+}
+
+// ---- jdsample.c: value of component `c` at full-resolution pixels x0..x0+3 of row y ----
+__device__ __forceinline__ void upsample4(const JpegFrameDesc& d, const uint8_t* __restrict__ fplanes, int c, int x0,
+                                          int y, int (&out)[4]) {
+  const uint8_t* pl = fplanes + d.plane_off[c];
+  const int pitch = d.wblk[c] * 8;
+  const int hx = d.hmax / d.h[c], vx = d.vmax / d.v[c];
+  const int dw = d.dw[c], dh = d.dh[c];
+  if (hx == 1 && vx == 1) {
+    const uint8_t* row = pl + (size_t)y * pitch;
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = row[min(x0 + j, pitch - 1)];
+    return;
+  }
+  const bool fancy = dw > 2;  // jdsample.c: fancy upsampling only when downsampled_width > 2
+  if (hx == 2 && vx == 1) {
+    const uint8_t* row = pl + (size_t)y * pitch;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int x = x0 + j, i = min(x >> 1, dw - 1);
+      const int cur = row[i];
+      int v;
+      if (!fancy) {
+        v = cur;
+      } else if (x & 1) {
+        v = (i == dw - 1) ? cur : (cur * 3 + row[i + 1] + 2) >> 2;
+      } else {
+        v = (i == 0) ? cur : (cur * 3 + row[i - 1] + 1) >> 2;
+      }
+      out[j] = v;
+    }
+    return;
+  }
+  if (hx == 2 && vx == 2) {
+    const int iy = y >> 1;
+    const int ny = max(0, min(dh - 1, (y & 1) ? iy + 1 : iy - 1));
+    const uint8_t* r0 = pl + (size_t)iy * pitch;
+    const uint8_t* r1 = pl + (size_t)ny * pitch;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int x = x0 + j, i = min(x >> 1, dw - 1);
+      int v;
+      if (!fancy) {
+        v = r0[i];
+      } else {
+        const int cur = r0[i] * 3 + r1[i];
+        if (x & 1) {
+          v = (i == dw - 1) ? (cur * 4 + 7) >> 4 : (cur * 3 + (r0[i + 1] * 3 + r1[i + 1]) + 7) >> 4;
+        } else {
+          v = (i == 0) ? (cur * 4 + 8) >> 4 : (cur * 3 + (r0[i - 1] * 3 + r1[i - 1]) + 8) >> 4;
+        }
+      }
+      out[j] = v;
+    }
+    return;
+  }
+  {  // hx == 1, vx == 2 (4:4:0): h1v2 fancy
+    const int iy = y >> 1;
+    const int ny = max(0, min(dh - 1, (y & 1) ? iy + 1 : iy - 1));
+    const uint8_t* r0 = pl + (size_t)iy * pitch;
+    const uint8_t* r1 = pl + (size_t)ny * pitch;
+    const int bias = (y & 1) ? 2 : 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = min(x0 + j, pitch - 1);
+      out[j] = (r0[i] * 3 + r1[i] + bias) >> 2;
+    }
+  }
+}
+
+__device__ __forceinline__ int clamp255(int v) { return min(255, max(0, v)); }
+
+// -> r,g,b for 4 pixels (jdcolor.c ycc_rgb_convert fixed point, SCALEBITS 16)
+__device__ __forceinline__ void pixels4(const JpegFrameDesc& d, const uint8_t* __restrict__ fplanes, int x0, int y,
+                                        int (&r)[4], int (&g)[4], int (&b)[4]) {
+  int c0[4];
+  upsample4(d, fplanes, 0, x0, y, c0);
+  if (d.color == kColorGray) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = g[j] = b[j] = c0[j];
+    return;
+  }
+  int c1[4], c2[4];
+  upsample4(d, fplanes, 1, x0, y, c1);
+  upsample4(d, fplanes, 2, x0, y, c2);
+  if (d.color == kColorRGB) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = c0[j], g[j] = c1[j], b[j] = c2[j];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int yy = c0[j], cb = c1[j] - 128, cr = c2[j] - 128;
+    r[j] = clamp255(yy + ((91881 * cr + 32768) >> 16));
+    g[j] = clamp255(yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+    b[j] = clamp255(yy + ((116130 * cb + 32768) >> 16));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_upsample_rgb(const JpegFrameDesc* __restrict__ descs,
+                                                      const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                      uint8_t* __restrict__ rgb, size_t rgb_stride) {
+  const int frame = blockIdx.z;
+  const JpegFrameDesc& d = descs[frame];
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (y >= d.height || x0 >= d.width) return;
+  int r[4], g[4], b[4];
+  pixels4(d, planes + (size_t)frame * plane_stride, x0, y, r, g, b);
+  uint8_t* o = rgb + (size_t)frame * rgb_stride + ((size_t)y * d.width + x0) * 3;
+  if (x0 + 4 <= d.width && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
+    uint32_t w0 = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
+    uint32_t w1 = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
+    uint32_t w2 = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+    o32[0] = w0;
+    o32[1] = w1;
+    o32[2] = w2;
+  } else {
+    for (int j = 0; j < 4 && x0 + j < d.width; j++) {
+      o[3 * j] = (uint8_t)r[j];
+      o[3 * j + 1] = (uint8_t)g[j];
+      o[3 * j + 2] = (uint8_t)b[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_upsample_norm(const JpegFrameDesc* __restrict__ descs,
+                                                       const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                       const float* __restrict__ lut, float* __restrict__ out, int W,
+                                                       int H) {
+  const int frame = blockIdx.z;
+  const JpegFrameDesc& d = descs[frame];
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (y >= H || x0 >= W) return;
+  int r[4], g[4], b[4];
+  pixels4(d, planes + (size_t)frame * plane_stride, x0, y, r, g, b);
+  const size_t hw = (size_t)W * H;
+  float* o = out + (size_t)frame * 3 * hw + (size_t)y * W + x0;
+  if (x0 + 4 <= W && (W & 3) == 0) {
+    *reinterpret_cast<float4*>(o) = make_float4(lut[r[0]], lut[r[1]], lut[r[2]], lut[r[3]]);
+    *reinterpret_cast<float4*>(o + hw) = make_float4(lut[256 + g[0]], lut[256 + g[1]], lut[256 + g[2]], lut[256 + g[3]]);
+    *reinterpret_cast<float4*>(o + 2 * hw) =
+        make_float4(lut[512 + b[0]], lut[512 + b[1]], lut[512 + b[2]], lut[512 + b[3]]);
+  } else {
+    for (int j = 0; j < 4 && x0 + j < W; j++) {
+      o[j] = lut[r[j]];
+      o[hw + j] = lut[256 + g[j]];
+      o[2 * hw + j] = lut[512 + b[j]];
+    }
+  }
+}
+
+}  // namespace
+
+void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, hipStream_t s) {
+  if (!count || !max_blocks) return;
+  dim3 grid((max_blocks + kBlocksPerWG - 1) / kBlocksPerWG, count);
+  hipLaunchKernelGGL(k_idct, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
+}
+
+void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
+                         size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s) {
+  if (!count) return;
+  dim3 grid((max_w + 1023) / 1024, max_h, count);
+  hipLaunchKernelGGL(k_upsample_rgb, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
+}
+
+void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
+                          const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count,
+                          hipStream_t s) {
+  if (!count) return;
+  dim3 grid((W + 1023) / 1024, H, count);
+  hipLaunchKernelGGL(k_upsample_norm, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
+                     (int)W, (int)H);
+}
+
+}  // namespace ufd

@@ -1,0 +1,82 @@
+// kernels.hpp -- launchers of the gfx950 HIP kernels of the hot path (one per stage row of
+// SURVEY.md section 8a).  Host code (model.cpp) only sees these plain C++ signatures.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "jpeg_host.hpp"
+
+namespace ufd {
+
+// ---------------- A1: JPEG reconstruction (jpeg_kernels.hip) ----------------
+// Dequantise + ISLOW IDCT of every 8x8 block of `count` frames into u8 sample planes.
+void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, hipStream_t s);
+// Fancy upsampling + colour conversion -> interleaved RGB8 (pitch 3*width, frame stride rgb_stride).
+void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
+                         size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s);
+// Same, fused with the A4 normalisation for frames that already have the model size:
+// -> f32 [count][3][H][W].  norm_lut: [3][256].
+void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
+                          const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count, hipStream_t s);
+
+// ---------------- A2-A4: Triangle resize + normalise (preproc_kernels.hip) ----------------
+struct ResizeTaps {          // device pointers, one table per axis
+  const int32_t* left;       // [D]
+  const int32_t* cnt;        // [D]
+  const float* w;            // [D][stride]
+  int32_t stride;
+};
+// src: [count] frames of sh x sw RGB8 (row pitch, frame stride src_stride) -> f32 [count][3][dh][dw].
+void launch_resize_norm(const uint8_t* d_src, uint32_t sw, uint32_t sh, uint32_t pitch, size_t src_stride,
+                        ResizeTaps vert, ResizeTaps horz, const float* d_norm_lut, float* d_out, uint32_t dw,
+                        uint32_t dh, uint32_t count, hipStream_t s);
+// same-size frames: normalise only.
+void launch_norm_only(const uint8_t* d_src, uint32_t w, uint32_t h, uint32_t pitch, size_t src_stride,
+                      const float* d_norm_lut, float* d_out, uint32_t count, hipStream_t s);
+
+// ---------------- A6: convolutions (conv_kernels.hip) ----------------
+struct ConvArgs {
+  const float* in;    // [B][in_ctotal][ih][iw]
+  const float* w;     // layer weights, kernel-specific packing
+  const float* bias;  // [cout]
+  float* out;         // [B][out_ctotal][oh][ow], written at channel offset out_coff
+  const float* res;   // optional residual [B][cout][oh][ow]: out = relu(conv + res)
+  int32_t B, cin, cout, ih, iw, oh, ow;
+  int32_t k, stride, pad, dil, depthwise, relu;
+  int32_t in_ctotal, out_ctotal, out_coff;
+};
+// Reference-order direct convolution (any layer).  w: [cout][cin/g][k][k].
+void launch_conv_direct(const ConvArgs& a, hipStream_t s);
+// Pointwise 1x1 on fp32 MFMA.  w: packed by pack_pointwise_weights().
+void launch_conv_pointwise_mfma(const ConvArgs& a, hipStream_t s);
+// floats needed for the packed pointwise weight image of a cin->cout layer
+size_t pointwise_packed_floats(int cin, int cout);
+void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, float* packed);
+
+// ---------------- A6 tail + A7: softmax, prior decode, threshold (post_kernels.hip) ----------------
+struct HeadArgs {
+  const float* cls[4];  // [B][A*2][fh][fw]
+  const float* reg[4];  // [B][A*4][fh][fw]
+  int32_t plane[4];     // fh*fw
+  int32_t anchors[4];
+  int32_t base[5];      // first prior index of each head; base[4] = K
+};
+// scores [B][K][2], boxes [B][K][4]; candidates conf > min_conf appended to keys[B][key_stride] / counts[B].
+void launch_head_decode(const HeadArgs& h, const float* d_priors, uint32_t B, float min_conf, float* d_scores,
+                        float* d_boxes, unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts,
+                        hipStream_t s);
+// threshold only, for caller-provided raw outputs (ufd_debug_postproc)
+void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_conf, unsigned long long* d_keys,
+                      size_t key_stride, uint32_t* d_counts, hipStream_t s);
+// ---------------- A8-A10: sort + greedy NMS, one workgroup per frame ----------------
+struct Det {
+  float x_tl, y_tl, x_br, y_br, conf;
+};
+void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
+                     uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
+                     uint32_t B, hipStream_t s);
+
+}  // namespace ufd

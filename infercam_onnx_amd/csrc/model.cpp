@@ -1,0 +1,1103 @@
+// model.cpp -- host side of libufacehip.so: the C ABI of include/ufd.h and the per-batch
+// pipeline that replaces the reference's single Inferer task (infer_server/src/inferer.rs:29-50):
+//   host workers: marker parse + Huffman decode -> coefficient slabs in pinned memory
+//   GPU (one HIP stream per handle): IDCT -> upsample/colour(+normalise) [-> Triangle resize]
+//        -> 52 convolutions -> softmax/prior decode/threshold -> sort + greedy NMS
+//   D2H: a few hundred bytes of detections per frame.
+// Weights (1.1 MB) and priors stay resident in HBM for the life of the handle.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ufd.h"
+#include "jpeg_host.hpp"
+#include "kernels.hpp"
+#include "onnx_loader.hpp"
+#include "thread_pool.hpp"
+#include "topology.hpp"
+
+namespace ufd {
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+  size_t off = 0;  // float offset in the activation arena (for the whole batch)
+  int c = 0, h = 0, w = 0;
+  size_t per_frame() const { return (size_t)c * h * w; }
+};
+
+struct Layer {
+  ConvSpec spec;
+  int ih, iw, oh, ow;
+  int in_tensor, out_tensor, res_tensor;
+  int out_coff;
+  bool pointwise;
+  const float* d_w = nullptr;
+  const float* d_b = nullptr;
+  double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
+};
+
+struct ProfEntry {
+  int name_id;
+  hipEvent_t e0, e1;
+  double bytes, flops;
+};
+
+struct Slot {
+  bool busy = false;
+  uint32_t ticket = 0, count = 0, cap = 0;
+  JpegFrameDesc* h_descs = nullptr;
+  int16_t* h_coef = nullptr;
+  Det* h_dets = nullptr;
+  uint32_t* h_ndet = nullptr;
+  ufd_det* out = nullptr;
+  uint32_t* n = nullptr;
+  int32_t* status = nullptr;
+  std::vector<int32_t> st;
+  hipEvent_t done = nullptr;
+};
+
+constexpr uint32_t kDetCopy = 256;  // detections per frame copied back with the batch
+
+struct TapsDev {
+  int32_t* left = nullptr;
+  int32_t* cnt = nullptr;
+  float* w = nullptr;
+  int stride = 0;
+};
+
+}  // namespace
+}  // namespace ufd
+
+using namespace ufd;
+
+struct ufd_model {
+  std::mutex mu;
+  std::string err;
+  ufd_config cfg{};
+  int W = 0, H = 0, K = 0;
+  uint32_t B = 0;
+  uint32_t max_w = 0, max_h = 0;
+  hipStream_t stream = nullptr;
+  std::unique_ptr<ThreadPool> pool;
+
+  // resident model
+  float* d_weights = nullptr;
+  float* d_priors = nullptr;
+  float* d_lut = nullptr;
+  std::vector<Layer> layers;
+  std::vector<Tensor> tensors;
+  size_t arena_floats = 0;
+  float* d_arena = nullptr;
+  float* d_input = nullptr;
+
+  // frame staging (device)
+  size_t coef_stride = 0, plane_stride = 0, rgb_stride = 0;
+  JpegFrameDesc* d_descs = nullptr;
+  int16_t* d_coef = nullptr;
+  uint8_t* d_planes = nullptr;
+  uint8_t* d_rgb = nullptr;
+
+  // post
+  float* d_scores = nullptr;
+  float* d_boxes = nullptr;
+  unsigned long long* d_keys = nullptr;
+  size_t key_stride = 0;
+  uint32_t* d_counts = nullptr;
+  Det* d_dets = nullptr;
+  uint32_t* d_ndet = nullptr;
+  float4* d_spill = nullptr;
+
+  Slot slots[UFD_MAX_SLOTS];
+  uint32_t next_ticket = 1;
+  uint32_t last_forward_count = 0;
+
+  std::map<std::pair<int, int>, std::pair<TapsDev, TapsDev>> taps;
+
+  // profiling
+  bool profile = false;
+  std::vector<std::string> prof_names;
+  std::vector<ufd_kernel_stat> prof_stats;
+  std::vector<ProfEntry> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIPC(m, expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return (m)->fail(UFD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+
+// ---------------------------------------------------------------- profiling
+int prof_name_id(ufd_model* m, const std::string& name) {
+  for (size_t i = 0; i < m->prof_names.size(); i++)
+    if (m->prof_names[i] == name) return (int)i;
+  m->prof_names.push_back(name);
+  ufd_kernel_stat st;
+  std::memset(&st, 0, sizeof(st));
+  std::snprintf(st.name, sizeof(st.name), "%s", name.c_str());
+  m->prof_stats.push_back(st);
+  return (int)m->prof_names.size() - 1;
+}
+
+hipEvent_t prof_event(ufd_model* m) {
+  if (!m->prof_free.empty()) {
+    hipEvent_t e = m->prof_free.back();
+    m->prof_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  ufd_model* m;
+  ProfEntry pe;
+  bool on;
+  ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops) : m(mm), on(mm->profile) {
+    if (!on) return;
+    pe.name_id = prof_name_id(m, name);
+    pe.bytes = bytes;
+    pe.flops = flops;
+    pe.e0 = prof_event(m);
+    pe.e1 = prof_event(m);
+    (void)hipEventRecord(pe.e0, m->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(pe.e1, m->stream);
+    m->prof_pending.push_back(pe);
+  }
+};
+
+void prof_flush(ufd_model* m) {
+  for (auto& pe : m->prof_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+      auto& st = m->prof_stats[pe.name_id];
+      st.launches++;
+      st.total_ms += ms;
+      st.bytes += pe.bytes;
+      st.flops += pe.flops;
+    }
+    m->prof_free.push_back(pe.e0);
+    m->prof_free.push_back(pe.e1);
+  }
+  m->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------- model construction
+void gen_priors(int W, int H, std::vector<float>& out) {
+  // upstream generate_priors: float64 arithmetic, cast to f32, clamp to [0, 1]
+  out.clear();
+  for (int idx = 0; idx < 4; idx++) {
+    int fw = (W + kStrides[idx] - 1) / kStrides[idx], fh = (H + kStrides[idx] - 1) / kStrides[idx];
+    double shrink_w = (double)W / fw, shrink_h = (double)H / fh;
+    double scale_w = (double)W / shrink_w, scale_h = (double)H / shrink_h;
+    for (int j = 0; j < fh; j++)
+      for (int i = 0; i < fw; i++) {
+        double xc = (i + 0.5) / scale_w, yc = (j + 0.5) / scale_h;
+        for (int a = 0; a < kHeadAnchors[idx]; a++) {
+          double v[4] = {xc, yc, kMinBoxes[idx][a] / W, kMinBoxes[idx][a] / H};
+          for (double x : v) {
+            float f = (float)x;
+            out.push_back(f < 0.f ? 0.f : (f > 1.f ? 1.f : f));
+          }
+        }
+      }
+  }
+}
+
+// Liveness-based arena: every conv output gets [B][c][h][w]; buffers are recycled after their
+// last reader unless UFD_FLAG_KEEP_LAYERS asks to keep all of them for ufd_debug_layer_output.
+void plan_tensors(ufd_model* m, bool keep_all) {
+  const ConvSpec* specs = conv_specs();
+  m->layers.resize(kNumConv);
+  m->tensors.clear();
+  std::vector<int> tensor_of(kNumConv, -1);
+  int cat_tensor = -1;
+  for (int i = 0; i < kNumConv; i++) {
+    Layer& L = m->layers[i];
+    L.spec = specs[i];
+    if (L.spec.src == -1) {
+      L.ih = m->H, L.iw = m->W;
+      L.in_tensor = -1;
+    } else if (L.spec.src == -2) {
+      L.ih = m->layers[kRfbCatA].oh, L.iw = m->layers[kRfbCatA].ow;
+      L.in_tensor = cat_tensor;
+    } else {
+      L.ih = m->layers[L.spec.src].oh, L.iw = m->layers[L.spec.src].ow;
+      L.in_tensor = tensor_of[L.spec.src];
+    }
+    L.oh = conv_out_dim(L.ih, L.spec);
+    L.ow = conv_out_dim(L.iw, L.spec);
+    L.pointwise = (L.spec.k == 1 && L.spec.groups == 1);
+    L.res_tensor = (i == kRfbShortcut) ? tensor_of[kRfbLinear] : -1;
+    L.out_coff = 0;
+    if (i == kRfbCatA || i == kRfbCatB || i == kRfbCatC) {
+      if (cat_tensor < 0) {
+        Tensor t;
+        t.c = 48, t.h = L.oh, t.w = L.ow;
+        m->tensors.push_back(t);
+        cat_tensor = (int)m->tensors.size() - 1;
+      }
+      L.out_tensor = cat_tensor;
+      L.out_coff = (i == kRfbCatA) ? 0 : (i == kRfbCatB ? 16 : 32);
+    } else {
+      Tensor t;
+      t.c = L.spec.cout, t.h = L.oh, t.w = L.ow;
+      m->tensors.push_back(t);
+      L.out_tensor = (int)m->tensors.size() - 1;
+    }
+    tensor_of[i] = L.out_tensor;
+    const double in_b = (double)L.spec.cin * L.ih * L.iw * 4, out_b = (double)L.spec.cout * L.oh * L.ow * 4;
+    L.weight_bytes = (double)(conv_weight_floats(L.spec) + L.spec.cout) * 4;
+    L.bytes_per_frame = in_b + out_b + (L.res_tensor >= 0 ? out_b : 0);
+    L.flops_per_frame = 2.0 * L.oh * L.ow * L.spec.cout * (L.spec.cin / L.spec.groups) * L.spec.k * L.spec.k;
+  }
+  // liveness: first writer, last reader (head outputs live until the decode kernel)
+  const int nt = (int)m->tensors.size();
+  std::vector<int> first(nt, kNumConv), last(nt, -1);
+  for (int i = 0; i < kNumConv; i++) {
+    const Layer& L = m->layers[i];
+    first[L.out_tensor] = std::min(first[L.out_tensor], i);
+    last[L.out_tensor] = std::max(last[L.out_tensor], i);
+    if (L.in_tensor >= 0) last[L.in_tensor] = std::max(last[L.in_tensor], i);
+    if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], i);
+  }
+  for (int h = 0; h < 4; h++) {
+    last[tensor_of[kHeadCls[h]]] = kNumConv;
+    last[tensor_of[kHeadReg[h]]] = kNumConv;
+  }
+  struct Blk {
+    size_t off, size;
+  };
+  std::vector<Blk> free_list;
+  size_t top = 0;
+  auto align = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  auto allocate = [&](int t) {
+    const size_t need = align(m->tensors[t].per_frame() * m->B);
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < free_list.size(); i++)
+      if (free_list[i].size >= need && (best == (size_t)-1 || free_list[i].size < free_list[best].size)) best = i;
+    if (best != (size_t)-1) {
+      m->tensors[t].off = free_list[best].off;
+      if (free_list[best].size > need) {
+        free_list[best].off += need;
+        free_list[best].size -= need;
+      } else {
+        free_list.erase(free_list.begin() + best);
+      }
+    } else {
+      m->tensors[t].off = top;
+      top += need;
+    }
+  };
+  for (int i = 0; i < kNumConv; i++) {
+    const int t = m->layers[i].out_tensor;
+    if (first[t] == i) allocate(t);
+    // a buffer is recycled only after the layer that reads it last has been issued, so a
+    // layer's output never aliases its own inputs
+    if (!keep_all)
+      for (int u = 0; u < nt; u++)
+        if (last[u] == i) free_list.push_back({m->tensors[u].off, align(m->tensors[u].per_frame() * m->B)});
+  }
+  m->arena_floats = top;
+}
+
+int upload_weights(ufd_model* m, const float* blob) {
+  const ConvSpec* specs = conv_specs();
+  std::vector<float> img;
+  std::vector<size_t> w_off(kNumConv), b_off(kNumConv);
+  const float* p = blob;
+  for (int i = 0; i < kNumConv; i++) {
+    const ConvSpec& s = specs[i];
+    const size_t nw = conv_weight_floats(s);
+    while (img.size() % 64) img.push_back(0.f);
+    w_off[i] = img.size();
+    if (m->layers[i].pointwise) {
+      const size_t np = pointwise_packed_floats(s.cin, s.cout);
+      img.resize(img.size() + np);
+      pack_pointwise_weights(p, s.cin, s.cout, img.data() + w_off[i]);
+    } else {
+      img.insert(img.end(), p, p + nw);
+    }
+    p += nw;
+    while (img.size() % 64) img.push_back(0.f);
+    b_off[i] = img.size();
+    img.insert(img.end(), p, p + s.cout);
+    p += s.cout;
+  }
+  HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
+  HIPC(m, hipMemcpy(m->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (int i = 0; i < kNumConv; i++) {
+    m->layers[i].d_w = m->d_weights + w_off[i];
+    m->layers[i].d_b = m->d_weights + b_off[i];
+  }
+  return UFD_OK;
+}
+
+int alloc_slot(ufd_model* m, Slot& s) {
+  if (s.h_descs) return UFD_OK;
+  HIPC(m, hipHostMalloc(&s.h_descs, sizeof(JpegFrameDesc) * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_coef, sizeof(int16_t) * m->coef_stride * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
+  HIPC(m, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  s.st.resize(m->B);
+  return UFD_OK;
+}
+
+// ---------------------------------------------------------------- resize taps (image 0.24.5 sample.rs)
+float tri_kernel(float x) {
+  float a = std::fabs(x);
+  return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
+int build_axis_taps(ufd_model* m, int S, int D, TapsDev* out) {
+  const float ratio = (float)S / (float)D;
+  const float sratio = ratio < 1.0f ? 1.0f : ratio;
+  const float support = 1.0f * sratio;
+  std::vector<int32_t> left(D), cnt(D);
+  std::vector<std::vector<float>> ws(D);
+  int maxn = 1;
+  for (int o = 0; o < D; o++) {
+    float in = ((float)o + 0.5f) * ratio;
+    long l = (long)std::floor(in - support);
+    l = std::max(0L, std::min(l, (long)S - 1));
+    long r = (long)std::ceil(in + support);
+    r = std::max(l + 1, std::min(r, (long)S));
+    in = in - 0.5f;
+    float sum = 0.0f;
+    for (long i = l; i < r; i++) {
+      float w = tri_kernel(((float)i - in) / sratio);
+      ws[o].push_back(w);
+      sum += w;
+    }
+    for (float& w : ws[o]) w /= sum;
+    left[o] = (int32_t)l;
+    cnt[o] = (int32_t)ws[o].size();
+    maxn = std::max(maxn, (int)ws[o].size());
+  }
+  std::vector<float> flat((size_t)D * maxn, 0.0f);
+  for (int o = 0; o < D; o++) std::copy(ws[o].begin(), ws[o].end(), flat.begin() + (size_t)o * maxn);
+  HIPC(m, hipMalloc(&out->left, sizeof(int32_t) * D));
+  HIPC(m, hipMalloc(&out->cnt, sizeof(int32_t) * D));
+  HIPC(m, hipMalloc(&out->w, sizeof(float) * flat.size()));
+  HIPC(m, hipMemcpy(out->left, left.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice));
+  HIPC(m, hipMemcpy(out->cnt, cnt.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice));
+  HIPC(m, hipMemcpy(out->w, flat.data(), sizeof(float) * flat.size(), hipMemcpyHostToDevice));
+  out->stride = maxn;
+  return UFD_OK;
+}
+
+int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
+  auto key = std::make_pair(sw, sh);
+  auto it = m->taps.find(key);
+  if (it == m->taps.end()) {
+    std::pair<TapsDev, TapsDev> e;
+    int rc = build_axis_taps(m, sh, m->H, &e.first);
+    if (rc) return rc;
+    rc = build_axis_taps(m, sw, m->W, &e.second);
+    if (rc) return rc;
+    it = m->taps.emplace(key, e).first;
+  }
+  *vert = ResizeTaps{it->second.first.left, it->second.first.cnt, it->second.first.w, it->second.first.stride};
+  *horz = ResizeTaps{it->second.second.left, it->second.second.cnt, it->second.second.w, it->second.second.stride};
+  return UFD_OK;
+}
+
+// ---------------------------------------------------------------- GPU stages
+float* tensor_ptr(ufd_model* m, int t) { return m->d_arena + m->tensors[t].off; }
+
+// [count][3][H][W] in d_input -> scores/boxes/candidate keys
+void enqueue_forward(ufd_model* m, uint32_t count) {
+  for (int i = 0; i < kNumConv; i++) {
+    const Layer& L = m->layers[i];
+    ConvArgs a;
+    a.in = L.in_tensor < 0 ? m->d_input : tensor_ptr(m, L.in_tensor);
+    a.w = L.d_w;
+    a.bias = L.d_b;
+    a.out = tensor_ptr(m, L.out_tensor);
+    a.res = L.res_tensor >= 0 ? tensor_ptr(m, L.res_tensor) : nullptr;
+    a.B = (int)count;
+    a.cin = L.spec.cin, a.cout = L.spec.cout;
+    a.ih = L.ih, a.iw = L.iw, a.oh = L.oh, a.ow = L.ow;
+    a.k = L.spec.k, a.stride = L.spec.stride, a.pad = L.spec.pad, a.dil = L.spec.dil;
+    a.depthwise = L.spec.groups > 1;
+    a.relu = L.spec.relu || i == kRfbShortcut;
+    a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
+    a.out_ctotal = m->tensors[L.out_tensor].c;
+    a.out_coff = L.out_coff;
+    const char* kind = L.pointwise ? "conv_pointwise_mfma" : (a.depthwise ? "conv_direct_dw" : "conv_direct_full");
+    ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
+                 L.flops_per_frame * count);
+    if (L.pointwise)
+      launch_conv_pointwise_mfma(a, m->stream);
+    else
+      launch_conv_direct(a, m->stream);
+  }
+  m->last_forward_count = count;
+}
+
+void enqueue_heads(ufd_model* m, uint32_t count) {
+  HeadArgs h;
+  int base = 0;
+  for (int i = 0; i < 4; i++) {
+    const Layer& c = m->layers[kHeadCls[i]];
+    h.cls[i] = tensor_ptr(m, c.out_tensor);
+    h.reg[i] = tensor_ptr(m, m->layers[kHeadReg[i]].out_tensor);
+    h.plane[i] = c.oh * c.ow;
+    h.anchors[i] = kHeadAnchors[i];
+    h.base[i] = base;
+    base += h.plane[i] * kHeadAnchors[i];
+  }
+  h.base[4] = base;
+  (void)hipMemsetAsync(m->d_counts, 0, sizeof(uint32_t) * count, m->stream);
+  ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 6 + 4) * 4, 0);
+  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, m->d_scores, m->d_boxes, m->d_keys, m->key_stride,
+                     m->d_counts, m->stream);
+}
+
+void enqueue_nms(ufd_model* m, uint32_t count) {
+  ProfScope ps(m, "sort_nms", 0, 0);
+  launch_sort_nms(m->d_keys, m->key_stride, m->d_counts, m->d_boxes, m->K, m->cfg.max_iou, m->d_dets, m->K, m->d_ndet,
+                  m->d_spill, count, m->stream);
+}
+
+int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
+  HIPC(m, hipMemcpyAsync(s.h_ndet, m->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->stream));
+  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, m->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
+                           hipMemcpyDeviceToHost, m->stream));
+  HIPC(m, hipEventRecord(s.done, m->stream));
+  return UFD_OK;
+}
+
+// waits for the slot's batch and hands results to the caller's arrays
+int finish_slot(ufd_model* m, Slot& s) {
+  HIPC(m, hipEventSynchronize(s.done));
+  prof_flush(m);
+  int rc = UFD_OK;
+  for (uint32_t i = 0; i < s.count; i++) {
+    int32_t st = s.st[i];
+    uint32_t nd = 0;
+    if (st == UFD_OK) {
+      nd = s.h_ndet[i];
+      const uint32_t ncopy = std::min(nd, s.cap);
+      ufd_det* dst = s.out + (size_t)i * s.cap;
+      const uint32_t fast = std::min(ncopy, kDetCopy);
+      std::memcpy(dst, s.h_dets + (size_t)i * kDetCopy, sizeof(Det) * fast);
+      if (ncopy > fast) {  // rare: more than kDetCopy detections requested for one frame
+        HIPC(m, hipMemcpy(dst + fast, m->d_dets + (size_t)i * m->K + fast, sizeof(Det) * (ncopy - fast),
+                          hipMemcpyDeviceToHost));
+      }
+      if (nd > s.cap) st = UFD_E_TRUNCATED;
+    }
+    if (s.n) s.n[i] = nd;
+    if (s.status) s.status[i] = st;
+    if (st != UFD_OK && rc == UFD_OK && !s.status) rc = st;
+  }
+  s.busy = false;
+  return rc;
+}
+
+Slot* find_free_slot(ufd_model* m) {
+  for (auto& s : m->slots)
+    if (!s.busy) return &s;
+  return nullptr;
+}
+
+int check_outputs(ufd_model* m, const void* out, uint32_t cap, const void* n) {
+  if ((!out && cap) || !n) return m->fail(UFD_E_ARG, "null output pointer");
+  return UFD_OK;
+}
+
+// Host entropy decode of `count` JPEGs into the slot, then enqueue the whole GPU pipeline.
+int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
+  int rc = alloc_slot(m, s);
+  if (rc) return rc;
+  s.count = count;
+  m->pool->parallel_for(count, [&](unsigned i) {
+    JpegFrameDesc* d = &s.h_descs[i];
+    int st = (jpegs[i] && lens[i]) ? jpeg_decode_coefficients(jpegs[i], lens[i], d, s.h_coef + (size_t)i * m->coef_stride,
+                                                               m->coef_stride)
+                                   : kJpegCorrupt;
+    if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
+    if (st != kJpegOk) {
+      std::memset(d, 0, sizeof(*d));  // total_blocks = 0, width = 0: every kernel skips the frame
+    }
+    s.st[i] = st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : (st == kJpegUnsupported ? UFD_E_UNSUPPORTED : st));
+  });
+  uint32_t max_blocks = 0, mw = 0, mh = 0;
+  bool all_model_size = true;
+  bool any_ok = false;
+  for (uint32_t i = 0; i < count; i++) {
+    if (s.st[i] != UFD_OK) continue;
+    any_ok = true;
+    const JpegFrameDesc& d = s.h_descs[i];
+    max_blocks = std::max(max_blocks, d.total_blocks);
+    mw = std::max(mw, (uint32_t)d.width);
+    mh = std::max(mh, (uint32_t)d.height);
+    if (d.width != m->W || d.height != m->H) all_model_size = false;
+  }
+  if (any_ok) {
+    HIPC(m, hipMemcpyAsync(m->d_descs, s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, m->stream));
+    {
+      ProfScope ps(m, "h2d_coef", 0, 0);
+      // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
+      size_t used = 0;
+      for (uint32_t i = 0; i < count; i++) used = std::max(used, (size_t)s.h_descs[i].coef_total);
+      HIPC(m, hipMemcpy2DAsync(m->d_coef, m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
+                               hipMemcpyHostToDevice, m->stream));
+    }
+    {
+      ProfScope ps(m, "idct", 0, 0);
+      launch_idct(m->d_descs, m->d_coef, m->coef_stride, m->d_planes, m->plane_stride, max_blocks, count, m->stream);
+    }
+    if (all_model_size) {
+      // failed frames keep stale input; their results are never reported
+      ProfScope ps(m, "upsample_norm", 0, 0);
+      launch_upsample_norm(m->d_descs, m->d_planes, m->plane_stride, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
+    } else {
+      {
+        ProfScope ps(m, "upsample_rgb", 0, 0);
+        launch_upsample_rgb(m->d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, mw, mh, count, m->stream);
+      }
+      for (uint32_t i = 0; i < count; i++) {
+        if (s.st[i] != UFD_OK) continue;
+        const JpegFrameDesc& d = s.h_descs[i];
+        float* dst = m->d_input + (size_t)i * 3 * m->W * m->H;
+        const uint8_t* src = m->d_rgb + (size_t)i * m->rgb_stride;
+        ProfScope ps(m, "resize_norm", 0, 0);
+        if (d.width == m->W && d.height == m->H) {
+          launch_norm_only(src, d.width, d.height, d.width * 3, 0, m->d_lut, dst, 1, m->stream);
+        } else {
+          ResizeTaps v, h;
+          rc = get_taps(m, d.width, d.height, &v, &h);
+          if (rc) return rc;
+          launch_resize_norm(src, d.width, d.height, d.width * 3, 0, v, h, m->d_lut, dst, m->W, m->H, 1, m->stream);
+        }
+      }
+    }
+    enqueue_forward(m, count);
+    enqueue_heads(m, count);
+    enqueue_nms(m, count);
+  }
+  return enqueue_results_copy(m, s, count);
+}
+
+// `count` same-size RGB frames already in d_rgb (tight pitch) -> pipeline
+int run_rgb_on_device(ufd_model* m, Slot& s, uint32_t w, uint32_t h, uint32_t count) {
+  {
+    ProfScope ps(m, "resize_norm", 0, 0);
+    if ((int)w == m->W && (int)h == m->H) {
+      launch_norm_only(m->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->d_input, count, m->stream);
+    } else {
+      ResizeTaps v, hz;
+      int rc = get_taps(m, w, h, &v, &hz);
+      if (rc) return rc;
+      launch_resize_norm(m->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
+    }
+  }
+  enqueue_forward(m, count);
+  enqueue_heads(m, count);
+  enqueue_nms(m, count);
+  return enqueue_results_copy(m, s, count);
+}
+
+int upload_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t count) {
+  if (!rgb || !w || !h || pitch < 3 * w) return m->fail(UFD_E_ARG, "bad RGB frame arguments");
+  if (w > m->max_w || h > m->max_h) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+  if (count > m->B) return m->fail(UFD_E_TOO_LARGE, "batch larger than max_batch");
+  for (uint32_t i = 0; i < count; i++)
+    HIPC(m, hipMemcpy2DAsync(m->d_rgb + (size_t)i * m->rgb_stride, (size_t)w * 3, rgb + (size_t)i * h * pitch, pitch,
+                             (size_t)w * 3, h, hipMemcpyHostToDevice, m->stream));
+  return UFD_OK;
+}
+
+std::string default_weights_path(int variant) {
+  // dirs::cache_dir()/infercam_onnx/ultraface-RFB-{640,320}.onnx (nn.rs:144-156)
+  const char* xdg = std::getenv("XDG_CACHE_HOME");
+  std::string base;
+  if (xdg && *xdg) {
+    base = xdg;
+  } else {
+    const char* home = std::getenv("HOME");
+    base = std::string(home ? home : ".") + "/.cache";
+  }
+  return base + "/infercam_onnx/ultraface-RFB-" + std::to_string(variant) + ".onnx";
+}
+
+void destroy(ufd_model* m) {
+  if (!m) return;
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  auto dfree = [](void* p) {
+    if (p) (void)hipFree(p);
+  };
+  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_arena), dfree(m->d_input);
+  dfree(m->d_descs), dfree(m->d_coef), dfree(m->d_planes), dfree(m->d_rgb);
+  dfree(m->d_scores), dfree(m->d_boxes), dfree(m->d_keys), dfree(m->d_counts), dfree(m->d_dets), dfree(m->d_ndet);
+  dfree(m->d_spill);
+  for (auto& kv : m->taps)
+    for (TapsDev* t : {&kv.second.first, &kv.second.second}) dfree(t->left), dfree(t->cnt), dfree(t->w);
+  for (auto& s : m->slots) {
+    if (s.h_descs) (void)hipHostFree(s.h_descs);
+    if (s.h_coef) (void)hipHostFree(s.h_coef);
+    if (s.h_dets) (void)hipHostFree(s.h_dets);
+    if (s.h_ndet) (void)hipHostFree(s.h_ndet);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
+  for (auto e : m->prof_free) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int create(const ufd_config* cfg, ufd_model** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(ufd_config)) {
+    g_create_error = "ufd_create: null argument or struct_size mismatch";
+    return UFD_E_ARG;
+  }
+  if (cfg->variant != 640 && cfg->variant != 320) {
+    g_create_error = "ufd_create: variant must be 640 or 320";
+    return UFD_E_ARG;
+  }
+  if (cfg->max_batch < 1 || cfg->max_batch > 1024) {
+    g_create_error = "ufd_create: max_batch must be in 1..1024";
+    return UFD_E_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device: libufacehip needs a gfx950 GPU (there is no CPU fallback)";
+    return UFD_E_DEVICE;
+  }
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) {
+    g_create_error = "ufd_create: device_id out of range";
+    return UFD_E_ARG;
+  }
+  ufd_model* m = new ufd_model();
+  auto bail = [&](int rc) {
+    g_create_error = m->err;
+    destroy(m);
+    return rc;
+  };
+  m->cfg = *cfg;
+  m->W = cfg->variant == 640 ? 640 : 320;  // UltrafaceVariant::width_height, nn.rs:36-41
+  m->H = cfg->variant == 640 ? 480 : 240;
+  m->B = cfg->max_batch;
+  m->max_w = cfg->max_src_width ? cfg->max_src_width : 1920;
+  m->max_h = cfg->max_src_height ? cfg->max_src_height : 1088;
+  m->max_w = std::max<uint32_t>(m->max_w, m->W);
+  m->max_h = std::max<uint32_t>(m->max_h, m->H);
+  m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
+  unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  m->pool.reset(new ThreadPool(threads));
+#define HIPB(expr)                                                                      \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      m->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+      return bail(UFD_E_DEVICE);                                                        \
+    }                                                                                   \
+  } while (0)
+  HIPB(hipSetDevice(cfg->device_id));
+  {
+    hipDeviceProp_t prop;
+    HIPB(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      m->err = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+      return bail(UFD_E_DEVICE);
+    }
+  }
+  HIPB(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+
+  // ---- weights + priors
+  std::vector<float> blob, priors;
+  if (cfg->weights) {
+    if (cfg->weights_floats != total_weight_floats()) {
+      m->err = "weights blob must hold " + std::to_string(total_weight_floats()) + " floats";
+      return bail(UFD_E_WEIGHTS);
+    }
+    blob.assign(cfg->weights, cfg->weights + cfg->weights_floats);
+    if (cfg->priors) priors.assign(cfg->priors, cfg->priors + cfg->priors_floats);
+  } else {
+    std::string path = cfg->weights_path ? cfg->weights_path : default_weights_path(cfg->variant);
+    std::string why;
+    if (!load_ultraface_onnx(path, m->W, m->H, &blob, &priors, &why)) {
+      m->err = "cannot load " + path + ": " + why;
+      return bail(UFD_E_WEIGHTS);
+    }
+  }
+  {
+    std::vector<float> gen;
+    gen_priors(m->W, m->H, gen);
+    m->K = (int)gen.size() / 4;
+    if (priors.empty()) priors = gen;
+    if (priors.size() != gen.size()) {
+      m->err = "priors must hold " + std::to_string(gen.size()) + " floats";
+      return bail(UFD_E_WEIGHTS);
+    }
+  }
+  plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0);
+  // shapes the kernels rely on (checked here once, not per launch)
+  for (const Layer& L : m->layers) {
+    if (L.pointwise && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
+      m->err = std::string("layer ") + L.spec.name + ": pointwise kernel needs H*W % 4 == 0 and even Cin";
+      return bail(UFD_E_WEIGHTS);
+    }
+  }
+  int rc = upload_weights(m, blob.data());
+  if (rc) return bail(rc);
+  HIPB(hipMalloc(&m->d_priors, priors.size() * sizeof(float)));
+  HIPB(hipMemcpy(m->d_priors, priors.data(), priors.size() * sizeof(float), hipMemcpyHostToDevice));
+  {
+    // (v as f32 / 255.0 - mean) / std with f32 literals and IEEE division (nn.rs:86-88)
+    static const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    std::vector<float> lut(768);
+    for (int c = 0; c < 3; c++)
+      for (int v = 0; v < 256; v++) {
+        volatile float q = (float)v / 255.0f;
+        volatile float d = q - mean[c];
+        lut[c * 256 + v] = d / stdv[c];
+      }
+    HIPB(hipMalloc(&m->d_lut, 768 * sizeof(float)));
+    HIPB(hipMemcpy(m->d_lut, lut.data(), 768 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // ---- buffers
+  const size_t B = m->B;
+  HIPB(hipMalloc(&m->d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
+  HIPB(hipMalloc(&m->d_input, B * 3 * m->W * m->H * sizeof(float)));
+  {
+    // worst-case slab: every component at full resolution, padded to 16-pixel MCUs
+    const size_t pw = (m->max_w + 15) / 16 * 16, ph = (m->max_h + 15) / 16 * 16;
+    m->coef_stride = pw * ph * 3;
+    m->plane_stride = pw * ph * 3;
+    m->rgb_stride = ((size_t)m->max_w * m->max_h * 3 + 15) & ~(size_t)15;
+  }
+  HIPB(hipMalloc(&m->d_descs, sizeof(JpegFrameDesc) * B));
+  HIPB(hipMalloc(&m->d_coef, sizeof(int16_t) * m->coef_stride * B));
+  HIPB(hipMalloc(&m->d_planes, m->plane_stride * B));
+  HIPB(hipMalloc(&m->d_rgb, m->rgb_stride * B));
+  m->key_stride = 1;
+  while (m->key_stride < (size_t)m->K) m->key_stride <<= 1;
+  HIPB(hipMalloc(&m->d_scores, B * m->K * 2 * sizeof(float)));
+  HIPB(hipMalloc(&m->d_boxes, B * m->K * 4 * sizeof(float)));
+  HIPB(hipMalloc(&m->d_keys, B * m->key_stride * sizeof(unsigned long long)));
+  HIPB(hipMalloc(&m->d_counts, B * sizeof(uint32_t)));
+  HIPB(hipMalloc(&m->d_dets, B * m->K * sizeof(Det)));
+  HIPB(hipMalloc(&m->d_ndet, B * sizeof(uint32_t)));
+  HIPB(hipMalloc(&m->d_spill, B * m->K * sizeof(float4)));
+  HIPB(hipMemset(m->d_dets, 0, B * m->K * sizeof(Det)));
+  HIPB(hipDeviceSynchronize());
+#undef HIPB
+  *out = m;
+  return UFD_OK;
+}
+
+template <typename F>
+int guarded(ufd_model* m, F&& f) {
+  if (!m) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(m->mu);
+  try {
+    if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
+    return f();
+  } catch (const std::exception& e) {
+    return m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
+  } catch (...) {
+    return m->fail(UFD_E_DEVICE, "unknown exception");
+  }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int ufd_create(const ufd_config* cfg, ufd_model** out) {
+  try {
+    return create(cfg, out);
+  } catch (const std::exception& e) {
+    g_create_error = std::string("exception: ") + e.what();
+    return UFD_E_DEVICE;
+  } catch (...) {
+    g_create_error = "unknown exception";
+    return UFD_E_DEVICE;
+  }
+}
+
+void ufd_destroy(ufd_model* m) {
+  try {
+    if (m) (void)hipSetDevice(m->cfg.device_id);
+    destroy(m);
+  } catch (...) {
+  }
+}
+
+const char* ufd_last_error(const ufd_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32_t* num_priors) {
+  if (!m) return UFD_E_ARG;
+  if (width) *width = m->W;
+  if (height) *height = m->H;
+  if (num_priors) *num_priors = m->K;
+  return UFD_OK;
+}
+
+int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t count,
+                        ufd_det* out, uint32_t cap, uint32_t* n) {
+  return guarded(m, [&]() -> int {
+    int rc = check_outputs(m, out, cap, n);
+    if (rc) return rc;
+    if (!count) return UFD_OK;
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
+    rc = alloc_slot(m, *s);
+    if (rc) return rc;
+    rc = upload_rgb(m, rgb, w, h, pitch, count);
+    if (rc) return rc;
+    s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
+    std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);
+    rc = run_rgb_on_device(m, *s, w, h, count);
+    if (rc) return rc;
+    return finish_slot(m, *s);
+  });
+}
+
+int ufd_infer_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, ufd_det* out, uint32_t cap,
+                  uint32_t* n) {
+  return ufd_infer_rgb_batch(m, rgb, w, h, pitch, 1, out, cap, n);
+}
+
+int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
+                          uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
+  return guarded(m, [&]() -> int {
+    int rc = check_outputs(m, out, cap, n);
+    if (rc) return rc;
+    if (!jpegs || !lens || !ticket) return m->fail(UFD_E_ARG, "null argument");
+    if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
+    s->cap = cap, s->out = out, s->n = n, s->status = status;
+    rc = submit_jpegs(m, *s, jpegs, lens, count);
+    if (rc) return rc;
+    s->busy = true;
+    s->ticket = m->next_ticket++;
+    if (!m->next_ticket) m->next_ticket = 1;
+    *ticket = s->ticket;
+    return UFD_OK;
+  });
+}
+
+int ufd_wait(ufd_model* m, uint32_t ticket) {
+  return guarded(m, [&]() -> int {
+    for (auto& s : m->slots)
+      if (s.busy && s.ticket == ticket) return finish_slot(m, s);
+    return m->fail(UFD_E_STATE, "unknown ticket");
+  });
+}
+
+int ufd_infer_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
+                         uint32_t cap, uint32_t* n, int32_t* status) {
+  if (m && count == 0) return UFD_OK;
+  uint32_t ticket = 0;
+  std::vector<int32_t> local;
+  if (!status) {
+    local.resize(count ? count : 1);
+    status = local.data();
+  }
+  int rc = ufd_submit_jpeg_batch(m, jpegs, lens, count, out, cap, n, status, &ticket);
+  if (rc) return rc;
+  return ufd_wait(m, ticket);
+}
+
+int ufd_infer_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, ufd_det* out, uint32_t cap, uint32_t* n,
+                   uint32_t* img_w, uint32_t* img_h) {
+  if (!m) return UFD_E_ARG;
+  if (!jpeg || !len) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    return m->fail(UFD_E_ARG, "null JPEG");
+  }
+  if (img_w || img_h) {
+    JpegFrameDesc d;
+    if (jpeg_parse_header(jpeg, len, &d) == kJpegOk) {
+      if (img_w) *img_w = d.width;
+      if (img_h) *img_h = d.height;
+    }
+  }
+  int32_t st = 0;
+  int rc = ufd_infer_jpeg_batch(m, &jpeg, &len, 1, out, cap, n, &st);
+  if (rc) return rc;
+  if (st != UFD_OK) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (st == UFD_E_DECODE) m->err = "corrupt JPEG";
+    if (st == UFD_E_UNSUPPORTED) m->err = "unsupported JPEG feature";
+    if (st == UFD_E_TOO_LARGE) m->err = "frame larger than max_src_width/height";
+    if (st == UFD_E_TRUNCATED) m->err = "more detections than cap";
+  }
+  return st;
+}
+
+// ---------------------------------------------------------------- stage taps
+int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes, uint32_t* w,
+                          uint32_t* h) {
+  return guarded(m, [&]() -> int {
+    if (!jpeg || !len || !rgb) return m->fail(UFD_E_ARG, "null argument");
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy");
+    int rc = alloc_slot(m, *s);
+    if (rc) return rc;
+    JpegFrameDesc* d = &s->h_descs[0];
+    int st = jpeg_decode_coefficients(jpeg, len, d, s->h_coef, m->coef_stride);
+    if (st == kJpegCorrupt) return m->fail(UFD_E_DECODE, "corrupt JPEG");
+    if (st != kJpegOk) return m->fail(UFD_E_UNSUPPORTED, "unsupported JPEG feature");
+    if ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)
+      return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+    if (w) *w = d->width;
+    if (h) *h = d->height;
+    const size_t bytes = (size_t)d->width * d->height * 3;
+    if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
+    HIPC(m, hipMemcpyAsync(m->d_descs, d, sizeof(*d), hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemcpyAsync(m->d_coef, s->h_coef, (size_t)d->coef_total * 2, hipMemcpyHostToDevice, m->stream));
+    launch_idct(m->d_descs, m->d_coef, m->coef_stride, m->d_planes, m->plane_stride, d->total_blocks, 1, m->stream);
+    launch_upsample_rgb(m->d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, d->width, d->height, 1,
+                        m->stream);
+    HIPC(m, hipMemcpyAsync(rgb, m->d_rgb, bytes, hipMemcpyDeviceToHost, m->stream));
+    HIPC(m, hipStreamSynchronize(m->stream));
+    return UFD_OK;
+  });
+}
+
+int ufd_debug_preproc_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, float* out_nchw) {
+  return guarded(m, [&]() -> int {
+    if (!out_nchw) return m->fail(UFD_E_ARG, "null argument");
+    int rc = upload_rgb(m, rgb, w, h, pitch, 1);
+    if (rc) return rc;
+    if ((int)w == m->W && (int)h == m->H) {
+      launch_norm_only(m->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->d_input, 1, m->stream);
+    } else {
+      ResizeTaps v, hz;
+      rc = get_taps(m, w, h, &v, &hz);
+      if (rc) return rc;
+      launch_resize_norm(m->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->d_input, m->W, m->H, 1, m->stream);
+    }
+    HIPC(m, hipMemcpyAsync(out_nchw, m->d_input, sizeof(float) * 3 * m->W * m->H, hipMemcpyDeviceToHost, m->stream));
+    HIPC(m, hipStreamSynchronize(m->stream));
+    return UFD_OK;
+  });
+}
+
+int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, float* scores, float* boxes) {
+  return guarded(m, [&]() -> int {
+    if (!input_nchw || !scores || !boxes) return m->fail(UFD_E_ARG, "null argument");
+    if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
+    const size_t in_floats = (size_t)count * 3 * m->W * m->H;
+    HIPC(m, hipMemcpyAsync(m->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    enqueue_forward(m, count);
+    enqueue_heads(m, count);
+    HIPC(m, hipMemcpyAsync(scores, m->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, m->stream));
+    HIPC(m, hipMemcpyAsync(boxes, m->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, m->stream));
+    HIPC(m, hipStreamSynchronize(m->stream));
+    prof_flush(m);
+    return UFD_OK;
+  });
+}
+
+int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats, size_t* floats) {
+  return guarded(m, [&]() -> int {
+    if (!(m->cfg.flags & UFD_FLAG_KEEP_LAYERS)) return m->fail(UFD_E_STATE, "needs UFD_FLAG_KEEP_LAYERS");
+    if (layer >= (uint32_t)kNumConv || frame >= m->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
+    const Layer& L = m->layers[layer];
+    const Tensor& t = m->tensors[L.out_tensor];
+    const size_t plane = (size_t)L.oh * L.ow, nf = (size_t)L.spec.cout * plane;
+    if (floats) *floats = nf;
+    if (!out || cap_floats < nf) return m->fail(UFD_E_ARG, "output buffer too small");
+    const float* src = tensor_ptr(m, L.out_tensor) + ((size_t)frame * t.c + L.out_coff) * plane;
+    HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIPC(m, hipStreamSynchronize(m->stream));
+    return UFD_OK;
+  });
+}
+
+int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, uint32_t count, ufd_det* out, uint32_t cap,
+                       uint32_t* n) {
+  return guarded(m, [&]() -> int {
+    int rc = check_outputs(m, out, cap, n);
+    if (rc) return rc;
+    if (!scores || !boxes) return m->fail(UFD_E_ARG, "null argument");
+    if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy");
+    rc = alloc_slot(m, *s);
+    if (rc) return rc;
+    HIPC(m, hipMemcpyAsync(m->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemcpyAsync(m->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemsetAsync(m->d_counts, 0, sizeof(uint32_t) * count, m->stream));
+    launch_threshold(m->d_scores, m->K, count, m->cfg.min_confidence, m->d_keys, m->key_stride, m->d_counts, m->stream);
+    enqueue_nms(m, count);
+    s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
+    std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);
+    rc = enqueue_results_copy(m, *s, count);
+    if (rc) return rc;
+    return finish_slot(m, *s);
+  });
+}
+
+int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, size_t cap_i16, uint32_t* n_i16,
+                                uint32_t* w, uint32_t* h) {
+  try {
+    if (!jpeg || !len) return UFD_E_ARG;
+    JpegFrameDesc d;
+    int st = jpeg_parse_header(jpeg, len, &d);
+    if (st != kJpegOk) return st == kJpegCorrupt ? UFD_E_DECODE : UFD_E_UNSUPPORTED;
+    if (w) *w = d.width;
+    if (h) *h = d.height;
+    if (n_i16) *n_i16 = d.coef_total;
+    if (!coef) return UFD_OK;
+    if (cap_i16 < d.coef_total) return UFD_E_ARG;
+    st = jpeg_decode_coefficients(jpeg, len, &d, coef, cap_i16);
+    return st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : UFD_E_UNSUPPORTED);
+  } catch (...) {
+    return UFD_E_DEVICE;
+  }
+}
+
+int ufd_profile_reset(ufd_model* m) {
+  return guarded(m, [&]() -> int {
+    HIPC(m, hipStreamSynchronize(m->stream));
+    prof_flush(m);
+    for (auto& st : m->prof_stats) st.launches = 0, st.total_ms = 0, st.bytes = 0, st.flops = 0;
+    return UFD_OK;
+  });
+}
+
+int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n) {
+  return guarded(m, [&]() -> int {
+    if (!n) return m->fail(UFD_E_ARG, "null argument");
+    HIPC(m, hipStreamSynchronize(m->stream));
+    prof_flush(m);
+    *n = (uint32_t)m->prof_stats.size();
+    for (uint32_t i = 0; i < std::min<uint32_t>(cap, *n); i++) stats[i] = m->prof_stats[i];
+    return UFD_OK;
+  });
+}
+
+}  // extern "C"

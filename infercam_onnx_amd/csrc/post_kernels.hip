@@ -1,0 +1,206 @@
+// post_kernels.hip -- tail of row A6 and rows A7-A10:
+//   softmax over the 2 classes + SSD prior-box decode (embedded in the ONNX graph that
+//     `self.model.run` executes, infer_server/src/nn.rs:181)
+//   UltrafaceModel::postproc: keep conf > min_confidence (strict), stable ascending sort
+//     (nn.rs:109-134), then non_maximum_suppression popping from the back (nn.rs:198-224) with
+//     iou / bbox_area in the reference's exact f32 operation order (nn.rs:227-260, EPS nn.rs:18).
+// Processing order = confidence descending, ties by HIGHER prior index first: encoded as one
+// 64-bit key (orderable confidence bits << 32 | prior index + 1) sorted descending.
+#include "kernels.hpp"
+
+namespace ufd {
+namespace {
+
+constexpr float kEps = 1.0e-7f;           // nn.rs:18
+constexpr int kSortLds = 4096;            // keys sorted inside LDS up to this many candidates
+constexpr int kSelLds = 1024;             // selected boxes kept in LDS; the rest spill to HBM
+
+__device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
+  conf = conf + 0.0f;  // -0.0 -> +0.0 (partial_cmp treats them as equal)
+  uint32_t u = __float_as_uint(conf);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+  return ((unsigned long long)u << 32) | (unsigned long long)(k + 1);
+}
+__device__ __forceinline__ float key_conf(unsigned long long key) {
+  uint32_t u = (uint32_t)(key >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void k_head_decode(HeadArgs h, const float* __restrict__ priors, int K,
+                                                     float min_conf, float* __restrict__ scores,
+                                                     float* __restrict__ boxes, unsigned long long* __restrict__ keys,
+                                                     size_t key_stride, uint32_t* __restrict__ counts) {
+  const int frame = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int head = k >= h.base[3] ? 3 : (k >= h.base[2] ? 2 : (k >= h.base[1] ? 1 : 0));
+  const int A = h.anchors[head], plane = h.plane[head];
+  const int local = k - h.base[head];
+  const int p = local / A, an = local - p * A;
+  const float* cls = h.cls[head] + (size_t)frame * (A * 2) * plane;
+  const float* reg = h.reg[head] + (size_t)frame * (A * 4) * plane;
+  // NCHW [A*c][fh][fw] -> NHWC -> [fh*fw*A][c]
+  const float s0 = cls[(size_t)(an * 2 + 0) * plane + p], s1 = cls[(size_t)(an * 2 + 1) * plane + p];
+  const float mx = fmaxf(s0, s1);
+  const float e0 = expf(s0 - mx), e1 = expf(s1 - mx);
+  const float sum = e0 + e1;
+  const float c0 = e0 / sum, c1 = e1 / sum;
+  const float l0 = reg[(size_t)(an * 4 + 0) * plane + p], l1 = reg[(size_t)(an * 4 + 1) * plane + p];
+  const float l2 = reg[(size_t)(an * 4 + 2) * plane + p], l3 = reg[(size_t)(an * 4 + 3) * plane + p];
+  const float4 pr = reinterpret_cast<const float4*>(priors)[k];
+  const float cx = __fadd_rn(__fmul_rn(__fmul_rn(l0, 0.1f), pr.z), pr.x);
+  const float cy = __fadd_rn(__fmul_rn(__fmul_rn(l1, 0.1f), pr.w), pr.y);
+  const float bw = expf(l2 * 0.2f) * pr.z, bh = expf(l3 * 0.2f) * pr.w;
+  float4 bb;
+  bb.x = cx - bw / 2.0f;
+  bb.y = cy - bh / 2.0f;
+  bb.z = cx + bw / 2.0f;
+  bb.w = cy + bh / 2.0f;
+  const size_t o = (size_t)frame * K + k;
+  reinterpret_cast<float2*>(scores)[o] = make_float2(c0, c1);
+  reinterpret_cast<float4*>(boxes)[o] = bb;
+  if (c1 > min_conf) {  // strict; NaN fails
+    const uint32_t pos = atomicAdd(&counts[frame], 1u);
+    keys[(size_t)frame * key_stride + pos] = make_key(c1, (uint32_t)k);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_threshold(const float* __restrict__ scores, int K, float min_conf,
+                                                   unsigned long long* __restrict__ keys, size_t key_stride,
+                                                   uint32_t* __restrict__ counts) {
+  const int frame = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float c1 = scores[((size_t)frame * K + k) * 2 + 1];
+  if (c1 > min_conf) {
+    const uint32_t pos = atomicAdd(&counts[frame], 1u);
+    keys[(size_t)frame * key_stride + pos] = make_key(c1, (uint32_t)k);
+  }
+}
+
+// nn.rs:251-260
+__device__ __forceinline__ float bbox_area(float x0, float y0, float x1, float y1) {
+  const float width = __fsub_rn(y1, y0);
+  const float height = __fsub_rn(x1, x0);
+  if (width < 0.0f || height < 0.0f) return 0.0f;
+  return __fmul_rn(width, height);
+}
+
+// descending bitonic sort of n2 (power of two) keys by one workgroup
+__device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthreads) {
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n2 >> 1); t += nthreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a < b) == desc) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
+                                                  const uint32_t* __restrict__ counts, const float* __restrict__ boxes,
+                                                  int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
+                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill) {
+  __shared__ unsigned long long s_keys[kSortLds];
+  __shared__ float4 s_sel[kSelLds];
+  const int frame = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = min((int)counts[frame], K);
+  unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  unsigned long long* keys;
+  if (n2 <= kSortLds) {
+    for (int i = tid; i < n2; i += 256) s_keys[i] = i < n ? fkeys[i] : 0ull;
+    keys = s_keys;
+  } else {
+    for (int i = n + tid; i < n2; i += 256) fkeys[i] = 0ull;  // key_stride >= next pow2 of K
+    __threadfence_block();
+    keys = fkeys;
+  }
+  __syncthreads();
+  if (n > 1) bitonic_desc(keys, n2, tid, 256);
+  if (n2 > kSortLds) __threadfence_block();
+  __syncthreads();
+  if (tid >= 64) return;  // greedy scan: one wave
+  const int lane = tid;
+  const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
+  float4* fspill = spill + (size_t)frame * K;
+  Det* fd = dets + (size_t)frame * det_stride;
+  int nsel = 0;
+  for (int i = 0; i < n; i++) {
+    const unsigned long long key = keys[i];
+    const int k = (int)(key & 0xffffffffull) - 1;
+    const float4 c = fb[k];
+    const float area_c = bbox_area(c.x, c.y, c.z, c.w);
+    bool suppressed = false;
+    for (int j0 = 0; j0 < nsel; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      if (j < nsel) {
+        const float4 sb = j < kSelLds ? s_sel[j] : fspill[j];
+        // iou(bbox, selected_bbox), nn.rs:227-243
+        const float ox0 = fmaxf(c.x, sb.x), oy0 = fmaxf(c.y, sb.y), ox1 = fminf(c.z, sb.z), oy1 = fminf(c.w, sb.w);
+        const float overlap = bbox_area(ox0, oy0, ox1, oy1);
+        const float denom = __fadd_rn(__fsub_rn(__fadd_rn(area_c, bbox_area(sb.x, sb.y, sb.z, sb.w)), overlap), kEps);
+        const float iou = __fdiv_rn(overlap, denom);
+        hit = iou > max_iou;
+      }
+      if (__any(hit)) {
+        suppressed = true;
+        break;
+      }
+    }
+    if (!suppressed) {
+      if (lane == 0) {
+        if (nsel < kSelLds)
+          s_sel[nsel] = c;
+        else
+          fspill[nsel] = c;
+        if ((uint32_t)nsel < det_stride) {
+          Det d;
+          d.x_tl = c.x, d.y_tl = c.y, d.x_br = c.z, d.y_br = c.w, d.conf = key_conf(key);
+          fd[nsel] = d;
+        }
+      }
+      nsel++;
+      if (nsel > kSelLds) __threadfence_block();
+    }
+  }
+  if (lane == 0) ndet[frame] = (uint32_t)nsel;
+}
+
+}  // namespace
+
+void launch_head_decode(const HeadArgs& h, const float* d_priors, uint32_t B, float min_conf, float* d_scores,
+                        float* d_boxes, unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts,
+                        hipStream_t s) {
+  const int K = h.base[4];
+  hipLaunchKernelGGL(k_head_decode, dim3((K + 255) / 256, B), dim3(256), 0, s, h, d_priors, K, min_conf, d_scores,
+                     d_boxes, d_keys, key_stride, d_counts);
+}
+
+void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_conf, unsigned long long* d_keys,
+                      size_t key_stride, uint32_t* d_counts, hipStream_t s) {
+  hipLaunchKernelGGL(k_threshold, dim3((K + 255) / 256, B), dim3(256), 0, s, d_scores, (int)K, min_conf, d_keys,
+                     key_stride, d_counts);
+}
+
+void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
+                     uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
+                     uint32_t B, hipStream_t s) {
+  hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
+                     d_dets, det_stride, d_ndet, d_sel_spill);
+}
+
+}  // namespace ufd

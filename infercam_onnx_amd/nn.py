@@ -1,0 +1,345 @@
+"""Host-side mirror of the reference's `infer_server/src/nn.rs` over the C ABI (include/ufd.h).
+
+Same names and meaning as the reference: `Bbox`, `InferModel.run`, `UltrafaceVariant`,
+`UltrafaceModel(variant, max_iou, min_confidence)`; `run(image)` returns the selected boxes with
+confidences in descending order, boxes as relative `[x_tl, y_tl, x_br, y_br]` (nn.rs:12,24-26,
+107-108).  All computation happens in libufacehip.so (HIP kernels for gfx950); there is no CPU
+fallback: if the library or a GPU is missing, construction raises.
+"""
+import ctypes
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libufacehip.so")
+
+UFD_OK = 0
+UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
+UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
+UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE = 1, 2
+UFD_MAX_SLOTS = 4
+
+_STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
+                 -5: "UFD_E_DEVICE", -6: "UFD_E_WEIGHTS", -7: "UFD_E_STATE", -8: "UFD_E_TOO_LARGE"}
+
+
+class UfdDet(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("x_tl", "y_tl", "x_br", "y_br", "conf")]
+
+
+class UfdConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("variant", ctypes.c_uint32), ("max_iou", ctypes.c_float),
+                ("min_confidence", ctypes.c_float), ("device_id", ctypes.c_int32), ("max_batch", ctypes.c_uint32),
+                ("max_src_width", ctypes.c_uint32), ("max_src_height", ctypes.c_uint32),
+                ("host_threads", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("weights_path", ctypes.c_char_p),
+                ("weights", ctypes.c_void_p), ("weights_floats", ctypes.c_size_t), ("priors", ctypes.c_void_p),
+                ("priors_floats", ctypes.c_size_t)]
+
+
+class UfdKernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
+                ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
+
+
+# every symbol include/ufd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
+    "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
+    "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
+    "ufd_debug_jpeg_coefficients", "ufd_profile_reset", "ufd_profile_read",
+)
+
+_lib = None
+
+
+class UfdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_STATUS_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+def load_library():
+    """dlopen libufacehip.so.  Raises if it was not built: the HIP path is the only path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                          "infercam_onnx_amd has no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, sz, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int32
+    pu32 = ctypes.POINTER(ctypes.c_uint32)
+    L.ufd_create.argtypes = [ctypes.POINTER(UfdConfig), ctypes.POINTER(vp)]
+    L.ufd_destroy.argtypes = [vp]
+    L.ufd_destroy.restype = None
+    L.ufd_last_error.argtypes = [vp]
+    L.ufd_last_error.restype = ctypes.c_char_p
+    L.ufd_model_info.argtypes = [vp, pu32, pu32, pu32]
+    L.ufd_infer_rgb.argtypes = [vp, vp, u32, u32, u32, vp, u32, pu32]
+    L.ufd_infer_jpeg.argtypes = [vp, vp, sz, vp, u32, pu32, pu32, pu32]
+    L.ufd_infer_jpeg_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp]
+    L.ufd_infer_rgb_batch.argtypes = [vp, vp, u32, u32, u32, u32, vp, u32, vp]
+    L.ufd_submit_jpeg_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, pu32]
+    L.ufd_wait.argtypes = [vp, u32]
+    L.ufd_debug_decode_jpeg.argtypes = [vp, vp, sz, vp, sz, pu32, pu32]
+    L.ufd_debug_preproc_rgb.argtypes = [vp, vp, u32, u32, u32, vp]
+    L.ufd_debug_forward.argtypes = [vp, vp, u32, vp, vp]
+    L.ufd_debug_layer_output.argtypes = [vp, u32, u32, vp, sz, ctypes.POINTER(sz)]
+    L.ufd_debug_postproc.argtypes = [vp, vp, vp, u32, vp, u32, vp]
+    L.ufd_debug_jpeg_coefficients.argtypes = [vp, sz, vp, sz, pu32, pu32, pu32]
+    L.ufd_profile_reset.argtypes = [vp]
+    L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
+    _lib = L
+    return L
+
+
+def jpeg_coefficients(jpeg):
+    """Host Huffman stage alone (no GPU): (int16 coefficients, width, height)."""
+    L = load_library()
+    buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+    n, w, h = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    rc = L.ufd_debug_jpeg_coefficients(buf, len(jpeg), None, 0, ctypes.byref(n), ctypes.byref(w), ctypes.byref(h))
+    if rc:
+        raise UfdError(rc, "jpeg header")
+    coef = np.empty(n.value, np.int16)
+    rc = L.ufd_debug_jpeg_coefficients(buf, len(jpeg), coef.ctypes.data, coef.size, ctypes.byref(n), ctypes.byref(w),
+                                       ctypes.byref(h))
+    if rc:
+        raise UfdError(rc, "jpeg entropy decode")
+    return coef, w.value, h.value
+
+
+#: Bounding box `[x_top_left, y_top_left, x_bottom_right, y_bottom_right]` (nn.rs:12)
+Bbox = tuple
+
+
+class InferModel:
+    """`pub trait InferModel { fn run(&self, input: &RgbImage) -> Result<Vec<(Bbox, f32)>>; }` (nn.rs:24-26)"""
+
+    def run(self, image):
+        raise NotImplementedError
+
+
+class UltrafaceVariant(enum.Enum):
+    """Supported variants of the Ultraface model (nn.rs:29-42)."""
+    W640H480 = 640
+    W320H240 = 320
+
+    def width_height(self):
+        return (640, 480) if self is UltrafaceVariant.W640H480 else (320, 240)
+
+
+def _dets_to_list(arr, n):
+    return [((arr[i].x_tl, arr[i].y_tl, arr[i].x_br, arr[i].y_br), arr[i].conf) for i in range(n)]
+
+
+class UltrafaceModel(InferModel):
+    """Loaded Ultraface model resident on one MI355X, with post-processing thresholds (nn.rs:45-67).
+
+    `UltrafaceModel(variant, max_iou, min_confidence)` as in the reference; keyword arguments add
+    placement (`device_id`, `max_batch`) and the weight source (`weights_path` = .onnx, or a packed
+    f32 `weights` blob + optional `priors`; default = the reference's cache path, nn.rs:144-156).
+    """
+
+    def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
+                 weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024):
+        self._h = None
+        self._lib = load_library()
+        self.variant = variant
+        self.width, self.height = variant.width_height()
+        self.max_iou, self.min_confidence = float(max_iou), float(min_confidence)
+        self.max_batch = int(max_batch)
+        self.det_cap = int(det_cap)
+        cfg = UfdConfig()
+        cfg.struct_size = ctypes.sizeof(UfdConfig)
+        cfg.variant = variant.value
+        cfg.max_iou, cfg.min_confidence = self.max_iou, self.min_confidence
+        cfg.device_id, cfg.max_batch = int(device_id), self.max_batch
+        cfg.max_src_width, cfg.max_src_height = int(max_src[0]), int(max_src[1])
+        cfg.host_threads = int(host_threads)
+        cfg.flags = (UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0)
+        keep = []
+        if weights is not None:
+            w = np.ascontiguousarray(weights, np.float32).ravel()
+            keep.append(w)
+            cfg.weights, cfg.weights_floats = w.ctypes.data, w.size
+            if priors is not None:
+                p = np.ascontiguousarray(priors, np.float32).ravel()
+                keep.append(p)
+                cfg.priors, cfg.priors_floats = p.ctypes.data, p.size
+        elif weights_path is not None:
+            cfg.weights_path = os.fsencode(weights_path)
+        h = ctypes.c_void_p()
+        rc = self._lib.ufd_create(ctypes.byref(cfg), ctypes.byref(h))
+        if rc != UFD_OK:
+            raise UfdError(rc, (self._lib.ufd_last_error(None) or b"").decode())
+        self._h = h
+        k = ctypes.c_uint32()
+        self._lib.ufd_model_info(h, None, None, ctypes.byref(k))
+        self.num_priors = k.value
+        self._pending = {}
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            self._lib.ufd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, allow=()):
+        if rc != UFD_OK and rc not in allow:
+            raise UfdError(rc, (self._lib.ufd_last_error(self._h) or b"").decode())
+        return rc
+
+    # -- InferModel::run (nn.rs:178-186)
+    def run(self, image):
+        """image: HxWx3 uint8 RGB (any size) -> [(bbox, confidence)] in descending confidence."""
+        return self.run_batch(np.asarray(image)[None])[0]
+
+    def run_batch(self, images):
+        """images: [N,H,W,3] uint8, all the same size."""
+        imgs = np.ascontiguousarray(images, np.uint8)
+        n, h, w, c = imgs.shape
+        assert c == 3
+        out = (UfdDet * (n * self.det_cap))()
+        cnt = (ctypes.c_uint32 * n)()
+        self._check(self._lib.ufd_infer_rgb_batch(self._h, imgs.ctypes.data, w, h, w * 3, n, out, self.det_cap, cnt),
+                    allow=(UFD_E_TRUNCATED,))
+        return [_dets_to_list(out[i * self.det_cap:(i + 1) * self.det_cap], min(cnt[i], self.det_cap)) for i in range(n)]
+
+    # -- Inferer::run decode -> infer (inferer.rs:35-37)
+    def infer_jpeg(self, jpeg):
+        out = (UfdDet * self.det_cap)()
+        n, w, h = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+        self._check(self._lib.ufd_infer_jpeg(self._h, buf, len(jpeg), out, self.det_cap, ctypes.byref(n),
+                                             ctypes.byref(w), ctypes.byref(h)), allow=(UFD_E_TRUNCATED,))
+        return _dets_to_list(out, min(n.value, self.det_cap))
+
+    class _Batch:
+        __slots__ = ("bufs", "ptrs", "lens", "out", "cnt", "status", "count", "ticket")
+
+    def _prep_batch(self, jpegs):
+        b = UltrafaceModel._Batch()
+        b.count = len(jpegs)
+        b.bufs = [j if isinstance(j, (ctypes.Array,)) else (ctypes.c_char * len(j)).from_buffer_copy(j) for j in jpegs]
+        b.ptrs = (ctypes.c_void_p * b.count)(*[ctypes.addressof(x) for x in b.bufs])
+        b.lens = (ctypes.c_size_t * b.count)(*[len(x) for x in b.bufs])
+        b.out = (UfdDet * (b.count * self.det_cap))()
+        b.cnt = (ctypes.c_uint32 * b.count)()
+        b.status = (ctypes.c_int32 * b.count)()
+        return b
+
+    def _collect(self, b):
+        res = []
+        for i in range(b.count):
+            if b.status[i] in (UFD_OK, UFD_E_TRUNCATED):
+                res.append(_dets_to_list(b.out[i * self.det_cap:(i + 1) * self.det_cap], min(b.cnt[i], self.det_cap)))
+            else:
+                res.append(None)  # frame skipped (corrupt / unsupported)
+        return res, list(b.status)
+
+    def infer_jpeg_batch(self, jpegs):
+        """-> ([detections or None per frame], [status per frame])"""
+        b = self._prep_batch(jpegs)
+        self._check(self._lib.ufd_infer_jpeg_batch(self._h, b.ptrs, b.lens, b.count, b.out, self.det_cap, b.cnt,
+                                                   b.status))
+        return self._collect(b)
+
+    def submit_jpeg_batch(self, jpegs):
+        """Asynchronous form: returns a ticket for `wait`."""
+        b = jpegs if isinstance(jpegs, UltrafaceModel._Batch) else self._prep_batch(jpegs)
+        t = ctypes.c_uint32()
+        self._check(self._lib.ufd_submit_jpeg_batch(self._h, b.ptrs, b.lens, b.count, b.out, self.det_cap, b.cnt,
+                                                    b.status, ctypes.byref(t)))
+        b.ticket = t.value
+        self._pending[t.value] = b
+        return t.value
+
+    def wait(self, ticket, collect=True):
+        b = self._pending.pop(ticket)
+        self._check(self._lib.ufd_wait(self._h, ticket))
+        return self._collect(b) if collect else (b.cnt, b.status)
+
+    # -- stage taps used by the parity tests
+    def debug_decode_jpeg(self, jpeg):
+        """A1 on the GPU: JPEG -> HxWx3 uint8."""
+        buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+        _, w, h = jpeg_coefficients_header(jpeg)
+        out = np.empty((h, w, 3), np.uint8)
+        ww, hh = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.ufd_debug_decode_jpeg(self._h, buf, len(jpeg), out.ctypes.data, out.nbytes,
+                                                    ctypes.byref(ww), ctypes.byref(hh)))
+        return out
+
+    def debug_preproc(self, rgb):
+        """A2-A4 on the GPU: HxWx3 uint8 -> [3, H_model, W_model] f32."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w, _ = rgb.shape
+        out = np.empty((3, self.height, self.width), np.float32)
+        self._check(self._lib.ufd_debug_preproc_rgb(self._h, rgb.ctypes.data, w, h, w * 3, out.ctypes.data))
+        return out
+
+    def debug_forward(self, inputs):
+        """A6 on the GPU: [N,3,H,W] f32 -> (scores [N,K,2], boxes [N,K,4])."""
+        x = np.ascontiguousarray(inputs, np.float32)
+        n = x.shape[0]
+        scores = np.empty((n, self.num_priors, 2), np.float32)
+        boxes = np.empty((n, self.num_priors, 4), np.float32)
+        self._check(self._lib.ufd_debug_forward(self._h, x.ctypes.data, n, scores.ctypes.data, boxes.ctypes.data))
+        return scores, boxes
+
+    def debug_layer_output(self, layer, frame=0):
+        nf = ctypes.c_size_t()
+        self._lib.ufd_debug_layer_output(self._h, layer, frame, None, 0, ctypes.byref(nf))
+        out = np.empty(nf.value, np.float32)
+        self._check(self._lib.ufd_debug_layer_output(self._h, layer, frame, out.ctypes.data, out.size, ctypes.byref(nf)))
+        return out
+
+    def debug_postproc(self, scores, boxes):
+        """A7-A10 on the GPU: raw outputs [N,K,2], [N,K,4] -> per-frame detection lists."""
+        s = np.ascontiguousarray(scores, np.float32)
+        b = np.ascontiguousarray(boxes, np.float32)
+        n = s.shape[0]
+        cap = self.num_priors
+        out = (UfdDet * (n * cap))()
+        cnt = (ctypes.c_uint32 * n)()
+        self._check(self._lib.ufd_debug_postproc(self._h, s.ctypes.data, b.ctypes.data, n, out, cap, cnt))
+        return [_dets_to_list(out[i * cap:(i + 1) * cap], cnt[i]) for i in range(n)]
+
+    # -- measurement
+    def profile_reset(self):
+        self._check(self._lib.ufd_profile_reset(self._h))
+
+    def profile_read(self):
+        """-> [dict(name, launches, total_ms, bytes, flops)] per kernel since the last reset."""
+        cap = 256
+        arr = (UfdKernelStat * cap)()
+        n = ctypes.c_uint32()
+        self._check(self._lib.ufd_profile_read(self._h, arr, cap, ctypes.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms,
+                     bytes=arr[i].bytes, flops=arr[i].flops) for i in range(min(n.value, cap))]
+
+
+def jpeg_coefficients_header(jpeg):
+    """(n_int16, width, height) from the JPEG header (host only)."""
+    L = load_library()
+    buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+    n, w, h = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    rc = L.ufd_debug_jpeg_coefficients(buf, len(jpeg), None, 0, ctypes.byref(n), ctypes.byref(w), ctypes.byref(h))
+    if rc:
+        raise UfdError(rc, "jpeg header")
+    return n.value, w.value, h.value

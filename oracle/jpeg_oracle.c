@@ -740,7 +740,11 @@ static int install_default_tables(dec_t* d) {
 }
 
 /* Walk markers. If rgb == NULL only the header is parsed (probe). */
+static int decode_stream_ex(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb, int want_w, int want_h, int coef_only);
 static int decode_stream(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb, int want_w, int want_h) {
+  return decode_stream_ex(data, len, d, rgb, want_w, want_h, 0);
+}
+static int decode_stream_ex(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb, int want_w, int want_h, int coef_only) {
   memset(d, 0, sizeof(*d));
   if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return UFO_E_DECODE;
   const uint8_t* p = data + 2;
@@ -750,10 +754,9 @@ static int decode_stream(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb
     /* find next marker */
     while (p < end && *p != 0xFF) p++;
     while (p < end && *p == 0xFF) p++;
-    if (p >= end) {
-      if (scans > 0 && rgb) break; /* missing EOI: libjpeg warns; treat as error like turbojpeg */
-      return UFO_E_DECODE;
-    }
+    /* missing EOI: libjpeg inserts a fake EOI and warns; tjDecompress2 turns any warning into
+     * a failure return, which the reference `expect`s on (inferer.rs:35-36) */
+    if (p >= end) return UFO_E_DECODE;
     int m = *p++;
     if (m == 0xD9) break;                       /* EOI */
     if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue; /* TEM / stray RST */
@@ -793,7 +796,7 @@ static int decode_stream(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb
       case 0xDA: {
         if (!d->saw_sof) return UFO_E_DECODE;
         if (!rgb) return UFO_OK; /* probe: header complete */
-        if (d->width != want_w || d->height != want_h) return UFO_E_ARG;
+        if (!coef_only && (d->width != want_w || d->height != want_h)) return UFO_E_ARG;
         if (sl < 1) return UFO_E_DECODE;
         scan_t sc;
         sc.ns = s[0];
@@ -837,6 +840,7 @@ static int decode_stream(const uint8_t* data, size_t len, dec_t* d, uint8_t* rgb
   }
   if (!rgb) return d->saw_sof ? UFO_OK : UFO_E_DECODE;
   if (!scans) return UFO_E_DECODE;
+  if (coef_only) return UFO_OK;
   return finish_image(d, rgb);
 }
 
@@ -863,6 +867,31 @@ int ufo_jpeg_decode_rgb(const uint8_t* data, size_t len, uint8_t* rgb, int width
   if (!data || !rgb) return UFO_E_ARG;
   dec_t d;
   int rc = decode_stream(data, len, &d, rgb, width, height);
+  dec_free(&d);
+  return rc;
+}
+
+int ufo_jpeg_coefficients(const uint8_t* data, size_t len, int16_t* coef, size_t cap_i16, size_t* n_i16) {
+  dec_t d;
+  uint8_t dummy;
+  int rc = decode_stream_ex(data, len, &d, coef ? &dummy : NULL, 0, 0, 1);
+  if (rc == UFO_OK) {
+    size_t total = 0;
+    for (int i = 0; i < d.ncomp; i++) total += (size_t)d.comp[i].wblk * d.comp[i].hblk * 64;
+    if (n_i16) *n_i16 = total;
+    if (coef) {
+      if (cap_i16 < total) {
+        rc = UFO_E_ARG;
+      } else {
+        size_t o = 0;
+        for (int i = 0; i < d.ncomp; i++) {
+          size_t n = (size_t)d.comp[i].wblk * d.comp[i].hblk * 64;
+          memcpy(coef + o, d.comp[i].coef, n * sizeof(int16_t));
+          o += n;
+        }
+      }
+    }
+  }
   dec_free(&d);
   return rc;
 }

@@ -50,6 +50,11 @@ int ufo_jpeg_probe(const uint8_t* data, size_t len, ufo_jpeg_info* info);
 /* rgb: height*width*3 bytes, interleaved, pitch = 3*width */
 int ufo_jpeg_decode_rgb(const uint8_t* data, size_t len, uint8_t* rgb, int width, int height);
 
+/* entropy-decoded quantised coefficients, int16 natural order, [comp][block_row][block_col][64]
+ * with MCU-padded block counts (for checking the product's host Huffman stage on a CPU box).
+ * coef may be NULL to query *n_i16. */
+int ufo_jpeg_coefficients(const uint8_t* data, size_t len, int16_t* coef, size_t cap_i16, size_t* n_i16);
+
 /* ---- A2/A3: image::imageops::resize(.., FilterType::Triangle)  (nn.rs:74-80) ---- */
 /* src: sh x sw x 3 u8 (pitch 3*sw), dst: dh x dw x 3 u8 */
 int ufo_resize_triangle_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);

@@ -1,0 +1,186 @@
+"""GPU parity tests: every stage of the hot path through the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import assert_dets_match, dets_array
+
+pytestmark = pytest.mark.gpu
+
+VARIANT_WH = {640: (640, 480), 320: (320, 240)}
+
+
+def make_model(variant, weights, **kw):
+    from infercam_onnx_amd import nn, synth
+
+    v = nn.UltrafaceVariant.W640H480 if variant == 640 else nn.UltrafaceVariant.W320H240
+    W, H = v.width_height()
+    kw.setdefault("max_src", (1280, 960))
+    return nn.UltrafaceModel(v, 0.5, 0.5, weights=weights, priors=synth.gen_priors(W, H), **kw)
+
+
+@pytest.fixture(scope="module")
+def model320(weights):
+    m = make_model(320, weights, max_batch=4, keep_layers=True)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def model640(weights):
+    m = make_model(640, weights, max_batch=8)
+    yield m
+    m.close()
+
+
+# ---------------------------------------------------------------- A1
+@pytest.mark.parametrize("size", [(640, 480), (320, 240), (641, 479), (17, 9), (1, 1), (1280, 720), (100, 37)])
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2", "4:4:4"])
+def test_jpeg_decode_bit_exact(model320, oracle_lib, size, subsampling):
+    from infercam_onnx_amd import synth
+
+    w, h = size
+    for kw in ({}, {"restart_rows": 1}, {"progressive": True}):
+        jpeg = synth.encode_jpeg(synth.synth_frame(11, w + h, w, h), quality=90, subsampling=subsampling, **kw)
+        got = model320.debug_decode_jpeg(jpeg)
+        ref = oracle_lib.jpeg_decode_rgb(jpeg)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), "decode mismatch %s %s %s: %d px differ" % (size, subsampling, kw, (got != ref).sum())
+
+
+def test_jpeg_decode_gray_and_quality(model320, oracle_lib):
+    from PIL import Image
+    import io
+    from infercam_onnx_amd import synth
+
+    f = synth.synth_frame(5, 0, 333, 111)
+    bio = io.BytesIO()
+    Image.fromarray(f[:, :, 0]).save(bio, "JPEG", quality=85)
+    jpeg = bio.getvalue()
+    assert np.array_equal(model320.debug_decode_jpeg(jpeg), oracle_lib.jpeg_decode_rgb(jpeg))
+    for q in (30, 100):
+        jpeg = synth.encode_jpeg(f, quality=q)
+        assert np.array_equal(model320.debug_decode_jpeg(jpeg), oracle_lib.jpeg_decode_rgb(jpeg))
+
+
+def test_corrupt_jpeg_is_an_error_not_a_crash(model320):
+    from infercam_onnx_amd import nn, synth
+
+    jpeg = synth.encode_jpeg(synth.synth_frame(1, 1, 320, 240))
+    for bad in (jpeg[:500], jpeg[:-2], b"\xff\xd8\xff", b"not a jpeg"):
+        with pytest.raises(nn.UfdError) as e:
+            model320.infer_jpeg(bad)
+        assert e.value.code == nn.UFD_E_DECODE
+    res, status = model320.infer_jpeg_batch([jpeg, jpeg[:500], jpeg])
+    assert status[0] == 0 and status[2] == 0 and status[1] == nn.UFD_E_DECODE
+    assert res[1] is None and res[0] == res[2]
+
+
+# ---------------------------------------------------------------- A2-A4
+@pytest.mark.parametrize("src", [(1280, 720), (640, 427), (640, 960), (320, 240), (640, 480), (100, 37), (333, 500)])
+@pytest.mark.parametrize("variant", [320, 640])
+def test_preproc_bit_exact(model320, model640, oracle_lib, src, variant):
+    from infercam_onnx_amd import synth
+
+    m = model320 if variant == 320 else model640
+    W, H = VARIANT_WH[variant]
+    rgb = synth.synth_frame(7, src[0], src[0], src[1])
+    got = m.debug_preproc(rgb)
+    ref = oracle_lib.normalize_nchw(oracle_lib.resize_triangle(rgb, W, H))
+    assert np.array_equal(got, ref), "preproc mismatch: %d values differ, max %g" % ((got != ref).sum(), np.abs(got - ref).max())
+
+
+# ---------------------------------------------------------------- A6
+def test_forward_per_layer(model320, oracle_lib, weights):
+    from infercam_onnx_amd import synth
+
+    W, H = 320, 240
+    pri = synth.gen_priors(W, H)
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(21, i, W, H)) for i in range(2)])
+    scores, boxes = model320.debug_forward(x)
+    for f in range(2):
+        rs, rb, outs = oracle_lib.forward(x[f], weights, pri, layers=True)
+        for li, ref in enumerate(outs):
+            got = model320.debug_layer_output(li, f).reshape(ref.shape)
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(got - ref).max() / scale
+            assert err <= 1e-5, "layer %d frame %d: rel err %g" % (li, f, err)
+        assert np.abs(scores[f] - rs).max() <= 1e-5
+        assert np.abs(boxes[f] - rb).max() <= 1e-5
+
+
+def test_forward_640_batch(model640, oracle_lib, weights):
+    from infercam_onnx_amd import synth
+
+    W, H = 640, 480
+    pri = synth.gen_priors(W, H)
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(22, i, W, H)) for i in range(3)])
+    scores, boxes = model640.debug_forward(x)
+    for f in range(3):
+        rs, rb = oracle_lib.forward(x[f], weights, pri)
+        assert np.abs(scores[f] - rs).max() <= 1e-5
+        assert np.abs(boxes[f] - rb).max() <= 1e-5
+
+
+# ---------------------------------------------------------------- A7-A10
+def test_postproc_exact_on_same_inputs(model320, oracle_lib):
+    rng = np.random.default_rng(5)
+    K = model320.num_priors
+    for trial, frac in enumerate((0.0, 0.002, 0.05, 0.6, 1.0)):
+        conf = rng.random(K).astype(np.float32) * 0.5
+        hot = rng.random(K) < frac
+        conf[hot] = 0.5 + rng.random(hot.sum()).astype(np.float32) * 0.5
+        if trial == 2:
+            conf[hot] = np.round(conf[hot] * 8) / 8  # exact ties: processing order = higher index first
+        scores = np.stack([1 - conf, conf], 1).astype(np.float32)
+        c = rng.random((K, 2)).astype(np.float32)
+        s = (rng.random((K, 2)).astype(np.float32) * 0.2 + 0.01)
+        boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+        boxes[::97, 2] = boxes[::97, 0] - 0.01  # degenerate boxes: zero area
+        got = dets_array(model320.debug_postproc(scores[None], boxes[None])[0])
+        ref = oracle_lib.postproc(scores, boxes, 0.5, 0.5)
+        assert got.shape == ref.shape, "trial %d: %d vs %d" % (trial, len(got), len(ref))
+        assert np.array_equal(got, ref), "trial %d differs" % trial
+
+
+# ---------------------------------------------------------------- end to end
+@pytest.mark.parametrize("variant,src", [(320, (320, 240)), (640, (640, 480)), (640, (1280, 720)), (320, (1280, 720)),
+                                         (640, (640, 427))])
+def test_infer_jpeg_end_to_end(model320, model640, oracle_lib, weights, variant, src):
+    from infercam_onnx_amd import synth
+
+    m = model320 if variant == 320 else model640
+    W, H = VARIANT_WH[variant]
+    pri = synth.gen_priors(W, H)
+    jpegs = [synth.encode_jpeg(synth.synth_frame(31, i, src[0], src[1])) for i in range(3)]
+    res, status = m.infer_jpeg_batch(jpegs)
+    assert status == [0, 0, 0]
+    for j, r in zip(jpegs, res):
+        ref = oracle_lib.infer_jpeg(j, W, H, weights, pri, 0.5, 0.5)
+        x = oracle_lib.normalize_nchw(oracle_lib.resize_triangle(oracle_lib.jpeg_decode_rgb(j), W, H))
+        scores, _ = oracle_lib.forward(x, weights, pri)
+        assert_dets_match(dets_array(r), ref, scores=scores, what="jpeg %s->%d" % (src, variant))
+        assert_dets_match(dets_array(m.infer_jpeg(j)), ref, scores=scores)
+
+
+def test_infer_rgb_matches_reference_run(model640, oracle_lib, weights):
+    from infercam_onnx_amd import synth
+
+    pri = synth.gen_priors(640, 480)
+    for src in ((640, 480), (640, 427), (1280, 720)):
+        rgb = synth.synth_frame(41, 3, src[0], src[1])
+        ref = oracle_lib.infer_rgb(rgb, 640, 480, weights, pri, 0.5, 0.5)
+        x = oracle_lib.normalize_nchw(oracle_lib.resize_triangle(rgb, 640, 480))
+        scores, _ = oracle_lib.forward(x, weights, pri)
+        assert_dets_match(dets_array(model640.run(rgb)), ref, scores=scores, what="rgb %s" % (src,))
+
+
+def test_async_submit_wait_order(model640, oracle_lib, weights):
+    from infercam_onnx_amd import synth
+
+    jpegs = [synth.encode_jpeg(synth.synth_frame(51, i, 640, 480)) for i in range(8)]
+    sync, _ = model640.infer_jpeg_batch(jpegs)
+    t1 = model640.submit_jpeg_batch(jpegs[:4])
+    t2 = model640.submit_jpeg_batch(jpegs[4:])
+    r2, _ = model640.wait(t2)
+    r1, _ = model640.wait(t1)
+    assert r1 + r2 == sync
