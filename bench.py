@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec end-to-end (JPEG bytes -> post-NMS boxes), UltraFace-640 @ 640x480.
+
+One "step" = one pass of the hot path over one batch of 32 synthetic 640x480 camera-like JPEGs
+(BASELINE.json configs[2]/[3]).  One process per GPU; independent camera
+streams shard one-per-GPU ("weak" scaling) and the only collective is the start-up RCCL
+broadcast of the weight blob.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+# bench kernel label -> device function name (as rocprofv3 --kernel-trace --stats prints it)
+KERNEL_FUNCS = {
+    "conv_pointwise_mfma": "k_conv_pointwise_mfma",
+    "conv_direct_dw": "k_conv_direct<1, true>",
+    "conv_direct_full": "k_conv_direct<16|4, false>",
+    "idct": "k_idct",
+    "upsample_norm": "k_upsample_norm",
+    "upsample_rgb": "k_upsample_rgb",
+    "resize_norm": "k_resize_norm",
+    "head_decode": "k_head_decode",
+    "sort_nms": "k_sort_nms",
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (async submit/wait)")
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(jpegs, weights, priors, budget_s):
+    """The CPU oracle (oracle/, a single-threaded plain-C port of the reference path) timed on
+    this host on a bounded sample of the same frames."""
+    import oracle
+
+    oracle.build()
+    oracle.infer_jpeg(jpegs[0], 640, 480, weights, priors)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.infer_jpeg(jpegs[n % len(jpegs)], 640, 480, weights, priors, 0.5, 0.5)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 4 * len(jpegs):
+            break
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the bench's 640x480 JPEG frames, full path decode->NMS, 1 thread, %.1f s" % (n, el)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from infercam_onnx_amd import nn, synth
+
+    W, H, B = 640, 480, args.batch
+    # ---- weights: generated on rank 0, broadcast over RCCL (the path's only collective)
+    nfl = synth.T.total_weight_floats()
+    if rank == 0:
+        wt = torch.from_numpy(synth.synthetic_weights()).cuda()
+    else:
+        wt = torch.empty(nfl, dtype=torch.float32, device="cuda")
+    if dist is not None:
+        dist.broadcast(wt, src=0)
+    weights = wt.cpu().numpy()
+    priors = synth.gen_priors(W, H)
+
+    # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
+    jpegs = synth.synth_jpeg_pool(rank, args.pool, W, H, quality=90, subsampling="4:2:0")
+    model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
+                              weights=weights, priors=priors, max_src=(W, H), host_threads=args.host_threads,
+                              profile=True, det_cap=256)
+    nb = max(1, args.pool // B)
+    batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+
+    def run_steps(k):
+        inflight = []
+        dets = 0
+        for s in range(k):
+            if len(inflight) >= args.depth:
+                cnt, _ = model.wait(inflight.pop(0), collect=False)
+                dets += sum(cnt)
+            inflight.append(model.submit_jpeg_batch(batches[s % nb]))
+        for t in inflight:
+            cnt, _ = model.wait(t, collect=False)
+            dets += sum(cnt)
+        return dets
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    model.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    ndet = run_steps(args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    stats = model.profile_read()
+
+    if rank == 0:
+        frames = world * B * args.steps
+        # ---- roofline of the dominant kernel (device time from HIP events on the library's stream)
+        agg = {}
+        for st in stats:
+            key = st["name"].split(":")[0]
+            a = agg.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            a["ms"] += st["total_ms"]
+            a["launches"] += st["launches"]
+            a["bytes"] += st["bytes"]
+            a["flops"] += st["flops"]
+        kern = {k: v for k, v in agg.items() if k != "h2d_coef"}
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        if dom == "conv_pointwise_mfma" and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+            roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
+        else:
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        roof.update({"traffic": None, "kernel": KERNEL_FUNCS.get(dom, dom),
+                     "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
+        gpu_ms = sum(v["ms"] for v in kern.values())
+        out = {
+            "metric": "frames/sec end-to-end (decode->NMS), UltraFace-640 @ 640x480",
+            "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UltraFace-640, one 640x480 synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
+                                   "frames), batch=%d, seeded synthetic weights" % (args.pool, B),
+                       "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
+                       "timed_region": "host JPEG bytes -> host detections (host Huffman + PCIe included)",
+                       "async_depth": args.depth},
+            "roofline": roof,
+            "gpu_ms_per_step": round(gpu_ms / args.steps, 3),
+            "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+            "detections_per_frame": round(ndet / (B * args.steps), 2),
+        }
+        dump = os.environ.get("UFD_BENCH_DUMP")
+        if dump:
+            with open(dump, "w") as f:
+                json.dump({"steps": args.steps, "batch": B, "stats": stats}, f, indent=1)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

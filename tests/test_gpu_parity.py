@@ -15,6 +15,7 @@ def make_model(variant, weights, **kw):
     v = nn.UltrafaceVariant.W640H480 if variant == 640 else nn.UltrafaceVariant.W320H240
     W, H = v.width_height()
     kw.setdefault("max_src", (1280, 960))
+    kw.setdefault("det_cap", 17640)
     return nn.UltrafaceModel(v, 0.5, 0.5, weights=weights, priors=synth.gen_priors(W, H), **kw)
 
 
