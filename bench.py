@@ -87,18 +87,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
 
-    from infercam_onnx_amd import nn, synth
+    from infercam_onnx_amd import nn, parallel, synth
 
     W, H, B = 640, 480, args.batch
     # ---- weights: generated on rank 0, broadcast over RCCL (the path's only collective)
-    nfl = synth.T.total_weight_floats()
-    if rank == 0:
-        wt = torch.from_numpy(synth.synthetic_weights()).cuda()
-    else:
-        wt = torch.empty(nfl, dtype=torch.float32, device="cuda")
-    if dist is not None:
-        dist.broadcast(wt, src=0)
-    weights = wt.cpu().numpy()
+    weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist,
+                                         device=torch.device("cuda", local_rank))
     priors = synth.gen_priors(W, H)
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
@@ -134,10 +128,7 @@ def main():
     ndet = run_steps(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = parallel.max_over_ranks(el, dist, device=torch.device("cuda", local_rank))
     stats = model.profile_read()
 
     if rank == 0:

@@ -134,6 +134,11 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
 int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, size_t cap_i16, uint32_t* n_i16,
                                 uint32_t* w, uint32_t* h);
 
+/* get_model alone (nn.rs:143-175; no GPU needed): parse an UltraFace-RFB .onnx into the packed
+ * blob (273 888 floats) and, if the graph embeds them, the K*4 priors (*priors_found = 1). */
+int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size_t weights_cap, float* priors,
+                        size_t priors_cap, uint32_t* priors_found, char* err, size_t err_cap);
+
 /* ---- measurement (bench.py roofline): per-kernel device time from HIP events on the handle's
  * stream; needs UFD_FLAG_PROFILE.  ufd_profile_reset() zeroes the accumulators. */
 typedef struct ufd_kernel_stat {

@@ -1080,6 +1080,30 @@ int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, 
   }
 }
 
+int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size_t weights_cap, float* priors,
+                        size_t priors_cap, uint32_t* priors_found, char* err, size_t err_cap) {
+  try {
+    if (!path || !weights || (variant != 640 && variant != 320)) return UFD_E_ARG;
+    std::vector<float> blob, pri;
+    std::string why;
+    const int W = variant == 640 ? 640 : 320, H = variant == 640 ? 480 : 240;
+    if (!load_ultraface_onnx(path, W, H, &blob, &pri, &why)) {
+      if (err && err_cap) std::snprintf(err, err_cap, "%s", why.c_str());
+      return UFD_E_WEIGHTS;
+    }
+    if (weights_cap < blob.size()) return UFD_E_ARG;
+    std::memcpy(weights, blob.data(), blob.size() * sizeof(float));
+    if (priors_found) *priors_found = pri.empty() ? 0 : 1;
+    if (!pri.empty() && priors) {
+      if (priors_cap < pri.size()) return UFD_E_ARG;
+      std::memcpy(priors, pri.data(), pri.size() * sizeof(float));
+    }
+    return UFD_OK;
+  } catch (...) {
+    return UFD_E_DEVICE;
+  }
+}
+
 int ufd_profile_reset(ufd_model* m) {
   return guarded(m, [&]() -> int {
     HIPC(m, hipStreamSynchronize(m->stream));

@@ -48,7 +48,7 @@ ABI_SYMBOLS = (
     "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
     "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
-    "ufd_debug_jpeg_coefficients", "ufd_profile_reset", "ufd_profile_read",
+    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_read",
 )
 
 _lib = None
@@ -89,6 +89,7 @@ def load_library():
     L.ufd_debug_layer_output.argtypes = [vp, u32, u32, vp, sz, ctypes.POINTER(sz)]
     L.ufd_debug_postproc.argtypes = [vp, vp, vp, u32, vp, u32, vp]
     L.ufd_debug_jpeg_coefficients.argtypes = [vp, sz, vp, sz, pu32, pu32, pu32]
+    L.ufd_debug_load_onnx.argtypes = [ctypes.c_char_p, u32, vp, sz, vp, sz, pu32, ctypes.c_char_p, sz]
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
     _lib = L
@@ -109,6 +110,23 @@ def jpeg_coefficients(jpeg):
     if rc:
         raise UfdError(rc, "jpeg entropy decode")
     return coef, w.value, h.value
+
+
+def load_onnx(path, variant=640):
+    """get_model's parsing step alone (host only): .onnx -> (packed weight blob, priors or None)."""
+    from . import topology as T
+
+    L = load_library()
+    w, h = T.VARIANTS[variant]
+    blob = np.empty(T.total_weight_floats(), np.float32)
+    pri = np.empty((T.num_priors(w, h), 4), np.float32)
+    found = ctypes.c_uint32()
+    err = ctypes.create_string_buffer(256)
+    rc = L.ufd_debug_load_onnx(os.fsencode(path), variant, blob.ctypes.data, blob.size, pri.ctypes.data, pri.size,
+                               ctypes.byref(found), err, 256)
+    if rc:
+        raise UfdError(rc, err.value.decode())
+    return blob, (pri if found.value else None)
 
 
 #: Bounding box `[x_top_left, y_top_left, x_bottom_right, y_bottom_right]` (nn.rs:12)

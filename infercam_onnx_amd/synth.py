@@ -110,3 +110,99 @@ def synth_jpeg_pool(stream_id, count, width, height, quality=90, subsampling="4:
     """Pool of `count` distinct frames for one camera stream (seed 0x5EED0000 + stream_id)."""
     seed = DEFAULT_FRAME_SEED + int(stream_id)
     return [encode_jpeg(synth_frame(seed, i, width, height), quality, subsampling, restart_rows) for i in range(count)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Minimal ONNX writer (protobuf wire format by hand; onnx.proto3 field numbers) so the loader
+# (csrc/onnx_loader.cpp, replacing tract's ONNX front end, nn.rs:166-172) can be exercised
+# without the real model file.
+def _varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(field, payload):
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def _vi(field, v):
+    return _varint(field << 3) + _varint(v)
+
+
+def _tensor(name, arr):
+    arr = np.ascontiguousarray(arr)
+    dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 7}[arr.dtype]
+    return b"".join(_vi(1, d) for d in arr.shape) + _vi(2, dt) + _ld(8, name.encode()) + _ld(9, arr.tobytes())
+
+
+def _attr_ints(name, vals):
+    return _ld(1, name.encode()) + b"".join(_vi(8, v) for v in vals) + _vi(20, 7)
+
+
+def _attr_int(name, v):
+    return _ld(1, name.encode()) + _vi(3, v) + _vi(20, 2)
+
+
+def _attr_float(name, v):
+    return _ld(1, name.encode()) + _varint((2 << 3) | 5) + np.float32(v).tobytes() + _vi(20, 1)
+
+
+def _attr_tensor(name, t):
+    return _ld(1, name.encode()) + _ld(5, t) + _vi(20, 4)
+
+
+def _node(op, ins, outs, attrs=()):
+    return (b"".join(_ld(1, i.encode()) for i in ins) + b"".join(_ld(2, o.encode()) for o in outs) + _ld(4, op.encode()) +
+            b"".join(_ld(5, a) for a in attrs))
+
+
+def write_onnx(path, blob, width, height, with_batchnorm=False, seed=99, priors_as="constant"):
+    """Writes an UltraFace-RFB-shaped ONNX file holding `blob`'s convolutions.  With
+    `with_batchnorm`, convs 0..24 (the BasicConv / conv_bn / conv_dw blocks upstream) are emitted
+    as bias-free Conv + BatchNormalization whose folding reproduces `blob`; returns the blob the
+    loader is expected to produce."""
+    rng = np.random.default_rng(seed)
+    nodes, inits = [], []
+    expect = np.array(blob, np.float32, copy=True)
+    for i, (s, (wo, bo)) in enumerate(zip(T.CONVS, T.weight_offsets())):
+        w, b = layer_params(blob, i)
+        attrs = [_attr_ints("dilations", [s.dil] * 2), _attr_int("group", s.groups),
+                 _attr_ints("kernel_shape", [s.k] * 2), _attr_ints("pads", [s.pad] * 4),
+                 _attr_ints("strides", [s.stride] * 2)]
+        x, wn, bn, y = "x%d" % i, "w%d" % i, "b%d" % i, "y%d" % i
+        if with_batchnorm and i <= 24:
+            gamma = rng.uniform(0.5, 1.5, s.cout).astype(np.float32)
+            beta = rng.normal(0, 0.1, s.cout).astype(np.float32)
+            mean = rng.normal(0, 0.1, s.cout).astype(np.float32)
+            var = rng.uniform(0.5, 1.5, s.cout).astype(np.float32)
+            eps = np.float32(1e-5)
+            inits += [_tensor(wn, w)] + [_tensor("%s_%s" % (bn, k), v) for k, v in
+                                         (("g", gamma), ("b", beta), ("m", mean), ("v", var))]
+            nodes.append(_node("Conv", [x, wn], [y + "_c"], attrs))
+            nodes.append(_node("BatchNormalization", [y + "_c", bn + "_g", bn + "_b", bn + "_m", bn + "_v"], [y],
+                               [_attr_float("epsilon", eps), _attr_float("momentum", 0.9)]))
+            sc = gamma / np.sqrt(var + eps)
+            n = T.weight_count(s)
+            expect[wo:wo + n] = (w * sc[:, None, None, None]).ravel()
+            expect[bo:bo + s.cout] = beta + (np.float32(0) - mean) * sc
+        else:
+            inits += [_tensor(wn, w), _tensor(bn, b)]
+            nodes.append(_node("Conv", [x, wn, bn], [y], attrs))
+        if s.relu:
+            nodes.append(_node("Relu", [y], [y + "_r"]))
+    pri = gen_priors(width, height)[None]
+    if priors_as == "constant":
+        nodes.append(_node("Constant", [], ["priors"], [_attr_tensor("value", _tensor("", pri))]))
+    elif priors_as == "initializer":
+        inits.append(_tensor("priors", pri))
+    graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"ultraface-rfb-synthetic") + b"".join(_ld(5, t) for t in inits)
+    model = _vi(1, 4) + _ld(2, b"infercam_onnx_amd.synth") + _ld(7, graph) + _ld(8, _vi(2, 9))
+    with open(path, "wb") as f:
+        f.write(model)
+    return expect

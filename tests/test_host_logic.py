@@ -1,0 +1,140 @@
+"""Host-side logic of the product library that needs no GPU: the C-ABI surface, the host Huffman
+stage, the ONNX loader, the Python mirror of nn.rs, and loud failure without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from infercam_onnx_amd import nn
+
+    lib = nn.load_library()
+    header = open(os.path.join(ROOT, "include", "ufd.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(ufd_\w+)\s*\(", header, re.M))
+    assert declared == set(nn.ABI_SYMBOLS), declared ^ set(nn.ABI_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
+def test_no_oracle_in_product():
+    """The product must not include, link or import the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "infercam_onnx_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", "Makefile")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "ufd_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("kw", [{}, {"restart_rows": 1}, {"progressive": True}, {"optimize": True},
+                                {"subsampling": "4:2:2"}, {"subsampling": "4:4:4"}, {"quality": 30}])
+@pytest.mark.parametrize("size", [(640, 480), (65, 47), (1, 1)])
+def test_host_huffman_coefficients_match_oracle(oracle_lib, kw, size):
+    import ctypes
+    from infercam_onnx_amd import nn, synth
+
+    jpeg = synth.encode_jpeg(synth.synth_frame(13, size[0], size[0], size[1]), **kw)
+    coef, w, h = nn.jpeg_coefficients(jpeg)
+    L = oracle_lib.lib()
+    L.ufo_jpeg_coefficients.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t)]
+    buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+    n = ctypes.c_size_t()
+    assert L.ufo_jpeg_coefficients(buf, len(jpeg), None, 0, ctypes.byref(n)) == 0
+    ref = np.empty(n.value, np.int16)
+    assert L.ufo_jpeg_coefficients(buf, len(jpeg), ref.ctypes.data, ref.size, ctypes.byref(n)) == 0
+    assert (w, h) == size and np.array_equal(coef, ref)
+
+
+def test_host_huffman_reference_test_pics(oracle_lib):
+    import ctypes
+    from infercam_onnx_amd import nn
+
+    d = os.path.join(ROOT, "tests", "golden", "test_pics")
+    L = oracle_lib.lib()
+    L.ufo_jpeg_coefficients.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t)]
+    for f in sorted(os.listdir(d))[:3]:
+        jpeg = open(os.path.join(d, f), "rb").read()
+        coef, w, h = nn.jpeg_coefficients(jpeg)
+        buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+        n = ctypes.c_size_t(coef.size)
+        ref = np.empty(coef.size, np.int16)
+        assert L.ufo_jpeg_coefficients(buf, len(jpeg), ref.ctypes.data, ref.size, ctypes.byref(n)) == 0
+        assert np.array_equal(coef, ref), f
+
+
+def test_corrupt_jpeg_status_codes():
+    from infercam_onnx_amd import nn, synth
+
+    jpeg = synth.encode_jpeg(synth.synth_frame(1, 1, 64, 48))
+    for bad in (jpeg[:300], jpeg[:-2], b"\xff\xd8\xff", b"junk"):
+        with pytest.raises(nn.UfdError) as e:
+            nn.jpeg_coefficients(bad)
+        assert e.value.code == nn.UFD_E_DECODE
+    # arithmetic-coded / lossless SOF markers are "unsupported", not "corrupt"
+    sof9 = jpeg.replace(b"\xff\xc0", b"\xff\xc9", 1)
+    with pytest.raises(nn.UfdError) as e:
+        nn.jpeg_coefficients(sof9)
+    assert e.value.code == nn.UFD_E_UNSUPPORTED
+
+
+def test_onnx_loader_roundtrip_and_bn_folding(tmp_path, weights):
+    from infercam_onnx_amd import nn, synth
+
+    for variant, (w, h) in ((640, (640, 480)), (320, (320, 240))):
+        for bn in (False, True):
+            for pri_as in ("constant", "initializer", "none"):
+                p = str(tmp_path / ("m_%d_%d_%s.onnx" % (variant, bn, pri_as)))
+                expect = synth.write_onnx(p, weights, w, h, with_batchnorm=bn, priors_as=pri_as)
+                blob, pri = nn.load_onnx(p, variant)
+                assert np.allclose(blob, expect, rtol=1e-6, atol=1e-7)
+                if bn:
+                    assert not np.array_equal(expect, weights)
+                if pri_as == "none":
+                    assert pri is None
+                else:
+                    assert np.array_equal(pri, synth.gen_priors(w, h))
+
+
+def test_onnx_loader_rejects_other_graphs(tmp_path, weights):
+    from infercam_onnx_amd import nn, synth
+
+    p = str(tmp_path / "m.onnx")
+    synth.write_onnx(p, weights, 640, 480)
+    data = open(p, "rb").read()
+    with pytest.raises(nn.UfdError) as e:
+        nn.load_onnx(str(tmp_path / "missing.onnx"), 640)
+    assert e.value.code == nn.UFD_E_WEIGHTS
+    open(p, "wb").write(data[: len(data) // 2])
+    with pytest.raises(nn.UfdError):
+        nn.load_onnx(p, 640)
+    open(p, "wb").write(b"\x08\x04")  # a ModelProto without a graph
+    with pytest.raises(nn.UfdError):
+        nn.load_onnx(p, 640)
+
+
+def test_variant_mirror_and_loud_failure_without_gpu(weights):
+    import torch
+    from infercam_onnx_amd import nn
+
+    assert nn.UltrafaceVariant.W640H480.width_height() == (640, 480)  # nn.rs:36-41
+    assert nn.UltrafaceVariant.W320H240.width_height() == (320, 240)
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(nn.UfdError) as e:
+            nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights)
+        assert e.value.code == nn.UFD_E_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_synthetic_inputs_are_deterministic():
+    from infercam_onnx_amd import synth
+
+    a, b = synth.synthetic_weights(), synth.synthetic_weights()
+    assert np.array_equal(a, b) and a.size == 273888
+    assert np.array_equal(synth.synth_frame(1, 2, 64, 48), synth.synth_frame(1, 2, 64, 48))
+    assert not np.array_equal(synth.synth_frame(1, 2, 64, 48), synth.synth_frame(1, 3, 64, 48))
+    j = synth.encode_jpeg(synth.synth_frame(synth.DEFAULT_FRAME_SEED, 0, 640, 480))
+    assert 15000 < len(j) < 90000  # camera-like size, not incompressible noise

@@ -1,0 +1,84 @@
+"""Oracle pinning, rows A2-A4: Triangle resize (image 0.24.5 sample.rs semantics) and
+the normalisation closure (nn.rs:82-93), against analytic tap tables and an independent numpy twin."""
+import numpy as np
+import pytest
+
+
+def axis_weights(S, D):
+    """independent float32 numpy restatement of the per-axis window of sample.rs"""
+    f = np.float32
+    ratio = f(S) / f(D)
+    sratio = max(ratio, f(1))
+    out = []
+    for o in range(D):
+        c = (f(o) + f(0.5)) * ratio
+        left = int(min(max(np.floor(c - sratio), 0), S - 1))
+        right = int(min(max(np.ceil(c + sratio), left + 1), S))
+        c = c - f(0.5)
+        w = np.array([max(f(0), f(1) - abs((f(i) - c) / sratio)) for i in range(left, right)], np.float32)
+        s = f(0)
+        for x in w:
+            s = f(s + x)
+        out.append((left, (w / s).astype(np.float32)))
+    return out
+
+
+def numpy_resize(src, dw, dh):
+    sh, sw, _ = src.shape
+    if (sw, sh) == (dw, dh):
+        return src.copy()
+    tmp = np.zeros((dh, sw, 3), np.float32)
+    for oy, (left, w) in enumerate(axis_weights(sh, dh)):
+        acc = np.zeros((sw, 3), np.float32)
+        for i, wi in enumerate(w):
+            acc = (acc + src[left + i].astype(np.float32) * wi).astype(np.float32)
+        tmp[oy] = acc
+    out = np.zeros((dh, dw, 3), np.uint8)
+    for ox, (left, w) in enumerate(axis_weights(sw, dw)):
+        acc = np.zeros((dh, 3), np.float32)
+        for i, wi in enumerate(w):
+            acc = (acc + tmp[:, left + i] * wi).astype(np.float32)
+        v = np.clip(acc, 0, 255)
+        out[:, ox] = np.where(v - np.floor(v) >= 0.5, np.floor(v) + 1, np.floor(v)).astype(np.uint8)  # round half away
+    return out
+
+
+def test_tap_tables_from_survey():
+    w = axis_weights(1280, 640)
+    assert np.allclose(w[5][1], [0.125, 0.375, 0.375, 0.125]) and len(w[0][1]) == 3
+    w = axis_weights(1280, 320)
+    assert np.allclose(w[7][1], np.array([1, 3, 5, 7, 7, 5, 3, 1]) / 32)
+    w = axis_weights(720, 240)
+    assert np.allclose(w[9][1], np.array([0, 1, 2, 3, 2, 1, 0]) / 9, atol=1e-7)
+    w = axis_weights(720, 480)
+    assert np.allclose(sorted(w[10][1]), sorted([0, 1 / 3, 5 / 9, 1 / 9]), atol=1e-6)
+    for left, ww in axis_weights(480, 480):
+        assert np.count_nonzero(ww) == 1 and ww.max() == 1.0  # identity
+
+
+@pytest.mark.parametrize("src,dst", [((128, 72), (64, 48)), ((64, 43), (64, 48)), ((37, 50), (64, 48)),
+                                     ((256, 144), (32, 24)), ((64, 48), (64, 48))])
+def test_resize_matches_numpy_twin(oracle_lib, src, dst):
+    from infercam_onnx_amd import synth
+
+    rgb = synth.synth_frame(9, src[0], src[0], src[1])
+    got = oracle_lib.resize_triangle(rgb, dst[0], dst[1])
+    assert np.array_equal(got, numpy_resize(rgb, dst[0], dst[1]))
+
+
+def test_constant_image_and_identity(oracle_lib):
+    rgb = np.full((90, 160, 3), 137, np.uint8)
+    assert (oracle_lib.resize_triangle(rgb, 64, 48) == 137).all()
+    from infercam_onnx_amd import synth
+
+    f = synth.synth_frame(1, 2, 64, 48)
+    assert np.array_equal(oracle_lib.resize_triangle(f, 64, 48), f)
+
+
+def test_normalize_closure(oracle_lib):
+    rgb = np.arange(256 * 3, dtype=np.uint32).reshape(16, 16, 3).astype(np.uint8)
+    got = oracle_lib.normalize_nchw(rgb)
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    ref = ((rgb.astype(np.float32) / np.float32(255.0) - mean) / std).transpose(2, 0, 1)
+    assert got.shape == (3, 16, 16) and np.array_equal(got, ref.astype(np.float32))
