@@ -26,7 +26,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
 # bench kernel label -> device function name (as rocprofv3 --kernel-trace --stats prints it)
 KERNEL_FUNCS = {
-    "conv_pointwise_mfma": "k_conv_pointwise_mfma",
+    "conv_pw_mfma": "k_pw_mfma",
+    "conv_dwpw_mfma": "k_dwpw_mfma",
+    "conv3x3_mfma": "k_conv3x3_mfma",
     "conv_direct_dw": "k_conv_direct<1, true>",
     "conv_direct_full": "k_conv_direct<16|4, false>",
     "idct": "k_idct",
@@ -147,7 +149,7 @@ def main():
         d = kern[dom]
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        if dom == "conv_pointwise_mfma" and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv3x3_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
             roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
         else:

@@ -56,7 +56,7 @@ typedef struct ufd_config {
   uint32_t max_batch;      /* frames per batched call (>= 1) */
   uint32_t max_src_width;  /* largest decoded frame accepted; 0 -> 1920 */
   uint32_t max_src_height; /* 0 -> 1088 */
-  uint32_t host_threads;   /* host entropy-decode workers; 0 -> min(16, hardware threads) */
+  uint32_t host_threads;   /* host entropy-decode workers; 0 -> min(32, hardware threads) */
   uint32_t flags;          /* UFD_FLAG_* */
   /* Weights: exactly one source.
    * (a) weights_path: an UltraFace-RFB .onnx (NULL and no blob -> the reference's cache path

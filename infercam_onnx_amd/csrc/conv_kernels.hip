@@ -1,41 +1,64 @@
 // conv_kernels.hip -- row A6: the 52 convolutions of UltraFace-RFB (what tract's SimplePlan::run
 // executes for `self.model.run(tvec!(input))`, infer_server/src/nn.rs:181; topology SURVEY 8.1).
-// Activations are planar NCHW f32 ([frame][channel][y][x]) so that consecutive lanes hold
-// consecutive pixels: depthwise stencils read rows, and the pointwise/implicit-GEMM kernels put
-// PIXELS on the MFMA column (lane) dimension and OUTPUT CHANNELS on rows -- every global access
-// is a 16-byte-per-lane row segment, no im2col buffer, no transposes.
 //
-//   k_conv_pointwise_mfma : 1x1 convs (66 % of the MACs) on v_mfma_f32_32x32x2_f32.  Exact fp32:
-//                           per output, acc = bias, then fma over input channels in order.
-//   k_conv_direct         : reference-order direct convolution for the remaining layer shapes
-//                           (stem, depthwise, dilated RFB 3x3, 3x3 heads).
+// Activations are planar NCHW f32 ([frame][channel][y][x]).  All MFMA kernels put PIXELS on the
+// matrix column (lane) dimension and OUTPUT CHANNELS on rows, so activation loads/stores are
+// row segments of the planes (16 B per lane where the shape allows), there is no im2col buffer
+// and no layout transform between layers.  The batch is flattened into the pixel dimension
+// (pixel groups are numbered over all frames), so small feature maps still fill whole waves.
+//
+//   k_pw_mfma        1x1 convs on v_mfma_f32_32x32x2_f32 (128 pixels x 32*CT couts per wave)
+//   k_dwpw_mfma      depthwise 3x3 (+bias, ReLU) computed per lane straight into the MFMA B
+//                    operand of the following 1x1 conv: the depthwise output never exists in
+//                    memory (18 of the network's dw->pw pairs)
+//   k_conv3x3_mfma   dense 3x3 (stem, dilated RFB convs, 3x3 heads) as implicit GEMM on
+//                    v_mfma_f32_16x16x4_f32: K runs over (channel, tap), 4 taps per instruction
+//   k_conv_direct    reference-order VALU fallback for shapes the MFMA kernels do not take
+//
+// Numerics: fp32 MFMA is an exact k-ordered fma chain, and every kernel keeps the order
+// "acc = bias; for ci, ky, kx: acc = fma(w, x, acc)" (zero taps add exactly 0), so results are
+// bit-identical to a plain fmaf loop nest in that order.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace ufd {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
 
 // ------------------------------------------------------------------------------------------------
-// Pointwise 1x1:  out[co][p] = act(bias[co] + sum_ci W[co][ci] * in[ci][p])
-// One wave computes a tile of 128 pixels x (CT*32) output channels:
-//   B operand (k x 32 pixels): lane l loads float4 in[ci = 2*ks + (l>>5)][p0 + 4*(l&31) .. +3];
-//                              component j feeds MFMA j, so lane column (l&31) <-> pixel 4*(l&31)+j
-//   A operand (32 couts x k):  pre-packed so that lane l reads W[ct*32 + (l&31)][2*ks + (l>>5)]
-//   D (32 couts x 32 pixels):  reg r, lane l -> cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel column l&31
-// After the K loop the 4 MFMA results of a register form a float4 of 4 consecutive pixels.
+// Shared tail of the 32x32x2 kernels.  D layout: reg r, lane l -> cout (r&3) + 8*(r>>2) + 4*(l>>5),
+// pixel column l&31; MFMA j of a k-step used component j of the lane's float4, so register r of
+// the four accumulators is the float4 of 4 consecutive pixels.
 template <int CT>
-__global__ __launch_bounds__(256) void k_conv_pointwise_mfma(ConvArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int frame = blockIdx.z;
-  const int hw = a.oh * a.ow;
-  const int p = (blockIdx.x * 4 + wave) * 128 + 4 * (lane & 31);
-  const int ct0 = blockIdx.y * CT;
-  const int half = lane >> 5;
-  const int ksteps = a.cin >> 1;
-  const bool live = p < hw;
+__device__ __forceinline__ void store_tiles(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half, size_t frame,
+                                            int pix, int hw) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.cout) {
+        float4 v = make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
+        if (a.res) {
+          const float4 q = *reinterpret_cast<const float4*>(a.res + (frame * a.cout + co) * hw + pix);
+          v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+        }
+        if (a.relu) v = relu4(v);
+        *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * hw + pix) = v;
+      }
+    }
+  }
+}
 
-  floatx16 acc[CT][4];
+template <int CT>
+__device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half) {
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
 #pragma unroll
@@ -46,7 +69,26 @@ __global__ __launch_bounds__(256) void k_conv_pointwise_mfma(ConvArgs a) {
       for (int j = 0; j < 4; j++) acc[ct][j][r] = b;
     }
   }
-  const float* in = a.in + ((size_t)frame * a.in_ctotal + half) * hw + (live ? p : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise 1x1:  out[co][p] = act(bias[co] + sum_ci W[co][ci] * in[ci][p])
+//   B operand (k x 32 pixel columns): lane l loads float4 in[ci = 2*ks + (l>>5)][4 pixels of group g]
+//   A operand (32 couts x k): pre-packed so that lane l reads W[ct*32 + (l&31)][2*ks + (l>>5)]
+// Pixel groups (4 consecutive pixels of one plane) are numbered over the whole batch.
+template <int CT>
+__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
+  const long g = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool live = g < (long)a.B * gpf;
+  const size_t frame = live ? g / gpf : 0;
+  const int pix = live ? (int)(g - (long)frame * gpf) * 4 : 0;
+  const int ct0 = blockIdx.y * CT, half = lane >> 5, ksteps = a.cin >> 1;
+
+  floatx16 acc[CT][4];
+  init_acc<CT>(a, acc, ct0, half);
+  const float* in = a.in + (frame * a.in_ctotal + half) * hw + pix;
   const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
   const size_t in_step = (size_t)2 * hw;
 #pragma unroll 4
@@ -61,29 +103,204 @@ __global__ __launch_bounds__(256) void k_conv_pointwise_mfma(ConvArgs a) {
       acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.w, acc[ct][3], 0, 0, 0);
     }
   }
-  if (!live) return;
+  if (live) store_tiles<CT>(a, acc, ct0, half, frame, pix, hw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused depthwise 3x3 (pad 1, stride S, +bias, ReLU) -> pointwise 1x1 (+bias, optional ReLU).
+// Lane l owns 4 consecutive output pixels (oy, ox..ox+3) and, per k-step, input channel
+// ci = 2*ks + (l>>5): it computes the depthwise result of that channel for its 4 pixels from a
+// 3 x (4*S+2) input window (aligned float4 row segments + edge scalars) and feeds it directly as
+// the B operand.  Needs ow % 4 == 0 and iw % 4 == 0.  a.w2/a.bias2 = depthwise weights [cin][9]
+// and bias [cin]; a.w/a.bias = packed pointwise weights and bias.
+template <int CT, int S>
+__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
+  extern __shared__ float s_dw[];  // [cin][12]: 9 taps, bias, pad
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < a.cin * 12; i += 256) {
+    const int c = i / 12, t = i - c * 12;
+    s_dw[i] = t < 9 ? a.w2[c * 9 + t] : (t == 9 ? a.bias2[c] : 0.0f);
+  }
+  __syncthreads();
+  const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
+  const long g = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool live = g < (long)a.B * gpf;
+  const size_t frame = live ? g / gpf : 0;
+  const int rem = live ? (int)(g - (long)frame * gpf) : 0;
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const int ct0 = blockIdx.y * CT, half = lane >> 5, ksteps = a.cin >> 1;
+  const int ihw = a.ih * a.iw;
+
+  floatx16 acc[CT][4];
+  init_acc<CT>(a, acc, ct0, half);
+
+  // input window: rows iy0..iy0+2, columns ix0-1 .. ix0+4*S (ix0 = ox*S is a multiple of 4).
+  // Loads are unconditional from clamped (always valid) addresses and zeroed by select
+  // afterwards, so the k-loop is branch-free and the loads of the next step can be hoisted.
+  const int iy0 = oy * S - 1, ix0 = ox * S;
+  bool rowok[3];
+  int rowoff[3];
 #pragma unroll
-  for (int ct = 0; ct < CT; ct++) {
+  for (int r = 0; r < 3; r++) {
+    rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
+    rowoff[r] = min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0;
+  }
+  const bool leftok = ix0 > 0;
+  const bool rightok = (S == 1) && (ix0 + 4 < a.iw);  // stride 2 never needs column ix0+8
+  const int loff = leftok ? -1 : 0, roff = rightok ? 4 : 0;
+  const float* in = a.in + (frame * a.in_ctotal + half) * ihw;
+  const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
+
+#pragma unroll 2
+  for (int ks = 0; ks < ksteps; ks++) {
+    const float* p = in + (size_t)(2 * ks) * ihw;
+    const float* wd = s_dw + (2 * ks + half) * 12;
+    float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.cout) {
-        float4 v = make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
-        if (a.res) {
-          const float4 q = *reinterpret_cast<const float4*>(a.res + ((size_t)frame * a.cout + co) * hw + p);
-          v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+    for (int r = 0; r < 3; r++) {
+      const float* row = p + rowoff[r];
+      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
+      if (S == 1) {
+        float4 m = *reinterpret_cast<const float4*>(row);
+        float l = row[loff], rr = row[roff];
+        m.x = rowok[r] ? m.x : 0.f, m.y = rowok[r] ? m.y : 0.f, m.z = rowok[r] ? m.z : 0.f, m.w = rowok[r] ? m.w : 0.f;
+        l = (rowok[r] && leftok) ? l : 0.f;
+        rr = (rowok[r] && rightok) ? rr : 0.f;
+        // per pixel, taps in kx order: x-1, x, x+1
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+        t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
+        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+      } else {
+        float4 m0 = *reinterpret_cast<const float4*>(row);
+        float4 m1 = *reinterpret_cast<const float4*>(row + 4);
+        float l = row[loff];
+        m0.x = rowok[r] ? m0.x : 0.f, m0.y = rowok[r] ? m0.y : 0.f, m0.z = rowok[r] ? m0.z : 0.f, m0.w = rowok[r] ? m0.w : 0.f;
+        m1.x = rowok[r] ? m1.x : 0.f, m1.y = rowok[r] ? m1.y : 0.f, m1.z = rowok[r] ? m1.z : 0.f, m1.w = rowok[r] ? m1.w : 0.f;
+        l = (rowok[r] && leftok) ? l : 0.f;
+        // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
+        t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
+        t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
+        t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
+      }
+    }
+    t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f), t2 = fmaxf(t2, 0.f), t3 = fmaxf(t3, 0.f);
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+      const float w = wp[((size_t)ct * ksteps + ks) * 64];
+      acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t0, acc[ct][0], 0, 0, 0);
+      acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t1, acc[ct][1], 0, 0, 0);
+      acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t2, acc[ct][2], 0, 0, 0);
+      acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t3, acc[ct][3], 0, 0, 0);
+    }
+  }
+  if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense 3x3 (any stride / dilation, pad = dilation, cout <= 16) as implicit GEMM on
+// v_mfma_f32_16x16x4_f32.  K runs over (input channel, tap) with the 9 taps of a channel padded
+// to 12 = 3 instructions of 4 taps: lane l supplies tap 4*s + (l>>4) of channel ci for pixel
+// column l&15 (a gather from the input plane, zero outside the image), so the accumulation order
+// is exactly ci-major / tap-minor.  A wave owns PG groups of 16 consecutive output pixels
+// (numbered over the whole batch); D: reg r, lane l -> cout 4*(l>>4) + r, pixel column l&15.
+// a.w: packed [cin][3][64] (lane l of slot s: W[l&15][ci][4s + (l>>4)], 0 for taps >= 9 / cout pad).
+template <int PG, int U>
+__global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, quad = lane >> 4;
+  const int ohw = a.oh * a.ow, ihw = a.ih * a.iw;
+  const long total = (long)a.B * ohw;
+  const long p0 = (((long)blockIdx.x * 4 + wave) * PG) * 16 + col;
+
+  // per pixel group: base pointer; per (slot, group): tap offset validity
+  const float* base[PG];
+  int off[3];
+  unsigned valid = 0;  // bit (s*PG + g)
+  bool live[PG];
+  long pidx[PG];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const int t = 4 * s + quad;
+    const int ky = t / 3, kx = t - ky * 3;
+    off[s] = (t < 9) ? ((ky - 1) * a.dil * a.iw + (kx - 1) * a.dil) : 0;
+  }
+  int goff[3][PG];  // per (slot, group) gather offset, 0 (the pixel itself: always valid) when masked
+#pragma unroll
+  for (int g = 0; g < PG; g++) {
+    const long p = p0 + (long)g * 16;
+    live[g] = p < total;
+    pidx[g] = p;
+    const long pc = live[g] ? p : 0;
+    const size_t frame = pc / ohw;
+    const int rem = (int)(pc - (long)frame * ohw);
+    const int oy = rem / a.ow, ox = rem - oy * a.ow;
+    const int iy = oy * a.stride, ix = ox * a.stride;
+    base[g] = a.in + frame * a.in_ctotal * (size_t)ihw + (size_t)iy * a.iw + ix;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int t = 4 * s + quad;
+      const int ky = t / 3, kx = t - ky * 3;
+      const int yy = iy + (ky - 1) * a.dil, xx = ix + (kx - 1) * a.dil;
+      const bool ok = live[g] && t < 9 && yy >= 0 && yy < a.ih && xx >= 0 && xx < a.iw;
+      valid |= (ok ? 1u : 0u) << (s * PG + g);
+      goff[s][g] = ok ? off[s] : 0;
+    }
+  }
+  floatx4 acc[PG];
+#pragma unroll
+  for (int g = 0; g < PG; g++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = 4 * quad + r;
+      acc[g][r] = co < a.cout ? a.bias[co] : 0.0f;
+    }
+  const float* wp = a.w + lane;
+  // U channels per iteration: their gathers are issued together (deep layers have one short
+  // dependent MFMA chain per wave and would otherwise pay a memory round trip per tap).
+  // Gathers are unconditional from clamped addresses; masked taps are zeroed by select.
+  for (int c0 = 0; c0 < a.cin; c0 += U) {
+    float x[U][3][PG], w[U][3];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const ptrdiff_t coff = (ptrdiff_t)(c0 + u) * ihw;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        w[u][s] = wp[((c0 + u) * 3 + s) * 64];
+#pragma unroll
+        for (int g = 0; g < PG; g++) x[u][s][g] = base[g][coff + goff[s][g]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          const float xv = ((valid >> (s * PG + g)) & 1u) ? x[u][s][g] : 0.0f;
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][s], xv, acc[g], 0, 0, 0);
         }
-        if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        *reinterpret_cast<float4*>(a.out + ((size_t)frame * a.out_ctotal + a.out_coff + co) * hw + p) = v;
+  }
+#pragma unroll
+  for (int g = 0; g < PG; g++) {
+    if (!live[g]) continue;
+    const size_t frame = pidx[g] / ohw;
+    const int rem = (int)(pidx[g] - (long)frame * ohw);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = 4 * quad + r;
+      if (co < a.cout) {
+        float v = acc[g][r];
+        if (a.relu) v = fmaxf(v, 0.0f);
+        a.out[(frame * a.out_ctotal + a.out_coff + co) * ohw + rem] = v;
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Direct convolution, one output pixel x COB output channels per thread.  Per output element:
-// acc = bias; for ci, ky, kx: acc = fma(w, x, acc) -- out-of-image taps skipped (they add 0).
-// Weight addresses are wave-uniform (scalar loads); activation loads are coalesced along x.
+// Direct convolution fallback, one output pixel x COB output channels per thread.
 template <int COB, bool DW>
 __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
   const int frame = blockIdx.z;
@@ -131,6 +348,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
 
 }  // namespace
 
+// ---------------------------------------------------------------- host side
 size_t pointwise_packed_floats(int cin, int cout) { return (size_t)((cout + 31) / 32) * (cin / 2) * 64; }
 
 void pack_pointwise_weights(const float* w, int cin, int cout, float* packed) {
@@ -143,14 +361,75 @@ void pack_pointwise_weights(const float* w, int cin, int cout, float* packed) {
       }
 }
 
+size_t conv3x3_packed_floats(int cin) { return (size_t)cin * 3 * 64; }
+
+void pack_conv3x3_weights(const float* w, int cin, int cout, float* packed) {
+  for (int ci = 0; ci < cin; ci++)
+    for (int s = 0; s < 3; s++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int co = lane & 15, t = 4 * s + (lane >> 4);
+        packed[((size_t)ci * 3 + s) * 64 + lane] = (co < cout && t < 9) ? w[((size_t)co * cin + ci) * 9 + t] : 0.0f;
+      }
+}
+
+bool dwpw_supported(const ConvArgs& a, int stride) {
+  return (a.ow % 4 == 0) && (a.iw % 4 == 0) && (a.cin % 2 == 0) && (stride == 1 || stride == 2) &&
+         (stride == 1 ? (a.iw == a.ow && a.ih == a.oh) : (a.iw == 2 * a.ow));
+}
+
+// Two 32-cout tiles per wave halve the activation reads but need 128 accumulator registers
+// (1 wave/SIMD); worth it only when the launch has far more wave tiles than the chip has SIMDs.
+static bool use_two_tiles(long groups, int cts) {
+  static const int force = std::getenv("UFD_CT") ? std::atoi(std::getenv("UFD_CT")) : 0;  // tuning knob
+  if (cts % 2) return false;
+  if (force) return force == 2;
+  const long waves_ct1 = (groups + 31) / 32 * cts;
+  return waves_ct1 >= 16384;
+}
+
 void launch_conv_pointwise_mfma(const ConvArgs& a, hipStream_t s) {
-  const int hw = a.oh * a.ow;
+  const long groups = (long)a.B * (a.oh * a.ow / 4);
+  const unsigned gx = (unsigned)((groups + 127) / 128);
   const int cts = (a.cout + 31) / 32;
-  const unsigned gx = (hw + 511) / 512;
-  if (cts % 2 == 0) {
-    hipLaunchKernelGGL(k_conv_pointwise_mfma<2>, dim3(gx, cts / 2, a.B), dim3(256), 0, s, a);
+  if (use_two_tiles(groups, cts)) {
+    hipLaunchKernelGGL(k_pw_mfma<2>, dim3(gx, cts / 2), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(k_conv_pointwise_mfma<1>, dim3(gx, cts, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pw_mfma<1>, dim3(gx, cts), dim3(256), 0, s, a);
+  }
+}
+
+void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s) {
+  const long groups = (long)a.B * (a.oh * a.ow / 4);
+  const unsigned gx = (unsigned)((groups + 127) / 128);
+  const int cts = (a.cout + 31) / 32;
+  const size_t lds = (size_t)a.cin * 12 * sizeof(float);
+  if (use_two_tiles(groups, cts)) {
+    if (stride == 1)
+      hipLaunchKernelGGL((k_dwpw_mfma<2, 1>), dim3(gx, cts / 2), dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_dwpw_mfma<2, 2>), dim3(gx, cts / 2), dim3(256), lds, s, a);
+  } else {
+    if (stride == 1)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1>), dim3(gx, cts), dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2>), dim3(gx, cts), dim3(256), lds, s, a);
+  }
+}
+
+void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s) {
+  const long total = (long)a.B * a.oh * a.ow;
+  if (total >= 64L * 4 * 1024) {  // enough pixels to fill the chip with 4 groups per wave
+    if (a.cin % 2 == 0)
+      hipLaunchKernelGGL((k_conv3x3_mfma<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  } else {
+    if (a.cin % 8 == 0)
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
+    else if (a.cin % 4 == 0)
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
   }
 }
 

@@ -44,6 +44,8 @@ struct ConvArgs {
   const float* bias;  // [cout]
   float* out;         // [B][out_ctotal][oh][ow], written at channel offset out_coff
   const float* res;   // optional residual [B][cout][oh][ow]: out = relu(conv + res)
+  const float* w2;    // fused dw->pw kernel: depthwise weights [cin][9]
+  const float* bias2; // fused dw->pw kernel: depthwise bias [cin]
   int32_t B, cin, cout, ih, iw, oh, ow;
   int32_t k, stride, pad, dil, depthwise, relu;
   int32_t in_ctotal, out_ctotal, out_coff;
@@ -55,6 +57,15 @@ void launch_conv_pointwise_mfma(const ConvArgs& a, hipStream_t s);
 // floats needed for the packed pointwise weight image of a cin->cout layer
 size_t pointwise_packed_floats(int cin, int cout);
 void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, float* packed);
+// Depthwise 3x3 (+ReLU) fused into the following pointwise conv.  `a` describes the pair:
+// in/ih/iw/cin = depthwise input, oh/ow/cout = pointwise output, w/bias = packed pointwise
+// weights, w2/bias2 = depthwise weights; relu applies to the pointwise output.
+bool dwpw_supported(const ConvArgs& a, int stride);
+void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s);
+// Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
+void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s);
+size_t conv3x3_packed_floats(int cin);
+void pack_conv3x3_weights(const float* w /*[cout][cin][3][3]*/, int cin, int cout, float* packed);
 
 // ---------------- A6 tail + A7: softmax, prior decode, threshold (post_kernels.hip) ----------------
 struct HeadArgs {

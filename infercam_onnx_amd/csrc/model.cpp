@@ -36,13 +36,23 @@ struct Tensor {
   size_t per_frame() const { return (size_t)c * h * w; }
 };
 
+enum LayerKind {
+  kKindPointwise,  // 1x1 on fp32 MFMA
+  kKindDwPw,       // 1x1 whose depthwise producer is fused in (the dw layer itself is kKindFusedAway)
+  kKindFusedAway,  // depthwise layer computed inside the following kKindDwPw launch
+  kKindConv3x3,    // dense 3x3 implicit GEMM on fp32 MFMA
+  kKindDirect,     // VALU fallback
+};
+
 struct Layer {
   ConvSpec spec;
   int ih, iw, oh, ow;
   int in_tensor, out_tensor, res_tensor;
   int out_coff;
-  bool pointwise;
-  const float* d_w = nullptr;
+  LayerKind kind;
+  int fused_dw = -1;       // kKindDwPw: index of the depthwise layer
+  bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
+  const float* d_w = nullptr;  // kernel-specific packing
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
 };
@@ -89,6 +99,7 @@ struct ufd_model {
   uint32_t B = 0;
   uint32_t max_w = 0, max_h = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
   std::unique_ptr<ThreadPool> pool;
 
   // resident model
@@ -103,8 +114,11 @@ struct ufd_model {
 
   // frame staging (device)
   size_t coef_stride = 0, plane_stride = 0, rgb_stride = 0;
-  JpegFrameDesc* d_descs = nullptr;
-  int16_t* d_coef = nullptr;
+  JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
+  int16_t* d_coef_buf[2] = {nullptr, nullptr};
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool consumed_valid[2] = {false, false};
+  int flip = 0;
   uint8_t* d_planes = nullptr;
   uint8_t* d_rgb = nullptr;
 
@@ -173,18 +187,20 @@ struct ProfScope {
   ufd_model* m;
   ProfEntry pe;
   bool on;
-  ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops) : m(mm), on(mm->profile) {
+  hipStream_t st;
+  ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
+      : m(mm), on(mm->profile), st(stream ? stream : mm->stream) {
     if (!on) return;
     pe.name_id = prof_name_id(m, name);
     pe.bytes = bytes;
     pe.flops = flops;
     pe.e0 = prof_event(m);
     pe.e1 = prof_event(m);
-    (void)hipEventRecord(pe.e0, m->stream);
+    (void)hipEventRecord(pe.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(pe.e1, m->stream);
+    (void)hipEventRecord(pe.e1, st);
     m->prof_pending.push_back(pe);
   }
 };
@@ -250,7 +266,12 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     }
     L.oh = conv_out_dim(L.ih, L.spec);
     L.ow = conv_out_dim(L.iw, L.spec);
-    L.pointwise = (L.spec.k == 1 && L.spec.groups == 1);
+    if (L.spec.k == 1 && L.spec.groups == 1)
+      L.kind = kKindPointwise;
+    else if (L.spec.k == 3 && L.spec.groups == 1 && L.spec.cout <= 16 && L.spec.pad == L.spec.dil)
+      L.kind = kKindConv3x3;
+    else
+      L.kind = kKindDirect;
     L.res_tensor = (i == kRfbShortcut) ? tensor_of[kRfbLinear] : -1;
     L.out_coff = 0;
     if (i == kRfbCatA || i == kRfbCatB || i == kRfbCatC) {
@@ -274,14 +295,36 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     L.bytes_per_frame = in_b + out_b + (L.res_tensor >= 0 ? out_b : 0);
     L.flops_per_frame = 2.0 * L.oh * L.ow * L.spec.cout * (L.spec.cin / L.spec.groups) * L.spec.k * L.spec.k;
   }
+  // fuse every depthwise 3x3 into the pointwise conv that consumes it (its only consumer)
+  for (int i = 0; i + 1 < kNumConv; i++) {
+    Layer& D = m->layers[i];
+    Layer& P = m->layers[i + 1];
+    if (D.spec.groups == 1 || D.spec.groups != D.spec.cin || D.spec.k != 3 || D.spec.pad != 1 || D.spec.dil != 1 ||
+        !D.spec.relu)
+      continue;
+    if (P.kind != kKindPointwise || P.spec.src != i || P.res_tensor >= 0) continue;
+    ConvArgs probe{};
+    probe.ih = D.ih, probe.iw = D.iw, probe.oh = P.oh, probe.ow = P.ow, probe.cin = D.spec.cin;
+    if (!dwpw_supported(probe, D.spec.stride)) continue;
+    P.kind = kKindDwPw;
+    P.fused_dw = i;
+    D.kind = kKindFusedAway;
+    D.materialize = keep_all;
+    P.bytes_per_frame = (double)D.spec.cin * D.ih * D.iw * 4 + (double)P.spec.cout * P.oh * P.ow * 4;
+    P.flops_per_frame += D.flops_per_frame;
+    P.weight_bytes += D.weight_bytes;
+  }
   // liveness: first writer, last reader (head outputs live until the decode kernel)
   const int nt = (int)m->tensors.size();
   std::vector<int> first(nt, kNumConv), last(nt, -1);
   for (int i = 0; i < kNumConv; i++) {
     const Layer& L = m->layers[i];
+    if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
     first[L.out_tensor] = std::min(first[L.out_tensor], i);
     last[L.out_tensor] = std::max(last[L.out_tensor], i);
-    if (L.in_tensor >= 0) last[L.in_tensor] = std::max(last[L.in_tensor], i);
+    const int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
+    if (src_t >= 0) last[src_t] = std::max(last[src_t], i);
+    if (L.in_tensor >= 0 && L.kind != kKindDwPw) last[L.in_tensor] = std::max(last[L.in_tensor], i);
     if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], i);
   }
   for (int h = 0; h < 4; h++) {
@@ -314,7 +357,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   };
   for (int i = 0; i < kNumConv; i++) {
     const int t = m->layers[i].out_tensor;
-    if (first[t] == i) allocate(t);
+    if (first[t] == i) allocate(t);  // (a fused-away depthwise output has first == kNumConv: no storage)
     // a buffer is recycled only after the layer that reads it last has been issued, so a
     // layer's output never aliases its own inputs
     if (!keep_all)
@@ -334,10 +377,15 @@ int upload_weights(ufd_model* m, const float* blob) {
     const size_t nw = conv_weight_floats(s);
     while (img.size() % 64) img.push_back(0.f);
     w_off[i] = img.size();
-    if (m->layers[i].pointwise) {
+    const LayerKind kind = m->layers[i].kind;
+    if (kind == kKindPointwise || kind == kKindDwPw) {
       const size_t np = pointwise_packed_floats(s.cin, s.cout);
       img.resize(img.size() + np);
       pack_pointwise_weights(p, s.cin, s.cout, img.data() + w_off[i]);
+    } else if (kind == kKindConv3x3) {
+      const size_t np = conv3x3_packed_floats(s.cin);
+      img.resize(img.size() + np);
+      pack_conv3x3_weights(p, s.cin, s.cout, img.data() + w_off[i]);
     } else {
       img.insert(img.end(), p, p + nw);
     }
@@ -429,11 +477,12 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 // ---------------------------------------------------------------- GPU stages
 float* tensor_ptr(ufd_model* m, int t) { return m->d_arena + m->tensors[t].off; }
 
-// [count][3][H][W] in d_input -> scores/boxes/candidate keys
+// [count][3][H][W] in d_input -> every conv output the heads need
 void enqueue_forward(ufd_model* m, uint32_t count) {
   for (int i = 0; i < kNumConv; i++) {
     const Layer& L = m->layers[i];
-    ConvArgs a;
+    if (L.kind == kKindFusedAway && !L.materialize) continue;
+    ConvArgs a{};
     a.in = L.in_tensor < 0 ? m->d_input : tensor_ptr(m, L.in_tensor);
     a.w = L.d_w;
     a.bias = L.d_b;
@@ -448,13 +497,32 @@ void enqueue_forward(ufd_model* m, uint32_t count) {
     a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
     a.out_ctotal = m->tensors[L.out_tensor].c;
     a.out_coff = L.out_coff;
-    const char* kind = L.pointwise ? "conv_pointwise_mfma" : (a.depthwise ? "conv_direct_dw" : "conv_direct_full");
+    int dw_stride = 1;
+    const char* kind = "conv_direct_full";
+    switch (L.kind) {
+      case kKindPointwise: kind = "conv_pw_mfma"; break;
+      case kKindDwPw: {
+        const Layer& D = m->layers[L.fused_dw];
+        kind = "conv_dwpw_mfma";
+        a.in = D.in_tensor < 0 ? m->d_input : tensor_ptr(m, D.in_tensor);
+        a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
+        a.ih = D.ih, a.iw = D.iw;
+        a.w2 = D.d_w, a.bias2 = D.d_b;
+        dw_stride = D.spec.stride;
+        break;
+      }
+      case kKindConv3x3: kind = "conv3x3_mfma"; break;
+      case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
+      case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
+    }
     ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
                  L.flops_per_frame * count);
-    if (L.pointwise)
-      launch_conv_pointwise_mfma(a, m->stream);
-    else
-      launch_conv_direct(a, m->stream);
+    switch (L.kind) {
+      case kKindPointwise: launch_conv_pointwise_mfma(a, m->stream); break;
+      case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->stream); break;
+      case kKindConv3x3: launch_conv3x3_mfma(a, m->stream); break;
+      default: launch_conv_direct(a, m->stream); break;
+    }
   }
   m->last_forward_count = count;
 }
@@ -560,28 +628,40 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     if (d.width != m->W || d.height != m->H) all_model_size = false;
   }
   if (any_ok) {
-    HIPC(m, hipMemcpyAsync(m->d_descs, s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, m->stream));
+    const int buf = m->flip;
+    m->flip ^= 1;
+    JpegFrameDesc* d_descs = m->d_descs_buf[buf];
+    int16_t* d_coef = m->d_coef_buf[buf];
+    // copy stream: wait until the kernels of two batches ago have consumed this buffer
+    if (m->consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(m->copy_stream, m->ev_consumed[buf], 0));
+    HIPC(m, hipMemcpyAsync(d_descs, s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, m->copy_stream));
     {
-      ProfScope ps(m, "h2d_coef", 0, 0);
+      ProfScope ps(m, "h2d_coef", 0, 0, m->copy_stream);
       // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
       size_t used = 0;
       for (uint32_t i = 0; i < count; i++) used = std::max(used, (size_t)s.h_descs[i].coef_total);
-      HIPC(m, hipMemcpy2DAsync(m->d_coef, m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
-                               hipMemcpyHostToDevice, m->stream));
+      HIPC(m, hipMemcpy2DAsync(d_coef, m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
+                               hipMemcpyHostToDevice, m->copy_stream));
     }
+    HIPC(m, hipEventRecord(m->ev_copied[buf], m->copy_stream));
+    HIPC(m, hipStreamWaitEvent(m->stream, m->ev_copied[buf], 0));
     {
       ProfScope ps(m, "idct", 0, 0);
-      launch_idct(m->d_descs, m->d_coef, m->coef_stride, m->d_planes, m->plane_stride, max_blocks, count, m->stream);
+      launch_idct(d_descs, d_coef, m->coef_stride, m->d_planes, m->plane_stride, max_blocks, count, m->stream);
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
       ProfScope ps(m, "upsample_norm", 0, 0);
-      launch_upsample_norm(m->d_descs, m->d_planes, m->plane_stride, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
+      launch_upsample_norm(d_descs, m->d_planes, m->plane_stride, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
+      HIPC(m, hipEventRecord(m->ev_consumed[buf], m->stream));
+      m->consumed_valid[buf] = true;
     } else {
       {
         ProfScope ps(m, "upsample_rgb", 0, 0);
-        launch_upsample_rgb(m->d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, mw, mh, count, m->stream);
+        launch_upsample_rgb(d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, mw, mh, count, m->stream);
       }
+      HIPC(m, hipEventRecord(m->ev_consumed[buf], m->stream));
+      m->consumed_valid[buf] = true;
       for (uint32_t i = 0; i < count; i++) {
         if (s.st[i] != UFD_OK) continue;
         const JpegFrameDesc& d = s.h_descs[i];
@@ -649,12 +729,18 @@ std::string default_weights_path(int variant) {
 
 void destroy(ufd_model* m) {
   if (!m) return;
+  if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   auto dfree = [](void* p) {
     if (p) (void)hipFree(p);
   };
   dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_arena), dfree(m->d_input);
-  dfree(m->d_descs), dfree(m->d_coef), dfree(m->d_planes), dfree(m->d_rgb);
+  for (int i = 0; i < 2; i++) {
+    dfree(m->d_descs_buf[i]), dfree(m->d_coef_buf[i]);
+    if (m->ev_copied[i]) (void)hipEventDestroy(m->ev_copied[i]);
+    if (m->ev_consumed[i]) (void)hipEventDestroy(m->ev_consumed[i]);
+  }
+  dfree(m->d_planes), dfree(m->d_rgb);
   dfree(m->d_scores), dfree(m->d_boxes), dfree(m->d_keys), dfree(m->d_counts), dfree(m->d_dets), dfree(m->d_ndet);
   dfree(m->d_spill);
   for (auto& kv : m->taps)
@@ -668,6 +754,7 @@ void destroy(ufd_model* m) {
   }
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
+  if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -709,7 +796,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->max_w = std::max<uint32_t>(m->max_w, m->W);
   m->max_h = std::max<uint32_t>(m->max_h, m->H);
   m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
-  unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   m->pool.reset(new ThreadPool(threads));
 #define HIPB(expr)                                                                      \
   do {                                                                                  \
@@ -729,6 +816,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
     }
   }
   HIPB(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  HIPB(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
 
   // ---- weights + priors
   std::vector<float> blob, priors;
@@ -760,7 +848,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0);
   // shapes the kernels rely on (checked here once, not per launch)
   for (const Layer& L : m->layers) {
-    if (L.pointwise && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
+    if ((L.kind == kKindPointwise || L.kind == kKindDwPw) && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
       m->err = std::string("layer ") + L.spec.name + ": pointwise kernel needs H*W % 4 == 0 and even Cin";
       return bail(UFD_E_WEIGHTS);
     }
@@ -793,8 +881,12 @@ int create(const ufd_config* cfg, ufd_model** out) {
     m->plane_stride = pw * ph * 3;
     m->rgb_stride = ((size_t)m->max_w * m->max_h * 3 + 15) & ~(size_t)15;
   }
-  HIPB(hipMalloc(&m->d_descs, sizeof(JpegFrameDesc) * B));
-  HIPB(hipMalloc(&m->d_coef, sizeof(int16_t) * m->coef_stride * B));
+  for (int i = 0; i < 2; i++) {
+    HIPB(hipMalloc(&m->d_descs_buf[i], sizeof(JpegFrameDesc) * B));
+    HIPB(hipMalloc(&m->d_coef_buf[i], sizeof(int16_t) * m->coef_stride * B));
+    HIPB(hipEventCreateWithFlags(&m->ev_copied[i], hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&m->ev_consumed[i], hipEventDisableTiming));
+  }
   HIPB(hipMalloc(&m->d_planes, m->plane_stride * B));
   HIPB(hipMalloc(&m->d_rgb, m->rgb_stride * B));
   m->key_stride = 1;
@@ -975,10 +1067,12 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
     if (h) *h = d->height;
     const size_t bytes = (size_t)d->width * d->height * 3;
     if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
-    HIPC(m, hipMemcpyAsync(m->d_descs, d, sizeof(*d), hipMemcpyHostToDevice, m->stream));
-    HIPC(m, hipMemcpyAsync(m->d_coef, s->h_coef, (size_t)d->coef_total * 2, hipMemcpyHostToDevice, m->stream));
-    launch_idct(m->d_descs, m->d_coef, m->coef_stride, m->d_planes, m->plane_stride, d->total_blocks, 1, m->stream);
-    launch_upsample_rgb(m->d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, d->width, d->height, 1,
+    HIPC(m, hipStreamSynchronize(m->copy_stream));  // tap runs on the main stream with buffer 0
+    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipMemcpyAsync(m->d_descs_buf[0], d, sizeof(*d), hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemcpyAsync(m->d_coef_buf[0], s->h_coef, (size_t)d->coef_total * 2, hipMemcpyHostToDevice, m->stream));
+    launch_idct(m->d_descs_buf[0], m->d_coef_buf[0], m->coef_stride, m->d_planes, m->plane_stride, d->total_blocks, 1, m->stream);
+    launch_upsample_rgb(m->d_descs_buf[0], m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, d->width, d->height, 1,
                         m->stream);
     HIPC(m, hipMemcpyAsync(rgb, m->d_rgb, bytes, hipMemcpyDeviceToHost, m->stream));
     HIPC(m, hipStreamSynchronize(m->stream));

@@ -107,77 +107,108 @@ __device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthr
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
+// iou(candidate, selected) > max_iou, nn.rs:227-243 operation order
+__device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const float4 sb, float max_iou) {
+  const float ox0 = fmaxf(c.x, sb.x), oy0 = fmaxf(c.y, sb.y), ox1 = fminf(c.z, sb.z), oy1 = fminf(c.w, sb.w);
+  const float overlap = bbox_area(ox0, oy0, ox1, oy1);
+  const float denom = __fadd_rn(__fsub_rn(__fadd_rn(area_c, bbox_area(sb.x, sb.y, sb.z, sb.w)), overlap), kEps);
+  return __fdiv_rn(overlap, denom) > max_iou;
+}
+
+// One 1024-thread workgroup per frame (16 waves; frames with thousands of candidates set the
+// batch latency, so the quadratic phases are spread as wide as a workgroup goes): bitonic sort of the candidate keys, then greedy NMS in
+// blocks of 64 candidates (sorted order).  Per block:
+//   phase 1  every wave tests the block's 64 candidates (one per lane) against a stripe of the
+//            boxes selected so far -> 64-bit "dead" mask (ballot + LDS atomicOr)
+//   phase 2  64x64 pairwise matrix inside the block (row i = candidates j > i it would suppress)
+//   phase 3  wave 0 resolves the block serially with bit operations: i survives iff not dead;
+//            a survivor kills row i.  Exactly the reference's greedy order (nn.rs:198-224).
+__global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
                                                   const uint32_t* __restrict__ counts, const float* __restrict__ boxes,
                                                   int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
                                                   uint32_t* __restrict__ ndet, float4* __restrict__ spill) {
   __shared__ unsigned long long s_keys[kSortLds];
   __shared__ float4 s_sel[kSelLds];
+  __shared__ float4 s_cand[64];
+  __shared__ unsigned long long s_row[64];
+  __shared__ unsigned long long s_dead;
+  __shared__ int s_nsel;
   const int frame = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwave = nthr >> 6;
   const int n = min((int)counts[frame], K);
   unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
   unsigned long long* keys;
   if (n2 <= kSortLds) {
-    for (int i = tid; i < n2; i += 256) s_keys[i] = i < n ? fkeys[i] : 0ull;
+    for (int i = tid; i < n2; i += nthr) s_keys[i] = i < n ? fkeys[i] : 0ull;
     keys = s_keys;
   } else {
-    for (int i = n + tid; i < n2; i += 256) fkeys[i] = 0ull;  // key_stride >= next pow2 of K
-    __threadfence_block();
+    for (int i = n + tid; i < n2; i += nthr) fkeys[i] = 0ull;  // key_stride >= next pow2 of K
     keys = fkeys;
   }
+  if (tid == 0) s_nsel = 0;
   __syncthreads();
-  if (n > 1) bitonic_desc(keys, n2, tid, 256);
-  if (n2 > kSortLds) __threadfence_block();
-  __syncthreads();
-  if (tid >= 64) return;  // greedy scan: one wave
-  const int lane = tid;
+  if (n > 1) bitonic_desc(keys, n2, tid, nthr);
   const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
   float4* fspill = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
-  int nsel = 0;
-  for (int i = 0; i < n; i++) {
-    const unsigned long long key = keys[i];
-    const int k = (int)(key & 0xffffffffull) - 1;
-    const float4 c = fb[k];
-    const float area_c = bbox_area(c.x, c.y, c.z, c.w);
-    bool suppressed = false;
-    for (int j0 = 0; j0 < nsel; j0 += 64) {
-      const int j = j0 + lane;
-      bool hit = false;
-      if (j < nsel) {
-        const float4 sb = j < kSelLds ? s_sel[j] : fspill[j];
-        // iou(bbox, selected_bbox), nn.rs:227-243
-        const float ox0 = fmaxf(c.x, sb.x), oy0 = fmaxf(c.y, sb.y), ox1 = fminf(c.z, sb.z), oy1 = fminf(c.w, sb.w);
-        const float overlap = bbox_area(ox0, oy0, ox1, oy1);
-        const float denom = __fadd_rn(__fsub_rn(__fadd_rn(area_c, bbox_area(sb.x, sb.y, sb.z, sb.w)), overlap), kEps);
-        const float iou = __fdiv_rn(overlap, denom);
-        hit = iou > max_iou;
-      }
-      if (__any(hit)) {
-        suppressed = true;
-        break;
-      }
+
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    const int m = min(64, n - b0);
+    if (tid < 64) {
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid < m) c = fb[(int)(keys[b0 + tid] & 0xffffffffull) - 1];
+      s_cand[tid] = c;
+      s_row[tid] = 0ull;
     }
-    if (!suppressed) {
-      if (lane == 0) {
-        if (nsel < kSelLds)
-          s_sel[nsel] = c;
-        else
-          fspill[nsel] = c;
-        if ((uint32_t)nsel < det_stride) {
-          Det d;
-          d.x_tl = c.x, d.y_tl = c.y, d.x_br = c.z, d.y_br = c.w, d.conf = key_conf(key);
-          fd[nsel] = d;
+    if (tid == 0) s_dead = 0ull;
+    __syncthreads();
+    const int nsel = s_nsel;
+    const float4 c = s_cand[lane];
+    const float area_c = bbox_area(c.x, c.y, c.z, c.w);
+    // phase 1: against previously selected boxes, wave w takes s = w, w+nwave, ...
+    unsigned long long dead = 0ull;
+    for (int sidx = wave; sidx < nsel; sidx += nwave) {
+      const float4 sb = sidx < kSelLds ? s_sel[sidx] : fspill[sidx];
+      dead |= __ballot(lane < m && iou_exceeds(c, area_c, sb, max_iou));
+    }
+    if (lane == 0 && dead) atomicOr(&s_dead, dead);
+    // phase 2: inside the block, wave w takes rows i = w, w+nwave, ...; lane = column j
+    for (int i = wave; i < m; i += nwave) {
+      const float4 sb = s_cand[i];  // the earlier (higher-confidence) box plays "selected"
+      const unsigned long long row = __ballot(lane > i && lane < m && iou_exceeds(c, area_c, sb, max_iou));
+      if (lane == 0) s_row[i] = row;
+    }
+    __syncthreads();
+    // phase 3
+    if (wave == 0) {
+      unsigned long long d = s_dead, keep = 0ull;
+      for (int i = 0; i < m; i++) {
+        if (!((d >> i) & 1ull)) {
+          keep |= 1ull << i;
+          d |= s_row[i];
         }
       }
-      nsel++;
-      if (nsel > kSelLds) __threadfence_block();
+      if ((keep >> lane) & 1ull) {
+        const int pos = nsel + __popcll(keep & ((1ull << lane) - 1ull));
+        if (pos < kSelLds)
+          s_sel[pos] = c;
+        else
+          fspill[pos] = c;
+        if ((uint32_t)pos < det_stride) {
+          Det dd;
+          dd.x_tl = c.x, dd.y_tl = c.y, dd.x_br = c.z, dd.y_br = c.w, dd.conf = key_conf(keys[b0 + lane]);
+          fd[pos] = dd;
+        }
+      }
+      if (lane == 0) s_nsel = nsel + __popcll(keep);
+      __threadfence_block();  // spilled boxes are read back by the other waves
     }
+    __syncthreads();
   }
-  if (lane == 0) ndet[frame] = (uint32_t)nsel;
+  if (tid == 0) ndet[frame] = (uint32_t)s_nsel;
 }
 
 }  // namespace
@@ -199,7 +230,7 @@ void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_c
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
                      uint32_t B, hipStream_t s) {
-  hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
+  hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
                      d_dets, det_stride, d_ndet, d_sel_spill);
 }
 
