@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4, help="record kernel events for every n-th timed step")
     return ap.parse_args()
 
 
@@ -125,6 +126,7 @@ def main():
 
     run_steps(args.warmup)
     model.profile_reset()
+    model.profile_sampling(args.profile_every)
     barrier()
     t0 = time.perf_counter()
     ndet = run_steps(args.steps)
@@ -135,6 +137,7 @@ def main():
 
     if rank == 0:
         frames = world * B * args.steps
+        prof_steps = (args.steps + args.profile_every - 1) // args.profile_every  # steps that carried events
         # ---- roofline of the dominant kernel (device time from HIP events on the library's stream)
         agg = {}
         for st in stats:
@@ -155,7 +158,15 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        roof.update({"traffic": None, "kernel": KERNEL_FUNCS.get(dom, dom),
+        traffic = None
+        try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))["kernels"]
+            traffic = round(pmc[KERNEL_FUNCS.get(dom, dom)]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+        per_launch = d["bytes"] / max(d["launches"], 1)
+        roof.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(per_launch),
+                     "kernel": KERNEL_FUNCS.get(dom, dom),
                      "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
         gpu_ms = sum(v["ms"] for v in kern.values())
         out = {
@@ -169,14 +180,14 @@ def main():
                        "timed_region": "host JPEG bytes -> host detections (host Huffman + PCIe included)",
                        "async_depth": args.depth},
             "roofline": roof,
-            "gpu_ms_per_step": round(gpu_ms / args.steps, 3),
-            "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+            "gpu_ms_per_step": round(gpu_ms / prof_steps, 3),
+            "kernels_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
             "detections_per_frame": round(ndet / (B * args.steps), 2),
         }
         dump = os.environ.get("UFD_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:
-                json.dump({"steps": args.steps, "batch": B, "stats": stats}, f, indent=1)
+                json.dump({"steps": prof_steps, "batch": B, "stats": stats}, f, indent=1)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds)
         print(json.dumps(out), flush=True)

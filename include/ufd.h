@@ -149,6 +149,9 @@ typedef struct ufd_kernel_stat {
   double flops; /* algorithmic FLOPs of those launches */
 } ufd_kernel_stat;
 int ufd_profile_reset(ufd_model* m);
+/* Record events only for every `every_n`-th batch (default 1 = all): keeps the event overhead
+ * (~100 timestamp packets per batch) out of a timed run while still sampling it. */
+int ufd_profile_sampling(ufd_model* m, uint32_t every_n);
 int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n);
 
 #ifdef __cplusplus

@@ -140,6 +140,8 @@ struct ufd_model {
 
   // profiling
   bool profile = false;
+  uint32_t prof_every = 1, prof_batch = 0;
+  bool prof_active = true;
   std::vector<std::string> prof_names;
   std::vector<ufd_kernel_stat> prof_stats;
   std::vector<ProfEntry> prof_pending;
@@ -189,7 +191,7 @@ struct ProfScope {
   bool on;
   hipStream_t st;
   ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
-      : m(mm), on(mm->profile), st(stream ? stream : mm->stream) {
+      : m(mm), on(mm->profile && mm->prof_active), st(stream ? stream : mm->stream) {
     if (!on) return;
     pe.name_id = prof_name_id(m, name);
     pe.bytes = bytes;
@@ -563,7 +565,9 @@ int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
 // waits for the slot's batch and hands results to the caller's arrays
 int finish_slot(ufd_model* m, Slot& s) {
   HIPC(m, hipEventSynchronize(s.done));
-  prof_flush(m);
+  // timing events are resolved lazily (ufd_profile_read): querying ~100 events per batch here
+  // would stall the submit/wait pipeline
+  if (m->prof_pending.size() > 16384) prof_flush(m);
   int rc = UFD_OK;
   for (uint32_t i = 0; i < s.count; i++) {
     int32_t st = s.st[i];
@@ -604,6 +608,7 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
   int rc = alloc_slot(m, s);
   if (rc) return rc;
   s.count = count;
+  m->prof_active = (m->prof_batch++ % m->prof_every) == 0;
   m->pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_decode_coefficients(jpegs[i], lens[i], d, s.h_coef + (size_t)i * m->coef_stride,
@@ -1203,6 +1208,16 @@ int ufd_profile_reset(ufd_model* m) {
     HIPC(m, hipStreamSynchronize(m->stream));
     prof_flush(m);
     for (auto& st : m->prof_stats) st.launches = 0, st.total_ms = 0, st.bytes = 0, st.flops = 0;
+    return UFD_OK;
+  });
+}
+
+int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
+  return guarded(m, [&]() -> int {
+    if (!every_n) return m->fail(UFD_E_ARG, "every_n must be >= 1");
+    m->prof_every = every_n;
+    m->prof_batch = 0;
+    m->prof_active = true;
     return UFD_OK;
   });
 }

@@ -48,7 +48,7 @@ ABI_SYMBOLS = (
     "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
     "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
-    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_read",
+    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
 )
 
 _lib = None
@@ -91,6 +91,7 @@ def load_library():
     L.ufd_debug_jpeg_coefficients.argtypes = [vp, sz, vp, sz, pu32, pu32, pu32]
     L.ufd_debug_load_onnx.argtypes = [ctypes.c_char_p, u32, vp, sz, vp, sz, pu32, ctypes.c_char_p, sz]
     L.ufd_profile_reset.argtypes = [vp]
+    L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
     _lib = L
     return L
@@ -341,6 +342,10 @@ class UltrafaceModel(InferModel):
     # -- measurement
     def profile_reset(self):
         self._check(self._lib.ufd_profile_reset(self._h))
+
+    def profile_sampling(self, every_n):
+        """Record kernel events only for every `every_n`-th batch."""
+        self._check(self._lib.ufd_profile_sampling(self._h, int(every_n)))
 
     def profile_read(self):
         """-> [dict(name, launches, total_ms, bytes, flops)] per kernel since the last reset."""
