@@ -1,0 +1,69 @@
+"""The host-side mirrors of the reference interface on the GPU: the C++ `nn.hpp` wrapper (a port of
+infer_server/tests/integration_tests.rs) and the Python `Inferer` loop (inferer.rs:29-50)."""
+import os
+import queue
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import assert_dets_match, dets_array
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_integration_test(tmp_path, weights):
+    exe = str(tmp_path / "integration_test")
+    lib_dir = os.path.join(ROOT, "infercam_onnx_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "integration_test.cpp"),
+                           "-o", exe, "-L" + lib_dir, "-lufacehip", "-Wl,-rpath," + lib_dir])
+    wfile = str(tmp_path / "w.f32")
+    np.asarray(weights, np.float32).tofile(wfile)
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test_pics"), wfile], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("ok") and out.stdout.count("faces=") == 8
+
+
+def test_reference_face_counts_if_real_model_present(oracle_lib):
+    """integration_tests.rs:20-35 proper: only runs when the real ONNX file is in the cache path."""
+    import json
+    from infercam_onnx_amd import nn
+
+    path = os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.expanduser("~/.cache")), "infercam_onnx",
+                        "ultraface-RFB-640.onnx")
+    if not os.path.exists(path):
+        pytest.skip("real UltraFace weights not available offline (reference downloads them, nn.rs:155-162)")
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "test_pics.json")))
+    with nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights_path=path, max_src=(1280, 1024)) as m:
+        for f, info in meta.items():
+            jpeg = open(os.path.join(ROOT, "tests", "golden", "test_pics", f), "rb").read()
+            assert len(m.infer_jpeg(jpeg)) == info["reference_face_count"], f
+
+
+def test_inferer_loop(oracle_lib, weights):
+    from infercam_onnx_amd import nn, synth
+    from infercam_onnx_amd.inferer import Inferer
+
+    W, H = 320, 240
+    pri = synth.gen_priors(W, H)
+    model = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights, priors=pri, max_batch=4,
+                              max_src=(1280, 720), det_cap=4420)
+    rx = queue.Queue()
+    got = {}
+    jpegs = [synth.encode_jpeg(synth.synth_frame(61, i, 1280, 720)) for i in range(6)]  # router stamps 1280x720
+    for i, j in enumerate(jpegs):
+        rx.put((1280, 720, j if i != 3 else j[:777], lambda r, i=i: got.__setitem__(i, r)))
+    rx.put(None)
+    Inferer(rx, model=model, max_batch=4).run()
+    assert sorted(got) == list(range(6))
+    assert got[3] == (None, nn.UFD_E_DECODE)  # corrupt frame skipped, loop keeps going
+    for i in (0, 1, 2, 4, 5):
+        dets, st = got[i]
+        assert st == 0
+        ref = oracle_lib.infer_jpeg(jpegs[i], W, H, weights, pri, 0.5, 0.5)
+        x = oracle_lib.normalize_nchw(oracle_lib.resize_triangle(oracle_lib.jpeg_decode_rgb(jpegs[i]), W, H))
+        scores, _ = oracle_lib.forward(x, weights, pri)
+        assert_dets_match(dets_array(dets), ref, scores=scores)
+    model.close()
