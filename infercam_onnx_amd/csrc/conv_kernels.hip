@@ -57,6 +57,18 @@ __device__ __forceinline__ void store_tiles(const ConvArgs& a, floatx16 (&acc)[C
   }
 }
 
+// XCD-aware block order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+// (each with a private L2).  Blocks that read the same activation tile but produce different
+// 32-cout tiles get ids 8 apart inside a group of 8*cts ids, so they run on the same XCD close in
+// time and the second..cts-th read of the tile hits that XCD's L2.  Placement only changes speed.
+__device__ __forceinline__ bool remap_block(const ConvArgs& a, int* tile, int* ct) {
+  const int per = 8 * a.cts;
+  const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+  *ct = r >> 3;
+  *tile = grp * 8 + (r & 7);
+  return *tile < a.tiles;
+}
+
 template <int CT>
 __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half) {
 #pragma unroll
@@ -76,31 +88,55 @@ __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][
 //   B operand (k x 32 pixel columns): lane l loads float4 in[ci = 2*ks + (l>>5)][4 pixels of group g]
 //   A operand (32 couts x k): pre-packed so that lane l reads W[ct*32 + (l&31)][2*ks + (l>>5)]
 // Pixel groups (4 consecutive pixels of one plane) are numbered over the whole batch.
-template <int CT>
+// The k-loop keeps D k-steps of activations and weights in flight in a register ring (loads are
+// unconditional: dead lanes read a valid dummy address), so a wave does not pay one memory round
+// trip per k-step.  Needs ksteps % D == 0.
+template <int CT, int D>
 __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tile, ctile;
+  if (!remap_block(a, &tile, &ctile)) return;
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
-  const long g = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const long g = ((long)tile * 4 + wave) * 32 + (lane & 31);
   const bool live = g < (long)a.B * gpf;
   const size_t frame = live ? g / gpf : 0;
   const int pix = live ? (int)(g - (long)frame * gpf) * 4 : 0;
-  const int ct0 = blockIdx.y * CT, half = lane >> 5, ksteps = a.cin >> 1;
+  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
-  const float* in = a.in + (frame * a.in_ctotal + half) * hw + pix;
+  // wave-uniform base pointer + 32-bit per-lane element offsets (tensors are < 2^32 bytes, checked
+  // by the launcher): lets the compiler use scalar-base addressing instead of 64-bit VALU adds
+  const float* __restrict__ in = a.in;
+  const uint32_t in_off = (uint32_t)((frame * a.in_ctotal + half) * hw + pix);
   const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
-  const size_t in_step = (size_t)2 * hw;
-#pragma unroll 4
-  for (int ks = 0; ks < ksteps; ks++) {
-    float4 b = live ? *reinterpret_cast<const float4*>(in + ks * in_step) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t in_step = 2u * (uint32_t)hw;
+  float4 bq[D];
+  float wq[D][CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-      const float w = wp[((size_t)ct * ksteps + ks) * 64];
-      acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.x, acc[ct][0], 0, 0, 0);
-      acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.y, acc[ct][1], 0, 0, 0);
-      acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.z, acc[ct][2], 0, 0, 0);
-      acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.w, acc[ct][3], 0, 0, 0);
+  for (int d = 0; d < D; d++) {
+    bq[d] = *reinterpret_cast<const float4*>(in + (in_off + d * in_step));
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + d) * 64];
+  }
+  for (int ks = 0; ks < ksteps; ks += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const float4 b = bq[d];
+      float w[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
+      const int kn = min(ks + D + d, ksteps - 1);  // refill the slot (tail: harmless re-read)
+      bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)kn * in_step));
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) {
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.x, acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.y, acc[ct][1], 0, 0, 0);
+        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.z, acc[ct][2], 0, 0, 0);
+        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.w, acc[ct][3], 0, 0, 0);
+      }
     }
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, pix, hw);
@@ -113,86 +149,125 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
 // 3 x (4*S+2) input window (aligned float4 row segments + edge scalars) and feeds it directly as
 // the B operand.  Needs ow % 4 == 0 and iw % 4 == 0.  a.w2/a.bias2 = depthwise weights [cin][9]
 // and bias [cin]; a.w/a.bias = packed pointwise weights and bias.
-template <int CT, int S>
+template <int S>
+struct DwWindow {  // raw 3 x (4*S+2) input window of one channel for 4 output pixels
+  float4 m0[3];
+  float4 m1[3];  // stride 2 only
+  float l[3];
+  float r[3];    // stride 1 only
+};
+
+template <int CT, int S, int D>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
   extern __shared__ float s_dw[];  // [cin][12]: 9 taps, bias, pad
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tile, ctile;
+  if (!remap_block(a, &tile, &ctile)) return;  // whole block, before the barrier
   for (int i = threadIdx.x; i < a.cin * 12; i += 256) {
     const int c = i / 12, t = i - c * 12;
     s_dw[i] = t < 9 ? a.w2[c * 9 + t] : (t == 9 ? a.bias2[c] : 0.0f);
   }
   __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long g = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const long g = ((long)tile * 4 + wave) * 32 + (lane & 31);
   const bool live = g < (long)a.B * gpf;
   const size_t frame = live ? g / gpf : 0;
   const int rem = live ? (int)(g - (long)frame * gpf) : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
-  const int ct0 = blockIdx.y * CT, half = lane >> 5, ksteps = a.cin >> 1;
+  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
   const int ihw = a.ih * a.iw;
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
 
   // input window: rows iy0..iy0+2, columns ix0-1 .. ix0+4*S (ix0 = ox*S is a multiple of 4).
-  // Loads are unconditional from clamped (always valid) addresses and zeroed by select
-  // afterwards, so the k-loop is branch-free and the loads of the next step can be hoisted.
+  // Loads are unconditional from clamped (always valid) addresses and zeroed by select, and D
+  // k-steps of windows are kept in flight in a register ring.
   const int iy0 = oy * S - 1, ix0 = ox * S;
   bool rowok[3];
-  int rowoff[3];
+  uint32_t rowoff[3];  // 32-bit element offsets from the wave-uniform base a.in (< 2^32 bytes, launcher-checked)
+  const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
-    rowoff[r] = min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0;
+    rowoff[r] = lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0);
   }
   const bool leftok = ix0 > 0;
   const bool rightok = (S == 1) && (ix0 + 4 < a.iw);  // stride 2 never needs column ix0+8
-  const int loff = leftok ? -1 : 0, roff = rightok ? 4 : 0;
-  const float* in = a.in + (frame * a.in_ctotal + half) * ihw;
+  const uint32_t loff = leftok ? 0xffffffffu : 0u, roff = rightok ? 4u : 0u;  // -1 / +4 elements
+  const float* __restrict__ in = a.in;
   const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
+  const uint32_t chan_step = 2u * (uint32_t)ihw;
 
-#pragma unroll 2
-  for (int ks = 0; ks < ksteps; ks++) {
-    const float* p = in + (size_t)(2 * ks) * ihw;
-    const float* wd = s_dw + (2 * ks + half) * 12;
-    float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
+  auto load_window = [&](int ks, DwWindow<S>& win) {
+    const uint32_t c = (uint32_t)ks * chan_step;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const float* row = p + rowoff[r];
-      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
-      if (S == 1) {
-        float4 m = *reinterpret_cast<const float4*>(row);
-        float l = row[loff], rr = row[roff];
-        m.x = rowok[r] ? m.x : 0.f, m.y = rowok[r] ? m.y : 0.f, m.z = rowok[r] ? m.z : 0.f, m.w = rowok[r] ? m.w : 0.f;
-        l = (rowok[r] && leftok) ? l : 0.f;
-        rr = (rowok[r] && rightok) ? rr : 0.f;
-        // per pixel, taps in kx order: x-1, x, x+1
-        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
-        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
-        t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
-        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
-      } else {
-        float4 m0 = *reinterpret_cast<const float4*>(row);
-        float4 m1 = *reinterpret_cast<const float4*>(row + 4);
-        float l = row[loff];
-        m0.x = rowok[r] ? m0.x : 0.f, m0.y = rowok[r] ? m0.y : 0.f, m0.z = rowok[r] ? m0.z : 0.f, m0.w = rowok[r] ? m0.w : 0.f;
-        m1.x = rowok[r] ? m1.x : 0.f, m1.y = rowok[r] ? m1.y : 0.f, m1.z = rowok[r] ? m1.z : 0.f, m1.w = rowok[r] ? m1.w : 0.f;
-        l = (rowok[r] && leftok) ? l : 0.f;
-        // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
-        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
-        t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
-        t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
-        t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
-      }
+      const uint32_t o = rowoff[r] + c;
+      win.m0[r] = *reinterpret_cast<const float4*>(in + o);
+      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(in + (o + 4u));
+      win.l[r] = in[o + loff];
+      if (S == 1) win.r[r] = in[o + roff];
     }
-    t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f), t2 = fmaxf(t2, 0.f), t3 = fmaxf(t3, 0.f);
+  };
+
+  DwWindow<S> ring[D];
+  float wq[D][CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-      const float w = wp[((size_t)ct * ksteps + ks) * 64];
-      acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t0, acc[ct][0], 0, 0, 0);
-      acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t1, acc[ct][1], 0, 0, 0);
-      acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t2, acc[ct][2], 0, 0, 0);
-      acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, t3, acc[ct][3], 0, 0, 0);
+  for (int d = 0; d < D; d++) {
+    load_window(d, ring[d]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + d) * 64];
+  }
+  for (int ks0 = 0; ks0 < ksteps; ks0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int ks = ks0 + d;
+      const DwWindow<S> win = ring[d];
+      float w[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
+      const int kn = min(ks + D, ksteps - 1);  // refill the slot (tail: harmless re-read)
+      load_window(kn, ring[d]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
+
+      const float* wd = s_dw + (2 * ks + half) * 12;
+      float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
+        const bool ok = rowok[r];
+        if (S == 1) {
+          float4 m = win.m0[r];
+          m.x = ok ? m.x : 0.f, m.y = ok ? m.y : 0.f, m.z = ok ? m.z : 0.f, m.w = ok ? m.w : 0.f;
+          const float l = (ok && leftok) ? win.l[r] : 0.f;
+          const float rr = (ok && rightok) ? win.r[r] : 0.f;
+          // per pixel, taps in kx order: x-1, x, x+1
+          t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+          t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+          t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
+          t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+        } else {
+          float4 m0 = win.m0[r], m1 = win.m1[r];
+          m0.x = ok ? m0.x : 0.f, m0.y = ok ? m0.y : 0.f, m0.z = ok ? m0.z : 0.f, m0.w = ok ? m0.w : 0.f;
+          m1.x = ok ? m1.x : 0.f, m1.y = ok ? m1.y : 0.f, m1.z = ok ? m1.z : 0.f, m1.w = ok ? m1.w : 0.f;
+          const float l = (ok && leftok) ? win.l[r] : 0.f;
+          // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
+          t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
+          t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
+          t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
+          t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
+        }
+      }
+      t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f), t2 = fmaxf(t2, 0.f), t3 = fmaxf(t3, 0.f);
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) {
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t0, acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t1, acc[ct][1], 0, 0, 0);
+        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t2, acc[ct][2], 0, 0, 0);
+        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t3, acc[ct][3], 0, 0, 0);
+      }
     }
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
@@ -377,42 +452,42 @@ bool dwpw_supported(const ConvArgs& a, int stride) {
          (stride == 1 ? (a.iw == a.ow && a.ih == a.oh) : (a.iw == 2 * a.ow));
 }
 
-// Two 32-cout tiles per wave halve the activation reads but need 128 accumulator registers
-// (1 wave/SIMD); worth it only when the launch has far more wave tiles than the chip has SIMDs.
-static bool use_two_tiles(long groups, int cts) {
-  static const int force = std::getenv("UFD_CT") ? std::atoi(std::getenv("UFD_CT")) : 0;  // tuning knob
-  if (cts % 2) return false;
-  if (force) return force == 2;
-  const long waves_ct1 = (groups + 31) / 32 * cts;
-  return waves_ct1 >= 16384;
+// One 32-cout tile per wave (64 accumulator registers, 3 waves/SIMD) measured faster than two
+// tiles (128 accumulators, 1 wave/SIMD) on every layer of this network at batch 32, so the
+// launchers use CT = 1: activations of wider layers are re-read per cout tile from L2.
+void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  const long groups = (long)a.B * (a.oh * a.ow / 4);
+  a.tiles = (int)((groups + 127) / 128);
+  a.cts = (a.cout + 31) / 32;
+  const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
+  if ((a.cin >> 1) % 4 == 0)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_pw_mfma<1, 1>), dim3(grid), dim3(256), 0, s, a);
 }
 
-void launch_conv_pointwise_mfma(const ConvArgs& a, hipStream_t s) {
+void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
+  ConvArgs a = a0;
   const long groups = (long)a.B * (a.oh * a.ow / 4);
-  const unsigned gx = (unsigned)((groups + 127) / 128);
-  const int cts = (a.cout + 31) / 32;
-  if (use_two_tiles(groups, cts)) {
-    hipLaunchKernelGGL(k_pw_mfma<2>, dim3(gx, cts / 2), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(k_pw_mfma<1>, dim3(gx, cts), dim3(256), 0, s, a);
-  }
-}
-
-void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s) {
-  const long groups = (long)a.B * (a.oh * a.ow / 4);
-  const unsigned gx = (unsigned)((groups + 127) / 128);
-  const int cts = (a.cout + 31) / 32;
+  a.tiles = (int)((groups + 127) / 128);
+  a.cts = (a.cout + 31) / 32;
+  const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
   const size_t lds = (size_t)a.cin * 12 * sizeof(float);
-  if (use_two_tiles(groups, cts)) {
-    if (stride == 1)
-      hipLaunchKernelGGL((k_dwpw_mfma<2, 1>), dim3(gx, cts / 2), dim3(256), lds, s, a);
+  const bool deep = (a.cin >> 1) % 4 == 0;
+  static const int knob = std::getenv("UFD_DWD") ? std::atoi(std::getenv("UFD_DWD")) : 2;  // tuning knob
+  if (stride == 1) {
+    if (deep && knob == 4)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 4>), grid, dim3(256), lds, s, a);
+    else if (deep && knob == 2)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2>), grid, dim3(256), lds, s, a);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<2, 2>), dim3(gx, cts / 2), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1>), grid, dim3(256), lds, s, a);
   } else {
-    if (stride == 1)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1>), dim3(gx, cts), dim3(256), lds, s, a);
+    if (deep)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2>), grid, dim3(256), lds, s, a);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2>), dim3(gx, cts), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1>), grid, dim3(256), lds, s, a);
   }
 }
 

@@ -49,6 +49,7 @@ struct ConvArgs {
   int32_t B, cin, cout, ih, iw, oh, ow;
   int32_t k, stride, pad, dil, depthwise, relu;
   int32_t in_ctotal, out_ctotal, out_coff;
+  int32_t tiles, cts;  // MFMA kernels: pixel tiles (blocks) and 32-cout tiles, set by the launcher
 };
 // Reference-order direct convolution (any layer).  w: [cout][cin/g][k][k].
 void launch_conv_direct(const ConvArgs& a, hipStream_t s);

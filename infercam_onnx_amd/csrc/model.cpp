@@ -479,53 +479,70 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 // ---------------------------------------------------------------- GPU stages
 float* tensor_ptr(ufd_model* m, int t) { return m->d_arena + m->tensors[t].off; }
 
-// [count][3][H][W] in d_input -> every conv output the heads need
-void enqueue_forward(ufd_model* m, uint32_t count) {
-  for (int i = 0; i < kNumConv; i++) {
-    const Layer& L = m->layers[i];
-    if (L.kind == kKindFusedAway && !L.materialize) continue;
-    ConvArgs a{};
-    a.in = L.in_tensor < 0 ? m->d_input : tensor_ptr(m, L.in_tensor);
-    a.w = L.d_w;
-    a.bias = L.d_b;
-    a.out = tensor_ptr(m, L.out_tensor);
-    a.res = L.res_tensor >= 0 ? tensor_ptr(m, L.res_tensor) : nullptr;
-    a.B = (int)count;
-    a.cin = L.spec.cin, a.cout = L.spec.cout;
-    a.ih = L.ih, a.iw = L.iw, a.oh = L.oh, a.ow = L.ow;
-    a.k = L.spec.k, a.stride = L.spec.stride, a.pad = L.spec.pad, a.dil = L.spec.dil;
-    a.depthwise = L.spec.groups > 1;
-    a.relu = L.spec.relu || i == kRfbShortcut;
-    a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
-    a.out_ctotal = m->tensors[L.out_tensor].c;
-    a.out_coff = L.out_coff;
-    int dw_stride = 1;
-    const char* kind = "conv_direct_full";
-    switch (L.kind) {
-      case kKindPointwise: kind = "conv_pw_mfma"; break;
-      case kKindDwPw: {
-        const Layer& D = m->layers[L.fused_dw];
-        kind = "conv_dwpw_mfma";
-        a.in = D.in_tensor < 0 ? m->d_input : tensor_ptr(m, D.in_tensor);
-        a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
-        a.ih = D.ih, a.iw = D.iw;
-        a.w2 = D.d_w, a.bias2 = D.d_b;
-        dw_stride = D.spec.stride;
-        break;
-      }
-      case kKindConv3x3: kind = "conv3x3_mfma"; break;
-      case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
-      case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
+// one conv layer for frames [f0, f0 + count) of the batch
+void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
+  const Layer& L = m->layers[i];
+  if (L.kind == kKindFusedAway && !L.materialize) return;
+  auto in_ptr = [&](int t, int ih, int iw) -> const float* {
+    if (t < 0) return m->d_input + (size_t)f0 * 3 * ih * iw;
+    return tensor_ptr(m, t) + (size_t)f0 * m->tensors[t].per_frame();
+  };
+  ConvArgs a{};
+  a.in = in_ptr(L.in_tensor, L.ih, L.iw);
+  a.w = L.d_w;
+  a.bias = L.d_b;
+  a.out = tensor_ptr(m, L.out_tensor) + (size_t)f0 * m->tensors[L.out_tensor].per_frame();
+  a.res = L.res_tensor >= 0 ? in_ptr(L.res_tensor, 0, 0) : nullptr;
+  a.B = (int)count;
+  a.cin = L.spec.cin, a.cout = L.spec.cout;
+  a.ih = L.ih, a.iw = L.iw, a.oh = L.oh, a.ow = L.ow;
+  a.k = L.spec.k, a.stride = L.spec.stride, a.pad = L.spec.pad, a.dil = L.spec.dil;
+  a.depthwise = L.spec.groups > 1;
+  a.relu = L.spec.relu || i == kRfbShortcut;
+  a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
+  a.out_ctotal = m->tensors[L.out_tensor].c;
+  a.out_coff = L.out_coff;
+  int dw_stride = 1;
+  const char* kind = "conv_direct_full";
+  switch (L.kind) {
+    case kKindPointwise: kind = "conv_pw_mfma"; break;
+    case kKindDwPw: {
+      const Layer& D = m->layers[L.fused_dw];
+      kind = "conv_dwpw_mfma";
+      a.in = in_ptr(D.in_tensor, D.ih, D.iw);
+      a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
+      a.ih = D.ih, a.iw = D.iw;
+      a.w2 = D.d_w, a.bias2 = D.d_b;
+      dw_stride = D.spec.stride;
+      break;
     }
-    ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
-                 L.flops_per_frame * count);
-    switch (L.kind) {
-      case kKindPointwise: launch_conv_pointwise_mfma(a, m->stream); break;
-      case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->stream); break;
-      case kKindConv3x3: launch_conv3x3_mfma(a, m->stream); break;
-      default: launch_conv_direct(a, m->stream); break;
-    }
+    case kKindConv3x3: kind = "conv3x3_mfma"; break;
+    case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
+    case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
+  ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
+               L.flops_per_frame * count);
+  switch (L.kind) {
+    case kKindPointwise: launch_conv_pointwise_mfma(a, m->stream); break;
+    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->stream); break;
+    case kKindConv3x3: launch_conv3x3_mfma(a, m->stream); break;
+    default: launch_conv_direct(a, m->stream); break;
+  }
+}
+
+// [count][3][H][W] in d_input -> every conv output the heads need.
+// The 240x320 / 120x160 stages move 10-20 MB per frame each, so a 32-frame batch streams through
+// HBM between layers; run in chunks of `early_chunk` frames those layers keep producer->consumer
+// tensors inside the 256 MiB Infinity Cache.  Deeper layers are small and want the whole batch
+// in one launch.
+void enqueue_forward(ufd_model* m, uint32_t count) {
+  static const int chunk_knob = std::getenv("UFD_CHUNK") ? std::atoi(std::getenv("UFD_CHUNK")) : 0;
+  static const int until_knob = std::getenv("UFD_CHUNK_LAYERS") ? std::atoi(std::getenv("UFD_CHUNK_LAYERS")) : 9;
+  const uint32_t chunk = chunk_knob > 0 ? (uint32_t)chunk_knob : count;
+  const int early_end = chunk < count ? std::min(until_knob, kNumConv) : 0;
+  for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
+    for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
+  for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
   m->last_forward_count = count;
 }
 
