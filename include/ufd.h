@@ -72,6 +72,9 @@ typedef struct ufd_config {
 
 #define UFD_FLAG_KEEP_LAYERS 1u /* keep every conv output resident for ufd_debug_layer_output */
 #define UFD_FLAG_PROFILE 2u     /* record HIP events around every kernel (ufd_profile_read) */
+#define UFD_FLAG_DEVICE_ENTROPY 4u /* Huffman-decode restart-interval streams on the GPU (one lane per
+                                      interval) instead of on host workers; JPEG bytes cross PCIe, not
+                                      coefficient slabs.  Off by default: see DESIGN.md section 4 */
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);

@@ -5,6 +5,7 @@
 // for DHT-less MJPEG camera streams.
 #include "jpeg_host.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 namespace ufd {
@@ -61,6 +62,9 @@ struct HuffTable {
     int total = 0;
     for (int i = 0; i < 16; i++) total += counts[i];
     if (total > 256 || total != nsym) return false;
+    std::memset(sym, 0, sizeof(sym));  // unused entries are compared too (device table-set cache)
+    std::memset(maxcode, 0, sizeof(maxcode));
+    std::memset(delta, 0, sizeof(delta));
     std::memcpy(sym, symbols, total);
     std::memset(fast, 0, sizeof(fast));
     std::memset(fast_ac, 0, sizeof(fast_ac));
@@ -197,6 +201,7 @@ struct Scan {
 struct Decoder {
   JpegFrameDesc* d;
   int16_t* coef;
+  GpuScanPlan* plan = nullptr;  // non-null: plan a device decode instead of decoding
   HuffTable dc[4], ac[4];
   uint16_t qtab[4][64];
   bool qt_present[4] = {false, false, false, false};
@@ -464,6 +469,97 @@ struct Decoder {
     return kJpegOk;
   }
 
+  static void export_lut(const HuffTable& t, HuffLut* o) {
+    static_assert(sizeof(o->fast) == sizeof(t.fast), "lookup width mismatch");
+    std::memcpy(o->fast, t.fast, sizeof(o->fast));
+    std::memcpy(o->maxcode, t.maxcode, sizeof(o->maxcode));
+    std::memcpy(o->delta, t.delta, sizeof(o->delta));
+    std::memcpy(o->sym, t.sym, sizeof(o->sym));
+  }
+
+  // Marker scan of one interleaved baseline scan with restart intervals: no bit is decoded.
+  int plan_scan(const Scan& sc, const uint8_t* base, const uint8_t* p, const uint8_t* end) {
+    const int ri = d->restart_interval;
+    if (d->progressive || sc.ns != d->ncomp || ri <= 0) return kJpegNotEligible;
+    std::memset(&plan->scan, 0, sizeof(plan->scan));
+    // table slots: at most 2 distinct DC and 2 distinct AC tables
+    int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
+    auto slot = [](int (&ids)[2], int id) {
+      for (int i = 0; i < 2; i++) {
+        if (ids[i] == id) return i;
+        if (ids[i] < 0) {
+          ids[i] = id;
+          return i;
+        }
+      }
+      return -1;
+    };
+    int nb = 0;
+    for (int i = 0; i < sc.ns; i++) {
+      const int c = sc.comp[i];
+      if (!dc[sc.td[i]].present || !ac[sc.ta[i]].present) return kJpegCorrupt;
+      const int ds = slot(dc_ids, sc.td[i]), as = slot(ac_ids, sc.ta[i]);
+      if (ds < 0 || as < 0) return kJpegNotEligible;
+      for (int by = 0; by < d->v[c]; by++)
+        for (int bx = 0; bx < d->h[c]; bx++) {
+          if (nb >= 10) return kJpegNotEligible;
+          plan->scan.blk_comp[nb] = (uint8_t)c, plan->scan.blk_bx[nb] = (uint8_t)bx, plan->scan.blk_by[nb] = (uint8_t)by;
+          plan->scan.blk_dc[nb] = (uint8_t)ds, plan->scan.blk_ac[nb] = (uint8_t)as;
+          nb++;
+        }
+    }
+    plan->scan.blocks_per_mcu = nb;
+    std::memset(plan->luts, 0, sizeof(plan->luts));
+    for (int i = 0; i < 2; i++) {
+      if (dc_ids[i] >= 0) export_lut(dc[dc_ids[i]], &plan->luts[i]);
+      if (ac_ids[i] >= 0) export_lut(ac[ac_ids[i]], &plan->luts[2 + i]);
+    }
+    const long total_mcus = (long)d->mcux * d->mcuy;
+    const long n_iv = (total_mcus + ri - 1) / ri;
+    if (n_iv > GpuScanPlan::kMaxIntervals) return kJpegNotEligible;
+    // walk the entropy-coded segment: 0xFF00 = stuffing, 0xFFFF.. = fill, 0xFFD0-D7 = RSTn
+    const uint8_t* q = p;
+    uint32_t begin = (uint32_t)(p - base);
+    long k = 0;
+    int next_rst = 0;
+    for (;;) {
+      const uint8_t* f = static_cast<const uint8_t*>(std::memchr(q, 0xFF, end - q));
+      if (!f || f + 1 >= end) return kJpegCorrupt;  // ran off the data: no EOI
+      const int m = f[1];
+      if (m == 0x00) {
+        q = f + 2;
+        continue;
+      }
+      if (m == 0xFF) {
+        q = f + 1;
+        continue;
+      }
+      if (k >= n_iv) return kJpegCorrupt;
+      HuffInterval& iv = plan->iv[k];
+      iv.frame = 0;
+      iv.begin = begin;
+      iv.end = (uint32_t)(f - base);
+      // (optional 0xFF fill bytes in front of the marker stay inside the range: the device bit
+      // reader stops at the first 0xFF that is not followed by 0x00)
+      iv.mcu0 = (uint32_t)(k * ri);
+      iv.nmcu = (uint32_t)std::min<long>(ri, total_mcus - k * ri);
+      k++;
+      if (m >= 0xD0 && m <= 0xD7) {
+        if (m != 0xD0 + next_rst) return kJpegCorrupt;
+        next_rst = (next_rst + 1) & 7;
+        begin = (uint32_t)(f + 2 - base);
+        q = f + 2;
+        continue;
+      }
+      // any other marker ends the scan
+      if (k != n_iv) return kJpegCorrupt;
+      plan->n_intervals = (uint32_t)n_iv;
+      scan_end = f;
+      return kJpegOk;
+    }
+  }
+  const uint8_t* scan_end = nullptr;
+
   // header_only: stop at the first SOS.
   int run(const uint8_t* data, size_t len, size_t coef_cap, bool header_only) {
     std::memset(d, 0, sizeof(*d));
@@ -510,7 +606,7 @@ struct Decoder {
             finish_desc();
             return kJpegOk;
           }
-          if (d->coef_total > coef_cap) return kJpegUnsupported;
+          if (!plan && d->coef_total > coef_cap) return kJpegUnsupported;
           Scan sc;
           if (sl < 1) return kJpegCorrupt;
           sc.ns = s[0];
@@ -536,6 +632,14 @@ struct Decoder {
             if ((sc.ss == 0 && sc.se != 0) || (sc.ss > 0 && sc.ns != 1)) return kJpegCorrupt;
           }
           install_defaults();
+          if (plan) {
+            if (scans) return kJpegNotEligible;
+            rc = plan_scan(sc, data, p + seglen, end);
+            if (rc) return rc;
+            scans++;
+            p = scan_end;
+            continue;
+          }
           // a sequential interleaved scan over all components writes every block in full;
           // anything else (progressive, per-component scans) accumulates into a zeroed slab
           const bool writes_all = !d->progressive && sc.ns == d->ncomp;
@@ -574,6 +678,15 @@ int jpeg_parse_header(const uint8_t* data, size_t len, JpegFrameDesc* d) {
   dec.d = d;
   dec.coef = nullptr;
   return dec.run(data, len, 0, true);
+}
+
+int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan) {
+  Decoder dec;
+  dec.d = d;
+  dec.coef = nullptr;
+  dec.plan = plan;
+  plan->n_intervals = 0;
+  return dec.run(data, len, 0, false);
 }
 
 int jpeg_decode_coefficients(const uint8_t* data, size_t len, JpegFrameDesc* d, int16_t* coef, size_t coef_cap) {

@@ -10,7 +10,7 @@ namespace ufd {
 
 constexpr int kMaxComps = 3;
 
-enum JpegStatus { kJpegOk = 0, kJpegCorrupt = -2, kJpegUnsupported = -3 };
+enum JpegStatus { kJpegOk = 0, kJpegCorrupt = -2, kJpegUnsupported = -3, kJpegNotEligible = -100 };
 
 // Colour handling after upsampling (libjpeg default_decompress_parms for 1/3 components).
 enum JpegColor : int32_t { kColorGray = 0, kColorYCbCr = 1, kColorRGB = 2 };
@@ -38,5 +38,43 @@ int jpeg_parse_header(const uint8_t* data, size_t len, JpegFrameDesc* d);
 // Full entropy decode: fills d (geometry + quant tables) and coef[d->coef_total]
 // (int16, natural order, [comp][block_row][block_col][64]).  `coef_cap` in int16 units.
 int jpeg_decode_coefficients(const uint8_t* data, size_t len, JpegFrameDesc* d, int16_t* coef, size_t coef_cap);
+
+// ---- device entropy decoding of restart-interval streams (huffman_kernels.hip) ----
+// Lookup form of one Huffman table, identical on host and device.
+struct HuffLut {
+  uint16_t fast[1024];  // peek(10) -> (code length << 8) | symbol; 0 = code longer than 10 bits
+  int32_t maxcode[18];  // exclusive upper bound of codes of length l, left-justified to 16 bits
+  int32_t delta[17];    // symbol index = (code >> (16 - l)) + delta[l]
+  uint8_t sym[256];
+};
+
+// Scan layout of one frame for the device decoder.
+struct HuffScan {
+  uint32_t blob_off;        // offset of the frame's JPEG bytes inside the batch blob
+  uint32_t blocks_per_mcu;  // <= 10
+  uint32_t lut_base;        // first of the 4 HuffLut of this frame: dc slot 0/1, ac slot 0/1
+  uint32_t pad;
+  uint8_t blk_comp[12], blk_bx[12], blk_by[12], blk_dc[12], blk_ac[12];  // per block of the MCU
+};
+
+// One restart interval = one independent unit of entropy decoding.
+struct HuffInterval {
+  uint32_t frame;
+  uint32_t begin, end;  // byte range inside the frame's JPEG (end = position of the terminating marker)
+  uint32_t mcu0, nmcu;  // first MCU and MCU count
+};
+
+struct GpuScanPlan {
+  HuffScan scan;
+  HuffLut luts[4];
+  static constexpr int kMaxIntervals = 1024;
+  uint32_t n_intervals;
+  HuffInterval iv[kMaxIntervals];
+};
+
+// Header + marker scan only (no entropy decoding): fills the frame geometry and the interval
+// list for the device decoder.  kJpegNotEligible when the stream is not a single interleaved
+// baseline scan with restart intervals (the caller then decodes on the host).
+int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan);
 
 }  // namespace ufd

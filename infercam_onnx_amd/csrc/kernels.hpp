@@ -22,6 +22,13 @@ void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, 
 void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
                           const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count, hipStream_t s);
 
+// Entropy decoding on the device for restart-interval streams (huffman_kernels.hip): one lane per
+// interval writes the non-zero quantised coefficients into pre-zeroed slabs; status[frame] |= 1 on
+// a corrupt stream.
+void launch_huffman_rst(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t n_iv,
+                        const HuffLut* d_luts, const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride,
+                        uint32_t* d_status, hipStream_t s);
+
 // ---------------- A2-A4: Triangle resize + normalise (preproc_kernels.hip) ----------------
 struct ResizeTaps {          // device pointers, one table per axis
   const int32_t* left;       // [D]

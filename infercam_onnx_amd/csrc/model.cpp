@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,8 @@ struct ProfEntry {
   double bytes, flops;
 };
 
+struct Ctx;
+
 struct Slot {
   bool busy = false;
   uint32_t ticket = 0, count = 0, cap = 0;
@@ -70,12 +73,50 @@ struct Slot {
   int16_t* h_coef = nullptr;
   Det* h_dets = nullptr;
   uint32_t* h_ndet = nullptr;
+  uint32_t* h_gpu_status = nullptr;  // per frame: device entropy decoder flagged a corrupt stream
+  uint8_t* h_blob = nullptr;        // pinned staging of the batch's JPEG bytes
+  HuffScan* h_scans = nullptr;
+  HuffInterval* h_ivs = nullptr;
+  std::vector<GpuScanPlan> plans;
+  bool gpu_entropy = false;
   ufd_det* out = nullptr;
   uint32_t* n = nullptr;
   int32_t* status = nullptr;
   std::vector<int32_t> st;
   hipEvent_t done = nullptr;
+  Ctx* ctx = nullptr;  // context whose stream produced this slot's results
 };
+
+// Device-side working set of one in-flight batch.  A handle owns kNumCtx of them and alternates
+// batches between them: their kernels run on different HIP streams, so the latency-bound stages
+// of one batch (small feature maps, NMS) overlap the bandwidth-bound stages of the other.
+struct Ctx {
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
+  float* d_arena = nullptr;
+  float* d_input = nullptr;
+  JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
+  int16_t* d_coef_buf[2] = {nullptr, nullptr};
+  // device entropy decoding: JPEG bytes, scan layouts and restart intervals of the batch
+  uint8_t* d_blob_buf[2] = {nullptr, nullptr};
+  HuffScan* d_scans_buf[2] = {nullptr, nullptr};
+  HuffInterval* d_ivs_buf[2] = {nullptr, nullptr};
+  uint32_t* d_status = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool consumed_valid[2] = {false, false};
+  int flip = 0;
+  uint8_t* d_planes = nullptr;
+  uint8_t* d_rgb = nullptr;
+  float* d_scores = nullptr;
+  float* d_boxes = nullptr;
+  unsigned long long* d_keys = nullptr;
+  uint32_t* d_counts = nullptr;
+  Det* d_dets = nullptr;
+  uint32_t* d_ndet = nullptr;
+  float4* d_spill = nullptr;
+  uint32_t last_forward_count = 0;
+};
+constexpr int kNumCtx = 2;
 
 constexpr uint32_t kDetCopy = 256;  // detections per frame copied back with the batch
 
@@ -98,8 +139,9 @@ struct ufd_model {
   int W = 0, H = 0, K = 0;
   uint32_t B = 0;
   uint32_t max_w = 0, max_h = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
+  Ctx ctx[kNumCtx];
+  Ctx* cur = &ctx[0];  // context of the call in progress (set under the handle lock)
+  int next_ctx = 0;
   std::unique_ptr<ThreadPool> pool;
 
   // resident model
@@ -109,32 +151,23 @@ struct ufd_model {
   std::vector<Layer> layers;
   std::vector<Tensor> tensors;
   size_t arena_floats = 0;
-  float* d_arena = nullptr;
-  float* d_input = nullptr;
 
   // frame staging (device)
   size_t coef_stride = 0, plane_stride = 0, rgb_stride = 0;
-  JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
-  int16_t* d_coef_buf[2] = {nullptr, nullptr};
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool consumed_valid[2] = {false, false};
-  int flip = 0;
-  uint8_t* d_planes = nullptr;
-  uint8_t* d_rgb = nullptr;
 
   // post
-  float* d_scores = nullptr;
-  float* d_boxes = nullptr;
-  unsigned long long* d_keys = nullptr;
   size_t key_stride = 0;
-  uint32_t* d_counts = nullptr;
-  Det* d_dets = nullptr;
-  uint32_t* d_ndet = nullptr;
-  float4* d_spill = nullptr;
+
+  // device entropy decoding: table sets seen so far (append-only, shared by the contexts)
+  static constexpr int kMaxLutSets = 16;
+  std::vector<std::array<HuffLut, 4>> lut_sets;
+  HuffLut* d_luts = nullptr;
+  size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
+  uint32_t iv_cap = 0;      // restart intervals per batch
+  bool gpu_entropy_enabled = true;
 
   Slot slots[UFD_MAX_SLOTS];
   uint32_t next_ticket = 1;
-  uint32_t last_forward_count = 0;
 
   std::map<std::pair<int, int>, std::pair<TapsDev, TapsDev>> taps;
 
@@ -191,7 +224,7 @@ struct ProfScope {
   bool on;
   hipStream_t st;
   ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
-      : m(mm), on(mm->profile && mm->prof_active), st(stream ? stream : mm->stream) {
+      : m(mm), on(mm->profile && mm->prof_active), st(stream ? stream : mm->cur->stream) {
     if (!on) return;
     pe.name_id = prof_name_id(m, name);
     pe.bytes = bytes;
@@ -412,6 +445,11 @@ int alloc_slot(ufd_model* m, Slot& s) {
   HIPC(m, hipHostMalloc(&s.h_coef, sizeof(int16_t) * m->coef_stride * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_blob, m->blob_stride * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_scans, sizeof(HuffScan) * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_ivs, sizeof(HuffInterval) * m->iv_cap, hipHostMallocDefault));
+  s.plans.resize(m->B);
   HIPC(m, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.st.resize(m->B);
   return UFD_OK;
@@ -477,14 +515,14 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 }
 
 // ---------------------------------------------------------------- GPU stages
-float* tensor_ptr(ufd_model* m, int t) { return m->d_arena + m->tensors[t].off; }
+float* tensor_ptr(ufd_model* m, int t) { return m->cur->d_arena + m->tensors[t].off; }
 
 // one conv layer for frames [f0, f0 + count) of the batch
 void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   const Layer& L = m->layers[i];
   if (L.kind == kKindFusedAway && !L.materialize) return;
   auto in_ptr = [&](int t, int ih, int iw) -> const float* {
-    if (t < 0) return m->d_input + (size_t)f0 * 3 * ih * iw;
+    if (t < 0) return m->cur->d_input + (size_t)f0 * 3 * ih * iw;
     return tensor_ptr(m, t) + (size_t)f0 * m->tensors[t].per_frame();
   };
   ConvArgs a{};
@@ -523,10 +561,10 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
                L.flops_per_frame * count);
   switch (L.kind) {
-    case kKindPointwise: launch_conv_pointwise_mfma(a, m->stream); break;
-    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->stream); break;
-    case kKindConv3x3: launch_conv3x3_mfma(a, m->stream); break;
-    default: launch_conv_direct(a, m->stream); break;
+    case kKindPointwise: launch_conv_pointwise_mfma(a, m->cur->stream); break;
+    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->cur->stream); break;
+    case kKindConv3x3: launch_conv3x3_mfma(a, m->cur->stream); break;
+    default: launch_conv_direct(a, m->cur->stream); break;
   }
 }
 
@@ -543,7 +581,7 @@ void enqueue_forward(ufd_model* m, uint32_t count) {
   for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
     for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
   for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
-  m->last_forward_count = count;
+  m->cur->last_forward_count = count;
 }
 
 void enqueue_heads(ufd_model* m, uint32_t count) {
@@ -559,23 +597,26 @@ void enqueue_heads(ufd_model* m, uint32_t count) {
     base += h.plane[i] * kHeadAnchors[i];
   }
   h.base[4] = base;
-  (void)hipMemsetAsync(m->d_counts, 0, sizeof(uint32_t) * count, m->stream);
+  (void)hipMemsetAsync(m->cur->d_counts, 0, sizeof(uint32_t) * count, m->cur->stream);
   ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 6 + 4) * 4, 0);
-  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, m->d_scores, m->d_boxes, m->d_keys, m->key_stride,
-                     m->d_counts, m->stream);
+  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, m->cur->d_scores, m->cur->d_boxes, m->cur->d_keys, m->key_stride,
+                     m->cur->d_counts, m->cur->stream);
 }
 
 void enqueue_nms(ufd_model* m, uint32_t count) {
   ProfScope ps(m, "sort_nms", 0, 0);
-  launch_sort_nms(m->d_keys, m->key_stride, m->d_counts, m->d_boxes, m->K, m->cfg.max_iou, m->d_dets, m->K, m->d_ndet,
-                  m->d_spill, count, m->stream);
+  launch_sort_nms(m->cur->d_keys, m->key_stride, m->cur->d_counts, m->cur->d_boxes, m->K, m->cfg.max_iou, m->cur->d_dets, m->K, m->cur->d_ndet,
+                  m->cur->d_spill, count, m->cur->stream);
 }
 
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
-  HIPC(m, hipMemcpyAsync(s.h_ndet, m->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->stream));
-  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, m->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
-                           hipMemcpyDeviceToHost, m->stream));
-  HIPC(m, hipEventRecord(s.done, m->stream));
+  HIPC(m, hipMemcpyAsync(s.h_ndet, m->cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->cur->stream));
+  if (s.gpu_entropy)
+    HIPC(m, hipMemcpyAsync(s.h_gpu_status, m->cur->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->cur->stream));
+  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, m->cur->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
+                           hipMemcpyDeviceToHost, m->cur->stream));
+  HIPC(m, hipEventRecord(s.done, m->cur->stream));
+  s.ctx = m->cur;
   return UFD_OK;
 }
 
@@ -589,6 +630,7 @@ int finish_slot(ufd_model* m, Slot& s) {
   for (uint32_t i = 0; i < s.count; i++) {
     int32_t st = s.st[i];
     uint32_t nd = 0;
+    if (st == UFD_OK && s.gpu_entropy && s.h_gpu_status[i]) st = UFD_E_DECODE;  // device decoder hit a corrupt stream
     if (st == UFD_OK) {
       nd = s.h_ndet[i];
       const uint32_t ncopy = std::min(nd, s.cap);
@@ -596,7 +638,7 @@ int finish_slot(ufd_model* m, Slot& s) {
       const uint32_t fast = std::min(ncopy, kDetCopy);
       std::memcpy(dst, s.h_dets + (size_t)i * kDetCopy, sizeof(Det) * fast);
       if (ncopy > fast) {  // rare: more than kDetCopy detections requested for one frame
-        HIPC(m, hipMemcpy(dst + fast, m->d_dets + (size_t)i * m->K + fast, sizeof(Det) * (ncopy - fast),
+        HIPC(m, hipMemcpy(dst + fast, s.ctx->d_dets + (size_t)i * m->K + fast, sizeof(Det) * (ncopy - fast),
                           hipMemcpyDeviceToHost));
       }
       if (nd > s.cap) st = UFD_E_TRUNCATED;
@@ -621,28 +663,179 @@ int check_outputs(ufd_model* m, const void* out, uint32_t cap, const void* n) {
 }
 
 // Host entropy decode of `count` JPEGs into the slot, then enqueue the whole GPU pipeline.
-int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
-  int rc = alloc_slot(m, s);
-  if (rc) return rc;
-  s.count = count;
-  m->prof_active = (m->prof_batch++ % m->prof_every) == 0;
+int status_from_jpeg(int st) {
+  return st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : (st == kJpegUnsupported ? UFD_E_UNSUPPORTED : st));
+}
+
+// Index of this frame's Huffman table set in d_luts (uploading it first if it is new), or -1.
+int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
+  for (size_t i = 0; i < m->lut_sets.size(); i++)
+    if (!std::memcmp(m->lut_sets[i].data(), luts, sizeof(HuffLut) * 4)) return (int)i;
+  if ((int)m->lut_sets.size() >= ufd_model::kMaxLutSets) return -1;
+  std::array<HuffLut, 4> set;
+  std::memcpy(set.data(), luts, sizeof(HuffLut) * 4);
+  const size_t idx = m->lut_sets.size();
+  // rare (once per camera stream): blocking copy into an unused slot of the shared table array
+  if (hipMemcpy(m->d_luts + idx * 4, set.data(), sizeof(HuffLut) * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  m->lut_sets.push_back(set);
+  return (int)idx;
+}
+
+// Stage 1 of row A1 for `count` JPEGs: leaves quantised coefficient slabs in d_coef_buf[*buf] and
+// frame descriptors in d_descs_buf[*buf], ordered before later work on the context's stream.
+//   device path: header/marker scan on host workers, JPEG bytes H2D, one lane per restart interval
+//   host path:   Huffman decoding on host workers, coefficient slabs H2D
+int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, int* buf_out,
+                  bool* any_ok_out) {
+  Ctx& c = *m->cur;
+  bool device_path = m->gpu_entropy_enabled;
+  if (device_path) {
+    m->pool->parallel_for(count, [&](unsigned i) {
+      JpegFrameDesc* d = &s.h_descs[i];
+      int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
+      if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
+      if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
+      s.st[i] = st;
+    });
+    uint32_t n_iv = 0;
+    for (uint32_t i = 0; i < count && device_path; i++) {
+      if (s.st[i] == kJpegNotEligible) device_path = false;
+      if (s.st[i] == kJpegOk) n_iv += s.plans[i].n_intervals;
+    }
+    if (n_iv > m->iv_cap) device_path = false;
+    if (!device_path && std::getenv("UFD_DEBUG")) std::fprintf(stderr, "[ufd] batch not eligible for device entropy decoding (n_iv %u)\n", n_iv);
+    if (device_path) {
+      uint32_t k = 0;
+      HuffScan ref_scan{};
+      bool have_ref = false;
+      for (uint32_t i = 0; i < count && device_path; i++) {
+        if (s.st[i] != kJpegOk) continue;
+        const int set = lut_set_for(m, s.plans[i].luts);
+        if (set < 0) {
+          device_path = false;
+          break;
+        }
+        HuffScan sc = s.plans[i].scan;
+        sc.blob_off = 0;
+        sc.lut_base = (uint32_t)set * 4;
+        // the kernel keeps ONE table set and MCU layout per wave in LDS: batches that mix them
+        // (different cameras in one batch) are decoded on the host instead
+        if (have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) {
+          if (std::getenv("UFD_DEBUG")) {
+            std::fprintf(stderr, "[ufd] frame %u: scan layout/table set differs from the batch's first frame (lut %u vs %u, bpm %u vs %u)\n",
+                         i, sc.lut_base, ref_scan.lut_base, sc.blocks_per_mcu, ref_scan.blocks_per_mcu);
+            const unsigned char* a = reinterpret_cast<const unsigned char*>(&sc);
+            const unsigned char* b = reinterpret_cast<const unsigned char*>(&ref_scan);
+            for (size_t q = 0; q < sizeof(sc); q++)
+              if (a[q] != b[q]) std::fprintf(stderr, "  byte %zu: %u vs %u\n", q, a[q], b[q]);
+          }
+          device_path = false;
+          break;
+        }
+        ref_scan = sc;
+        have_ref = true;
+        sc.blob_off = (uint32_t)(i * m->blob_stride);
+        s.h_scans[i] = sc;
+        for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
+          HuffInterval iv = s.plans[i].iv[j];
+          iv.frame = i;
+          s.h_ivs[k++] = iv;
+        }
+      }
+      if (device_path) {
+        m->pool->parallel_for(count, [&](unsigned i) {
+          if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
+        });
+        bool any_ok = false;
+        size_t used_blob = 0, used_coef = 0;
+        for (uint32_t i = 0; i < count; i++) {
+          if (s.st[i] == kJpegOk) {
+            any_ok = true;
+            used_blob = std::max(used_blob, (lens[i] + 15) & ~(size_t)15);
+            used_coef = std::max(used_coef, (size_t)s.h_descs[i].coef_total);
+          } else {
+            std::memset(&s.h_descs[i], 0, sizeof(JpegFrameDesc));
+          }
+          s.st[i] = status_from_jpeg(s.st[i]);
+        }
+        s.gpu_entropy = true;
+        *any_ok_out = any_ok;
+        if (!any_ok) return UFD_OK;
+        const int buf = c.flip;
+        c.flip ^= 1;
+        *buf_out = buf;
+        if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
+        HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
+        HIPC(m, hipMemcpyAsync(c.d_scans_buf[buf], s.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice, c.copy_stream));
+        HIPC(m, hipMemcpyAsync(c.d_ivs_buf[buf], s.h_ivs, sizeof(HuffInterval) * k, hipMemcpyHostToDevice, c.copy_stream));
+        {
+          ProfScope ps(m, "h2d_jpeg", (double)used_blob * count, 0, c.copy_stream);
+          HIPC(m, hipMemcpy2DAsync(c.d_blob_buf[buf], m->blob_stride, s.h_blob, m->blob_stride, used_blob, count,
+                                   hipMemcpyHostToDevice, c.copy_stream));
+        }
+        HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
+        // zero the slabs while the bytes are still in flight, then decode
+        HIPC(m, hipMemset2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, 0, used_coef * 2, count, c.stream));
+        HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
+        HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+        {
+          ProfScope ps(m, "huffman_rst", (double)used_blob * count, 0);
+          launch_huffman_rst(c.d_blob_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf], k, m->d_luts, c.d_descs_buf[buf],
+                             c.d_coef_buf[buf], m->coef_stride, c.d_status, c.stream);
+        }
+        return UFD_OK;
+      }
+    }
+  }
+  // ---- host entropy decoding
+  s.gpu_entropy = false;
   m->pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_decode_coefficients(jpegs[i], lens[i], d, s.h_coef + (size_t)i * m->coef_stride,
                                                                m->coef_stride)
                                    : kJpegCorrupt;
     if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
-    if (st != kJpegOk) {
-      std::memset(d, 0, sizeof(*d));  // total_blocks = 0, width = 0: every kernel skips the frame
-    }
-    s.st[i] = st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : (st == kJpegUnsupported ? UFD_E_UNSUPPORTED : st));
+    if (st != kJpegOk) std::memset(d, 0, sizeof(*d));  // total_blocks = 0, width = 0: every kernel skips the frame
+    s.st[i] = status_from_jpeg(st);
   });
+  bool any_ok = false;
+  size_t used = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (s.st[i] == UFD_OK) any_ok = true;
+    used = std::max(used, (size_t)s.h_descs[i].coef_total);
+  }
+  *any_ok_out = any_ok;
+  if (!any_ok) return UFD_OK;
+  const int buf = c.flip;
+  c.flip ^= 1;
+  *buf_out = buf;
+  // copy stream: wait until the kernels of two batches ago have consumed this buffer
+  if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
+  HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
+  {
+    ProfScope ps(m, "h2d_coef", 0, 0, c.copy_stream);
+    // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
+    HIPC(m, hipMemcpy2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
+                             hipMemcpyHostToDevice, c.copy_stream));
+  }
+  HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
+  HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+  return UFD_OK;
+}
+
+int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
+  int rc = alloc_slot(m, s);
+  if (rc) return rc;
+  s.count = count;
+  m->prof_active = (m->prof_batch++ % m->prof_every) == 0;
+  int buf = 0;
+  bool any_ok = false;
+  rc = entropy_stage(m, s, jpegs, lens, count, &buf, &any_ok);
+  if (rc) return rc;
   uint32_t max_blocks = 0, mw = 0, mh = 0;
   bool all_model_size = true;
-  bool any_ok = false;
   for (uint32_t i = 0; i < count; i++) {
     if (s.st[i] != UFD_OK) continue;
-    any_ok = true;
     const JpegFrameDesc& d = s.h_descs[i];
     max_blocks = std::max(max_blocks, d.total_blocks);
     mw = std::max(mw, (uint32_t)d.width);
@@ -650,53 +843,38 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     if (d.width != m->W || d.height != m->H) all_model_size = false;
   }
   if (any_ok) {
-    const int buf = m->flip;
-    m->flip ^= 1;
-    JpegFrameDesc* d_descs = m->d_descs_buf[buf];
-    int16_t* d_coef = m->d_coef_buf[buf];
-    // copy stream: wait until the kernels of two batches ago have consumed this buffer
-    if (m->consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(m->copy_stream, m->ev_consumed[buf], 0));
-    HIPC(m, hipMemcpyAsync(d_descs, s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, m->copy_stream));
-    {
-      ProfScope ps(m, "h2d_coef", 0, 0, m->copy_stream);
-      // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
-      size_t used = 0;
-      for (uint32_t i = 0; i < count; i++) used = std::max(used, (size_t)s.h_descs[i].coef_total);
-      HIPC(m, hipMemcpy2DAsync(d_coef, m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
-                               hipMemcpyHostToDevice, m->copy_stream));
-    }
-    HIPC(m, hipEventRecord(m->ev_copied[buf], m->copy_stream));
-    HIPC(m, hipStreamWaitEvent(m->stream, m->ev_copied[buf], 0));
+    JpegFrameDesc* d_descs = m->cur->d_descs_buf[buf];
+    int16_t* d_coef = m->cur->d_coef_buf[buf];
     {
       ProfScope ps(m, "idct", 0, 0);
-      launch_idct(d_descs, d_coef, m->coef_stride, m->d_planes, m->plane_stride, max_blocks, count, m->stream);
+      launch_idct(d_descs, d_coef, m->coef_stride, m->cur->d_planes, m->plane_stride, max_blocks, count, m->cur->stream);
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
       ProfScope ps(m, "upsample_norm", 0, 0);
-      launch_upsample_norm(d_descs, m->d_planes, m->plane_stride, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
-      HIPC(m, hipEventRecord(m->ev_consumed[buf], m->stream));
-      m->consumed_valid[buf] = true;
+      launch_upsample_norm(d_descs, m->cur->d_planes, m->plane_stride, m->d_lut, m->cur->d_input, m->W, m->H, count, m->cur->stream);
+      HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
+      m->cur->consumed_valid[buf] = true;
     } else {
       {
         ProfScope ps(m, "upsample_rgb", 0, 0);
-        launch_upsample_rgb(d_descs, m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, mw, mh, count, m->stream);
+        launch_upsample_rgb(d_descs, m->cur->d_planes, m->plane_stride, m->cur->d_rgb, m->rgb_stride, mw, mh, count, m->cur->stream);
       }
-      HIPC(m, hipEventRecord(m->ev_consumed[buf], m->stream));
-      m->consumed_valid[buf] = true;
+      HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
+      m->cur->consumed_valid[buf] = true;
       for (uint32_t i = 0; i < count; i++) {
         if (s.st[i] != UFD_OK) continue;
         const JpegFrameDesc& d = s.h_descs[i];
-        float* dst = m->d_input + (size_t)i * 3 * m->W * m->H;
-        const uint8_t* src = m->d_rgb + (size_t)i * m->rgb_stride;
+        float* dst = m->cur->d_input + (size_t)i * 3 * m->W * m->H;
+        const uint8_t* src = m->cur->d_rgb + (size_t)i * m->rgb_stride;
         ProfScope ps(m, "resize_norm", 0, 0);
         if (d.width == m->W && d.height == m->H) {
-          launch_norm_only(src, d.width, d.height, d.width * 3, 0, m->d_lut, dst, 1, m->stream);
+          launch_norm_only(src, d.width, d.height, d.width * 3, 0, m->d_lut, dst, 1, m->cur->stream);
         } else {
           ResizeTaps v, h;
           rc = get_taps(m, d.width, d.height, &v, &h);
           if (rc) return rc;
-          launch_resize_norm(src, d.width, d.height, d.width * 3, 0, v, h, m->d_lut, dst, m->W, m->H, 1, m->stream);
+          launch_resize_norm(src, d.width, d.height, d.width * 3, 0, v, h, m->d_lut, dst, m->W, m->H, 1, m->cur->stream);
         }
       }
     }
@@ -712,12 +890,12 @@ int run_rgb_on_device(ufd_model* m, Slot& s, uint32_t w, uint32_t h, uint32_t co
   {
     ProfScope ps(m, "resize_norm", 0, 0);
     if ((int)w == m->W && (int)h == m->H) {
-      launch_norm_only(m->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->d_input, count, m->stream);
+      launch_norm_only(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->cur->d_input, count, m->cur->stream);
     } else {
       ResizeTaps v, hz;
       int rc = get_taps(m, w, h, &v, &hz);
       if (rc) return rc;
-      launch_resize_norm(m->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->d_input, m->W, m->H, count, m->stream);
+      launch_resize_norm(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->cur->d_input, m->W, m->H, count, m->cur->stream);
     }
   }
   enqueue_forward(m, count);
@@ -731,8 +909,8 @@ int upload_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_
   if (w > m->max_w || h > m->max_h) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
   if (count > m->B) return m->fail(UFD_E_TOO_LARGE, "batch larger than max_batch");
   for (uint32_t i = 0; i < count; i++)
-    HIPC(m, hipMemcpy2DAsync(m->d_rgb + (size_t)i * m->rgb_stride, (size_t)w * 3, rgb + (size_t)i * h * pitch, pitch,
-                             (size_t)w * 3, h, hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemcpy2DAsync(m->cur->d_rgb + (size_t)i * m->rgb_stride, (size_t)w * 3, rgb + (size_t)i * h * pitch, pitch,
+                             (size_t)w * 3, h, hipMemcpyHostToDevice, m->cur->stream));
   return UFD_OK;
 }
 
@@ -751,20 +929,26 @@ std::string default_weights_path(int variant) {
 
 void destroy(ufd_model* m) {
   if (!m) return;
-  if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
-  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (Ctx& c : m->ctx) {
+    if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+  }
   auto dfree = [](void* p) {
     if (p) (void)hipFree(p);
   };
-  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_arena), dfree(m->d_input);
-  for (int i = 0; i < 2; i++) {
-    dfree(m->d_descs_buf[i]), dfree(m->d_coef_buf[i]);
-    if (m->ev_copied[i]) (void)hipEventDestroy(m->ev_copied[i]);
-    if (m->ev_consumed[i]) (void)hipEventDestroy(m->ev_consumed[i]);
+  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_luts);
+  for (Ctx& c : m->ctx) {
+    dfree(c.d_arena), dfree(c.d_input), dfree(c.d_status);
+    for (int i = 0; i < 2; i++) {
+      dfree(c.d_descs_buf[i]), dfree(c.d_coef_buf[i]);
+      dfree(c.d_blob_buf[i]), dfree(c.d_scans_buf[i]), dfree(c.d_ivs_buf[i]);
+      if (c.ev_copied[i]) (void)hipEventDestroy(c.ev_copied[i]);
+      if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
+    }
+    dfree(c.d_planes), dfree(c.d_rgb);
+    dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_dets), dfree(c.d_ndet);
+    dfree(c.d_spill);
   }
-  dfree(m->d_planes), dfree(m->d_rgb);
-  dfree(m->d_scores), dfree(m->d_boxes), dfree(m->d_keys), dfree(m->d_counts), dfree(m->d_dets), dfree(m->d_ndet);
-  dfree(m->d_spill);
   for (auto& kv : m->taps)
     for (TapsDev* t : {&kv.second.first, &kv.second.second}) dfree(t->left), dfree(t->cnt), dfree(t->w);
   for (auto& s : m->slots) {
@@ -772,12 +956,18 @@ void destroy(ufd_model* m) {
     if (s.h_coef) (void)hipHostFree(s.h_coef);
     if (s.h_dets) (void)hipHostFree(s.h_dets);
     if (s.h_ndet) (void)hipHostFree(s.h_ndet);
+    if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);
+    if (s.h_blob) (void)hipHostFree(s.h_blob);
+    if (s.h_scans) (void)hipHostFree(s.h_scans);
+    if (s.h_ivs) (void)hipHostFree(s.h_ivs);
     if (s.done) (void)hipEventDestroy(s.done);
   }
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
-  if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  for (Ctx& c : m->ctx) {
+    if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+  }
   delete m;
 }
 
@@ -837,8 +1027,10 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
-  HIPB(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-  HIPB(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+  for (Ctx& c : m->ctx) {
+    HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  }
 
   // ---- weights + priors
   std::vector<float> blob, priors;
@@ -894,8 +1086,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
   }
   // ---- buffers
   const size_t B = m->B;
-  HIPB(hipMalloc(&m->d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
-  HIPB(hipMalloc(&m->d_input, B * 3 * m->W * m->H * sizeof(float)));
   {
     // worst-case slab: every component at full resolution, padded to 16-pixel MCUs
     const size_t pw = (m->max_w + 15) / 16 * 16, ph = (m->max_h + 15) / 16 * 16;
@@ -903,24 +1093,38 @@ int create(const ufd_config* cfg, ufd_model** out) {
     m->plane_stride = pw * ph * 3;
     m->rgb_stride = ((size_t)m->max_w * m->max_h * 3 + 15) & ~(size_t)15;
   }
-  for (int i = 0; i < 2; i++) {
-    HIPB(hipMalloc(&m->d_descs_buf[i], sizeof(JpegFrameDesc) * B));
-    HIPB(hipMalloc(&m->d_coef_buf[i], sizeof(int16_t) * m->coef_stride * B));
-    HIPB(hipEventCreateWithFlags(&m->ev_copied[i], hipEventDisableTiming));
-    HIPB(hipEventCreateWithFlags(&m->ev_consumed[i], hipEventDisableTiming));
-  }
-  HIPB(hipMalloc(&m->d_planes, m->plane_stride * B));
-  HIPB(hipMalloc(&m->d_rgb, m->rgb_stride * B));
   m->key_stride = 1;
   while (m->key_stride < (size_t)m->K) m->key_stride <<= 1;
-  HIPB(hipMalloc(&m->d_scores, B * m->K * 2 * sizeof(float)));
-  HIPB(hipMalloc(&m->d_boxes, B * m->K * 4 * sizeof(float)));
-  HIPB(hipMalloc(&m->d_keys, B * m->key_stride * sizeof(unsigned long long)));
-  HIPB(hipMalloc(&m->d_counts, B * sizeof(uint32_t)));
-  HIPB(hipMalloc(&m->d_dets, B * m->K * sizeof(Det)));
-  HIPB(hipMalloc(&m->d_ndet, B * sizeof(uint32_t)));
-  HIPB(hipMalloc(&m->d_spill, B * m->K * sizeof(float4)));
-  HIPB(hipMemset(m->d_dets, 0, B * m->K * sizeof(Det)));
+  // a JPEG is rarely larger than one byte per pixel; bigger frames take the host entropy path
+  m->blob_stride = (((size_t)m->max_w * m->max_h) + 64 + 4095) & ~(size_t)4095;
+  m->iv_cap = (uint32_t)B * 160;
+  m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
+  HIPB(hipMalloc(&m->d_luts, sizeof(HuffLut) * 4 * ufd_model::kMaxLutSets));
+  for (Ctx& c : m->ctx) {
+    HIPB(hipMalloc(&c.d_status, sizeof(uint32_t) * B));
+    HIPB(hipMemset(c.d_status, 0, sizeof(uint32_t) * B));
+    HIPB(hipMalloc(&c.d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
+    HIPB(hipMalloc(&c.d_input, B * 3 * m->W * m->H * sizeof(float)));
+    for (int i = 0; i < 2; i++) {
+      HIPB(hipMalloc(&c.d_descs_buf[i], sizeof(JpegFrameDesc) * B));
+      HIPB(hipMalloc(&c.d_coef_buf[i], sizeof(int16_t) * m->coef_stride * B));
+      HIPB(hipMalloc(&c.d_blob_buf[i], m->blob_stride * B));
+      HIPB(hipMalloc(&c.d_scans_buf[i], sizeof(HuffScan) * B));
+      HIPB(hipMalloc(&c.d_ivs_buf[i], sizeof(HuffInterval) * m->iv_cap));
+      HIPB(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
+      HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
+    }
+    HIPB(hipMalloc(&c.d_planes, m->plane_stride * B));
+    HIPB(hipMalloc(&c.d_rgb, m->rgb_stride * B));
+    HIPB(hipMalloc(&c.d_scores, B * m->K * 2 * sizeof(float)));
+    HIPB(hipMalloc(&c.d_boxes, B * m->K * 4 * sizeof(float)));
+    HIPB(hipMalloc(&c.d_keys, B * m->key_stride * sizeof(unsigned long long)));
+    HIPB(hipMalloc(&c.d_counts, B * sizeof(uint32_t)));
+    HIPB(hipMalloc(&c.d_dets, B * m->K * sizeof(Det)));
+    HIPB(hipMalloc(&c.d_ndet, B * sizeof(uint32_t)));
+    HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
+    HIPB(hipMemset(c.d_dets, 0, B * m->K * sizeof(Det)));
+  }
   HIPB(hipDeviceSynchronize());
 #undef HIPB
   *out = m;
@@ -933,6 +1137,7 @@ int guarded(ufd_model* m, F&& f) {
   std::lock_guard<std::mutex> lk(m->mu);
   try {
     if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
+    m->cur = &m->ctx[0];  // batch submissions switch to the next context themselves
     return f();
   } catch (const std::exception& e) {
     return m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
@@ -989,6 +1194,7 @@ int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h
     rc = upload_rgb(m, rgb, w, h, pitch, count);
     if (rc) return rc;
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
+    s->gpu_entropy = false;
     std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);
     rc = run_rgb_on_device(m, *s, w, h, count);
     if (rc) return rc;
@@ -1011,6 +1217,8 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
     Slot* s = find_free_slot(m);
     if (!s) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
     s->cap = cap, s->out = out, s->n = n, s->status = status;
+    m->cur = &m->ctx[m->next_ctx];  // alternate contexts: consecutive batches overlap on the GPU
+    m->next_ctx = (m->next_ctx + 1) % kNumCtx;
     rc = submit_jpegs(m, *s, jpegs, lens, count);
     if (rc) return rc;
     s->busy = true;
@@ -1079,25 +1287,30 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
     int rc = alloc_slot(m, *s);
     if (rc) return rc;
-    JpegFrameDesc* d = &s->h_descs[0];
-    int st = jpeg_decode_coefficients(jpeg, len, d, s->h_coef, m->coef_stride);
-    if (st == kJpegCorrupt) return m->fail(UFD_E_DECODE, "corrupt JPEG");
-    if (st != kJpegOk) return m->fail(UFD_E_UNSUPPORTED, "unsupported JPEG feature");
-    if ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)
-      return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+    // same stage-1 code as the batch path (device entropy decoding when the stream is eligible)
+    int buf = 0;
+    bool any_ok = false;
+    rc = entropy_stage(m, *s, &jpeg, &len, 1, &buf, &any_ok);
+    if (rc) return rc;
+    if (s->st[0] == UFD_E_DECODE) return m->fail(UFD_E_DECODE, "corrupt JPEG");
+    if (s->st[0] == UFD_E_TOO_LARGE) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+    if (s->st[0] != UFD_OK) return m->fail(UFD_E_UNSUPPORTED, "unsupported JPEG feature");
+    const JpegFrameDesc* d = &s->h_descs[0];
     if (w) *w = d->width;
     if (h) *h = d->height;
     const size_t bytes = (size_t)d->width * d->height * 3;
     if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
-    HIPC(m, hipStreamSynchronize(m->copy_stream));  // tap runs on the main stream with buffer 0
-    HIPC(m, hipStreamSynchronize(m->stream));
-    HIPC(m, hipMemcpyAsync(m->d_descs_buf[0], d, sizeof(*d), hipMemcpyHostToDevice, m->stream));
-    HIPC(m, hipMemcpyAsync(m->d_coef_buf[0], s->h_coef, (size_t)d->coef_total * 2, hipMemcpyHostToDevice, m->stream));
-    launch_idct(m->d_descs_buf[0], m->d_coef_buf[0], m->coef_stride, m->d_planes, m->plane_stride, d->total_blocks, 1, m->stream);
-    launch_upsample_rgb(m->d_descs_buf[0], m->d_planes, m->plane_stride, m->d_rgb, m->rgb_stride, d->width, d->height, 1,
-                        m->stream);
-    HIPC(m, hipMemcpyAsync(rgb, m->d_rgb, bytes, hipMemcpyDeviceToHost, m->stream));
-    HIPC(m, hipStreamSynchronize(m->stream));
+    launch_idct(m->cur->d_descs_buf[buf], m->cur->d_coef_buf[buf], m->coef_stride, m->cur->d_planes, m->plane_stride,
+                d->total_blocks, 1, m->cur->stream);
+    launch_upsample_rgb(m->cur->d_descs_buf[buf], m->cur->d_planes, m->plane_stride, m->cur->d_rgb, m->rgb_stride, d->width,
+                        d->height, 1, m->cur->stream);
+    HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
+    m->cur->consumed_valid[buf] = true;
+    if (s->gpu_entropy)
+      HIPC(m, hipMemcpyAsync(s->h_gpu_status, m->cur->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipMemcpyAsync(rgb, m->cur->d_rgb, bytes, hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    if (s->gpu_entropy && s->h_gpu_status[0]) return m->fail(UFD_E_DECODE, "corrupt JPEG");
     return UFD_OK;
   });
 }
@@ -1108,15 +1321,15 @@ int ufd_debug_preproc_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t
     int rc = upload_rgb(m, rgb, w, h, pitch, 1);
     if (rc) return rc;
     if ((int)w == m->W && (int)h == m->H) {
-      launch_norm_only(m->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->d_input, 1, m->stream);
+      launch_norm_only(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->cur->d_input, 1, m->cur->stream);
     } else {
       ResizeTaps v, hz;
       rc = get_taps(m, w, h, &v, &hz);
       if (rc) return rc;
-      launch_resize_norm(m->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->d_input, m->W, m->H, 1, m->stream);
+      launch_resize_norm(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->cur->d_input, m->W, m->H, 1, m->cur->stream);
     }
-    HIPC(m, hipMemcpyAsync(out_nchw, m->d_input, sizeof(float) * 3 * m->W * m->H, hipMemcpyDeviceToHost, m->stream));
-    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipMemcpyAsync(out_nchw, m->cur->d_input, sizeof(float) * 3 * m->W * m->H, hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
     return UFD_OK;
   });
 }
@@ -1126,12 +1339,12 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
     if (!input_nchw || !scores || !boxes) return m->fail(UFD_E_ARG, "null argument");
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
     const size_t in_floats = (size_t)count * 3 * m->W * m->H;
-    HIPC(m, hipMemcpyAsync(m->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIPC(m, hipMemcpyAsync(m->cur->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, m->cur->stream));
     enqueue_forward(m, count);
     enqueue_heads(m, count);
-    HIPC(m, hipMemcpyAsync(scores, m->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, m->stream));
-    HIPC(m, hipMemcpyAsync(boxes, m->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, m->stream));
-    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipMemcpyAsync(scores, m->cur->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipMemcpyAsync(boxes, m->cur->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
     prof_flush(m);
     return UFD_OK;
   });
@@ -1140,15 +1353,15 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
 int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats, size_t* floats) {
   return guarded(m, [&]() -> int {
     if (!(m->cfg.flags & UFD_FLAG_KEEP_LAYERS)) return m->fail(UFD_E_STATE, "needs UFD_FLAG_KEEP_LAYERS");
-    if (layer >= (uint32_t)kNumConv || frame >= m->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
+    if (layer >= (uint32_t)kNumConv || frame >= m->cur->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
     const Layer& L = m->layers[layer];
     const Tensor& t = m->tensors[L.out_tensor];
     const size_t plane = (size_t)L.oh * L.ow, nf = (size_t)L.spec.cout * plane;
     if (floats) *floats = nf;
     if (!out || cap_floats < nf) return m->fail(UFD_E_ARG, "output buffer too small");
     const float* src = tensor_ptr(m, L.out_tensor) + ((size_t)frame * t.c + L.out_coff) * plane;
-    HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, m->cur->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
     return UFD_OK;
   });
 }
@@ -1164,12 +1377,13 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
     rc = alloc_slot(m, *s);
     if (rc) return rc;
-    HIPC(m, hipMemcpyAsync(m->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, m->stream));
-    HIPC(m, hipMemcpyAsync(m->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, m->stream));
-    HIPC(m, hipMemsetAsync(m->d_counts, 0, sizeof(uint32_t) * count, m->stream));
-    launch_threshold(m->d_scores, m->K, count, m->cfg.min_confidence, m->d_keys, m->key_stride, m->d_counts, m->stream);
+    HIPC(m, hipMemcpyAsync(m->cur->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, m->cur->stream));
+    HIPC(m, hipMemcpyAsync(m->cur->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, m->cur->stream));
+    HIPC(m, hipMemsetAsync(m->cur->d_counts, 0, sizeof(uint32_t) * count, m->cur->stream));
+    launch_threshold(m->cur->d_scores, m->K, count, m->cfg.min_confidence, m->cur->d_keys, m->key_stride, m->cur->d_counts, m->cur->stream);
     enqueue_nms(m, count);
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
+    s->gpu_entropy = false;
     std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);
     rc = enqueue_results_copy(m, *s, count);
     if (rc) return rc;
@@ -1222,7 +1436,7 @@ int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size
 
 int ufd_profile_reset(ufd_model* m) {
   return guarded(m, [&]() -> int {
-    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
     prof_flush(m);
     for (auto& st : m->prof_stats) st.launches = 0, st.total_ms = 0, st.bytes = 0, st.flops = 0;
     return UFD_OK;
@@ -1242,7 +1456,7 @@ int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
 int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n) {
   return guarded(m, [&]() -> int {
     if (!n) return m->fail(UFD_E_ARG, "null argument");
-    HIPC(m, hipStreamSynchronize(m->stream));
+    HIPC(m, hipStreamSynchronize(m->cur->stream));
     prof_flush(m);
     *n = (uint32_t)m->prof_stats.size();
     for (uint32_t i = 0; i < std::min<uint32_t>(cap, *n); i++) stats[i] = m->prof_stats[i];

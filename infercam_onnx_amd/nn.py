@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libufacehip.so")
 UFD_OK = 0
 UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
 UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
-UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE = 1, 2
+UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY = 1, 2, 4
 UFD_MAX_SLOTS = 4
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
@@ -163,7 +163,8 @@ class UltrafaceModel(InferModel):
     """
 
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
-                 weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024):
+                 weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
+                 device_entropy=False):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -178,7 +179,8 @@ class UltrafaceModel(InferModel):
         cfg.device_id, cfg.max_batch = int(device_id), self.max_batch
         cfg.max_src_width, cfg.max_src_height = int(max_src[0]), int(max_src[1])
         cfg.host_threads = int(host_threads)
-        cfg.flags = (UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0)
+        cfg.flags = ((UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0) |
+                     (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()

@@ -185,3 +185,76 @@ def test_async_submit_wait_order(model640, oracle_lib, weights):
     r2, _ = model640.wait(t2)
     r1, _ = model640.wait(t1)
     assert r1 + r2 == sync
+
+
+# ---------------------------------------------------------------- A1 with device entropy decoding
+@pytest.fixture(scope="module")
+def model320_dev(weights):
+    m = make_model(320, weights, max_batch=4, device_entropy=True)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def model640_dev(weights):
+    m = make_model(640, weights, max_batch=8, device_entropy=True)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("size", [(640, 480), (641, 479), (1280, 720), (17, 9)])
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2", "4:4:4"])
+def test_device_entropy_decode_bit_exact(model320_dev, oracle_lib, size, subsampling):
+    """Restart-interval streams take the device Huffman path: same pixels as the oracle and as
+    the host-entropy path for every interval length."""
+    from infercam_onnx_amd import synth
+
+    w, h = size
+    rgb = synth.synth_frame(12, w * 3 + h, w, h)
+    for kw in ({"restart_rows": 1}, {"restart_rows": 2}, {"restart_rows": 1, "quality": 30}, {"restart_rows": 1, "optimize": True}):
+        jpeg = synth.encode_jpeg(rgb, subsampling=subsampling, **kw)
+        assert b"\xff\xdd" in jpeg  # DRI present
+        got = model320_dev.debug_decode_jpeg(jpeg)
+        assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (size, subsampling, kw)
+
+
+def test_device_entropy_end_to_end_matches_host_entropy(model640, model640_dev, oracle_lib, weights):
+    from infercam_onnx_amd import synth
+
+    jpegs = [synth.encode_jpeg(synth.synth_frame(73, i, 640, 480), restart_rows=1) for i in range(6)]
+    host, st_h = model640.infer_jpeg_batch(jpegs)
+    dev, st_d = model640_dev.infer_jpeg_batch(jpegs)
+    assert st_h == st_d == [0] * 6 and host == dev
+    prof = [p["name"] for p in model640_dev.profile_read()] if False else None  # (profiling is per-handle opt-in)
+
+
+def test_device_entropy_corrupt_interval_is_flagged(model640_dev, oracle_lib, weights):
+    model640 = model640_dev
+    from infercam_onnx_amd import nn, synth
+
+    good = synth.encode_jpeg(synth.synth_frame(71, 0, 640, 480), restart_rows=1)
+    sos = good.index(b"\xff\xda")
+    bad = bytearray(good)
+    for i in range(sos + 200, sos + 260):  # garbage inside the first intervals (keep marker structure)
+        if bad[i] != 0xFF and bad[i - 1] != 0xFF:
+            bad[i] = 0x55
+    res, status = model640.infer_jpeg_batch([good, bytes(bad), good])
+    assert status[0] == 0 and status[2] == 0 and res[0] == res[2]
+    # the reference would panic on any libjpeg warning; here the frame is either skipped or decoded
+    assert status[1] in (0, nn.UFD_E_DECODE)
+    pri = synth.gen_priors(640, 480)
+    ref = oracle_lib.infer_jpeg(good, 640, 480, weights, pri, 0.5, 0.5)
+    x = oracle_lib.normalize_nchw(oracle_lib.jpeg_decode_rgb(good))
+    scores, _ = oracle_lib.forward(x, weights, pri)
+    assert_dets_match(dets_array(res[0]), ref, scores=scores)
+
+
+def test_mixed_batch_falls_back_to_host_entropy(model640_dev, oracle_lib):
+    model640 = model640_dev
+    from infercam_onnx_amd import synth
+
+    f = synth.synth_frame(72, 0, 640, 480)
+    a = synth.encode_jpeg(f, restart_rows=1)
+    b = synth.encode_jpeg(f)  # no DRI: not eligible for the device decoder
+    res, status = model640.infer_jpeg_batch([a, b, a])
+    assert status == [0, 0, 0] and res[0] == res[1] == res[2]
