@@ -83,6 +83,36 @@ __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][
   }
 }
 
+// Split-K (SK = 4): the four waves of a block share ONE 128-pixel tile and each takes a quarter of
+// the input channels; partial accumulators of waves 1..3 go through LDS and wave 0 adds them in
+// fixed order (deterministic) before the epilogue.  Used where a launch has too few wave tiles to
+// fill the chip (feature maps <= 30x40), so the serial k-chain per wave is 4x shorter.
+template <int CT>
+__device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red, int wave, int lane) {
+  if (wave > 0) {
+    float* dst = red + (size_t)(wave - 1) * CT * 64 * 64;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((ct * 4 + j) * 16 + r) * 64 + lane] = acc[ct][j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const float* src = red + (size_t)w * CT * 64 * 64;
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[ct][j][r] += src[((ct * 4 + j) * 16 + r) * 64 + lane];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pointwise 1x1:  out[co][p] = act(bias[co] + sum_ci W[co][ci] * in[ci][p])
 //   B operand (k x 32 pixel columns): lane l loads float4 in[ci = 2*ks + (l>>5)][4 pixels of group g]
@@ -91,13 +121,14 @@ __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][
 // The k-loop keeps D k-steps of activations and weights in flight in a register ring (loads are
 // unconditional: dead lanes read a valid dummy address), so a wave does not pay one memory round
 // trip per k-step.  Needs ksteps % D == 0.
-template <int CT, int D>
+template <int CT, int D, int SK>
 __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
+  extern __shared__ float s_dyn[];  // split-K reduction buffer (SK == 4)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
   if (!remap_block(a, &tile, &ctile)) return;
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
-  const long g = ((long)tile * 4 + wave) * 32 + (lane & 31);
+  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * 32 + (lane & 31);
   const bool live = g < (long)a.B * gpf;
   const size_t frame = live ? g / gpf : 0;
   const int pix = live ? (int)(g - (long)frame * gpf) * 4 : 0;
@@ -105,6 +136,15 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
+  const int kper = ksteps / SK, kbeg = (SK == 1) ? 0 : wave * kper, kend = kbeg + kper;
+  if (SK > 1 && wave > 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
+  }
   // wave-uniform base pointer + 32-bit per-lane element offsets (tensors are < 2^32 bytes, checked
   // by the launcher): lets the compiler use scalar-base addressing instead of 64-bit VALU adds
   const float* __restrict__ in = a.in;
@@ -115,18 +155,18 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
   float wq[D][CT];
 #pragma unroll
   for (int d = 0; d < D; d++) {
-    bq[d] = *reinterpret_cast<const float4*>(in + (in_off + d * in_step));
+    bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)(kbeg + d) * in_step));
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + d) * 64];
+    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kbeg + d) * 64];
   }
-  for (int ks = 0; ks < ksteps; ks += D) {
+  for (int ks = kbeg; ks < kend; ks += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const float4 b = bq[d];
       float w[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
-      const int kn = min(ks + D + d, ksteps - 1);  // refill the slot (tail: harmless re-read)
+      const int kn = min(ks + D + d, kend - 1);  // refill the slot (tail: harmless re-read)
       bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)kn * in_step));
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
@@ -138,6 +178,10 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
         acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.w, acc[ct][3], 0, 0, 0);
       }
     }
+  }
+  if (SK > 1) {
+    splitk_reduce<CT>(acc, s_dyn, wave, lane);
+    if (wave > 0) return;
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, pix, hw);
 }
@@ -157,9 +201,9 @@ struct DwWindow {  // raw 3 x (4*S+2) input window of one channel for 4 output p
   float r[3];    // stride 1 only
 };
 
-template <int CT, int S, int D>
+template <int CT, int S, int D, int SK>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
-  extern __shared__ float s_dw[];  // [cin][12]: 9 taps, bias, pad
+  extern __shared__ float s_dw[];  // [cin][12]: 9 taps, bias, pad; then the split-K reduction buffer
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
   if (!remap_block(a, &tile, &ctile)) return;  // whole block, before the barrier
@@ -169,7 +213,7 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
   }
   __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long g = ((long)tile * 4 + wave) * 32 + (lane & 31);
+  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * 32 + (lane & 31);
   const bool live = g < (long)a.B * gpf;
   const size_t frame = live ? g / gpf : 0;
   const int rem = live ? (int)(g - (long)frame * gpf) : 0;
@@ -179,6 +223,15 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
+  const int kper = ksteps / SK, kbeg = (SK == 1) ? 0 : wave * kper, kend = kbeg + kper;
+  if (SK > 1 && wave > 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
+  }
 
   // input window: rows iy0..iy0+2, columns ix0-1 .. ix0+4*S (ix0 = ox*S is a multiple of 4).
   // Loads are unconditional from clamped (always valid) addresses and zeroed by select, and D
@@ -215,11 +268,11 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
   float wq[D][CT];
 #pragma unroll
   for (int d = 0; d < D; d++) {
-    load_window(d, ring[d]);
+    load_window(kbeg + d, ring[d]);
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + d) * 64];
+    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kbeg + d) * 64];
   }
-  for (int ks0 = 0; ks0 < ksteps; ks0 += D) {
+  for (int ks0 = kbeg; ks0 < kend; ks0 += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int ks = ks0 + d;
@@ -227,7 +280,7 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
       float w[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
-      const int kn = min(ks + D, ksteps - 1);  // refill the slot (tail: harmless re-read)
+      const int kn = min(ks + D, kend - 1);  // refill the slot (tail: harmless re-read)
       load_window(kn, ring[d]);
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
@@ -269,6 +322,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
         acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t3, acc[ct][3], 0, 0, 0);
       }
     }
+  }
+  if (SK > 1) {
+    splitk_reduce<CT>(acc, s_dw + a.cin * 12, wave, lane);
+    if (wave > 0) return;
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
 }
@@ -455,39 +512,66 @@ bool dwpw_supported(const ConvArgs& a, int stride) {
 // One 32-cout tile per wave (64 accumulator registers, 3 waves/SIMD) measured faster than two
 // tiles (128 accumulators, 1 wave/SIMD) on every layer of this network at batch 32, so the
 // launchers use CT = 1: activations of wider layers are re-read per cout tile from L2.
+// Split-K when a launch would have fewer wave tiles than ~2 per SIMD.
+static bool want_splitk(long wave_tiles, int cts, int ksteps) {
+  static const int knob = std::getenv("UFD_SPLITK") ? std::atoi(std::getenv("UFD_SPLITK")) : -1;  // tuning knob
+  if (ksteps % 16 != 0) return false;
+  if (knob >= 0) return knob != 0 && wave_tiles * cts < (long)knob;
+  // measured on MI355X at batch 32: pays when the launch has fewer than ~6 waves per k-step of
+  // chain length (15x20 maps, 64->4/8 heads at 30x40, the 256-channel layers); costs otherwise
+  return wave_tiles * cts < 6L * ksteps;
+}
+constexpr size_t kSplitKBytes = 3 * 64 * 64 * sizeof(float);  // CT = 1
+
 void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   const long groups = (long)a.B * (a.oh * a.ow / 4);
-  a.tiles = (int)((groups + 127) / 128);
+  const long wave_tiles = (groups + 31) / 32;
   a.cts = (a.cout + 31) / 32;
+  const int ksteps = a.cin >> 1;
+  if (want_splitk(wave_tiles, a.cts, ksteps)) {
+    a.tiles = (int)wave_tiles;
+    const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid), dim3(256), kSplitKBytes, s, a);
+    return;
+  }
+  a.tiles = (int)((groups + 127) / 128);
   const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
-  if ((a.cin >> 1) % 4 == 0)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4>), dim3(grid), dim3(256), 0, s, a);
+  if (ksteps % 4 == 0)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_pw_mfma<1, 1>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid), dim3(256), 0, s, a);
 }
 
 void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
   ConvArgs a = a0;
   const long groups = (long)a.B * (a.oh * a.ow / 4);
-  a.tiles = (int)((groups + 127) / 128);
+  const long wave_tiles = (groups + 31) / 32;
   a.cts = (a.cout + 31) / 32;
-  const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
+  const int ksteps = a.cin >> 1;
   const size_t lds = (size_t)a.cin * 12 * sizeof(float);
-  const bool deep = (a.cin >> 1) % 4 == 0;
-  static const int knob = std::getenv("UFD_DWD") ? std::atoi(std::getenv("UFD_DWD")) : 2;  // tuning knob
-  if (stride == 1) {
-    if (deep && knob == 4)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 4>), grid, dim3(256), lds, s, a);
-    else if (deep && knob == 2)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2>), grid, dim3(256), lds, s, a);
+  if (want_splitk(wave_tiles, a.cts, ksteps)) {
+    a.tiles = (int)wave_tiles;
+    const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
+    if (stride == 1)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 4>), grid, dim3(256), lds + kSplitKBytes, s, a);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 4>), grid, dim3(256), lds + kSplitKBytes, s, a);
+    return;
+  }
+  a.tiles = (int)((groups + 127) / 128);
+  const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
+  const bool deep = ksteps % 4 == 0;
+  if (stride == 1) {
+    if (deep)
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 1>), grid, dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1, 1>), grid, dim3(256), lds, s, a);
   } else {
     if (deep)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 1>), grid, dim3(256), lds, s, a);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1, 1>), grid, dim3(256), lds, s, a);
   }
 }
 

@@ -184,7 +184,9 @@ def test_async_submit_wait_order(model640, oracle_lib, weights):
     t2 = model640.submit_jpeg_batch(jpegs[4:])
     r2, _ = model640.wait(t2)
     r1, _ = model640.wait(t1)
-    assert r1 + r2 == sync
+    # (kernel selection, e.g. split-K, depends on the batch size: equal within fp32 rounding)
+    for a, b in zip(r1 + r2, sync):
+        assert_dets_match(dets_array(a), dets_array(b), atol=1e-5)
 
 
 # ---------------------------------------------------------------- A1 with device entropy decoding
@@ -224,7 +226,7 @@ def test_device_entropy_end_to_end_matches_host_entropy(model640, model640_dev, 
     jpegs = [synth.encode_jpeg(synth.synth_frame(73, i, 640, 480), restart_rows=1) for i in range(6)]
     host, st_h = model640.infer_jpeg_batch(jpegs)
     dev, st_d = model640_dev.infer_jpeg_batch(jpegs)
-    assert st_h == st_d == [0] * 6 and host == dev
+    assert st_h == st_d == [0] * 6 and host == dev  # same batch size, same kernels: bit-identical
     prof = [p["name"] for p in model640_dev.profile_read()] if False else None  # (profiling is per-handle opt-in)
 
 
