@@ -110,7 +110,7 @@ int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h
  * batches): ufd_submit_jpeg_batch copies/entropy-decodes on host workers and enqueues the GPU
  * work on the handle's stream, returning a ticket; ufd_wait blocks until that batch is done
  * and fills the outputs given at submit.  Input and output buffers must stay valid until then. */
-#define UFD_MAX_SLOTS 4
+#define UFD_MAX_SLOTS 8
 int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
                           ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket);
 int ufd_wait(ufd_model* m, uint32_t ticket);

@@ -264,63 +264,86 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
     }
   };
 
+  // depthwise result of one k-step (4 pixels of channel 2*ks + half), from a loaded window
+  auto dw_compute = [&](const DwWindow<S>& win, int ks, float (&t)[4]) {
+    const float* wd = s_dw + (2 * ks + half) * 12;
+    float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
+      const bool ok = rowok[r];
+      if (S == 1) {
+        float4 m = win.m0[r];
+        m.x = ok ? m.x : 0.f, m.y = ok ? m.y : 0.f, m.z = ok ? m.z : 0.f, m.w = ok ? m.w : 0.f;
+        const float l = (ok && leftok) ? win.l[r] : 0.f;
+        const float rr = (ok && rightok) ? win.r[r] : 0.f;
+        // per pixel, taps in kx order: x-1, x, x+1
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+        t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
+        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+      } else {
+        float4 m0 = win.m0[r], m1 = win.m1[r];
+        m0.x = ok ? m0.x : 0.f, m0.y = ok ? m0.y : 0.f, m0.z = ok ? m0.z : 0.f, m0.w = ok ? m0.w : 0.f;
+        m1.x = ok ? m1.x : 0.f, m1.y = ok ? m1.y : 0.f, m1.z = ok ? m1.z : 0.f, m1.w = ok ? m1.w : 0.f;
+        const float l = (ok && leftok) ? win.l[r] : 0.f;
+        // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
+        t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
+        t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
+        t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
+      }
+    }
+    t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2, 0.f), t[3] = fmaxf(t3, 0.f);
+  };
+
+  // Software pipeline: while the matrix pipe works through the MFMAs of k-step ks, the vector ALU
+  // computes the depthwise result of k-step ks+1 (sched_group_barrier pins "1 MFMA, then a slice
+  // of VALU work" so the in-order wave does not queue four MFMAs back to back and stall behind
+  // them); input windows are prefetched D steps ahead in a register ring.
   DwWindow<S> ring[D];
   float wq[D][CT];
 #pragma unroll
   for (int d = 0; d < D; d++) {
-    load_window(kbeg + d, ring[d]);
+    load_window(min(kbeg + d, kend - 1), ring[d]);
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kbeg + d) * 64];
+    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + min(kbeg + d, kend - 1)) * 64];
   }
+  float tcur[4], wcur[CT];
+  dw_compute(ring[0], kbeg, tcur);
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) wcur[ct] = wq[0][ct];
   for (int ks0 = kbeg; ks0 < kend; ks0 += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int ks = ks0 + d;
-      const DwWindow<S> win = ring[d];
-      float w[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
-      const int kn = min(ks + D, kend - 1);  // refill the slot (tail: harmless re-read)
+      // slot d held step ks (already consumed into tcur): refill it with step ks + D
+      const int kn = min(ks + D, kend - 1);
       load_window(kn, ring[d]);
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
-
-      const float* wd = s_dw + (2 * ks + half) * 12;
-      float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
+      // next step's depthwise values from slot (d+1)%D, beside this step's MFMAs
+      float tnext[4], wnext[CT];
+      const int ksn = min(ks + 1, kend - 1);
+      dw_compute(ring[(d + 1) % D], ksn, tnext);
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
-        const bool ok = rowok[r];
-        if (S == 1) {
-          float4 m = win.m0[r];
-          m.x = ok ? m.x : 0.f, m.y = ok ? m.y : 0.f, m.z = ok ? m.z : 0.f, m.w = ok ? m.w : 0.f;
-          const float l = (ok && leftok) ? win.l[r] : 0.f;
-          const float rr = (ok && rightok) ? win.r[r] : 0.f;
-          // per pixel, taps in kx order: x-1, x, x+1
-          t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
-          t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
-          t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
-          t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
-        } else {
-          float4 m0 = win.m0[r], m1 = win.m1[r];
-          m0.x = ok ? m0.x : 0.f, m0.y = ok ? m0.y : 0.f, m0.z = ok ? m0.z : 0.f, m0.w = ok ? m0.w : 0.f;
-          m1.x = ok ? m1.x : 0.f, m1.y = ok ? m1.y : 0.f, m1.z = ok ? m1.z : 0.f, m1.w = ok ? m1.w : 0.f;
-          const float l = (ok && leftok) ? win.l[r] : 0.f;
-          // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
-          t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
-          t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
-          t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
-          t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
-        }
-      }
-      t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f), t2 = fmaxf(t2, 0.f), t3 = fmaxf(t3, 0.f);
+      for (int ct = 0; ct < CT; ct++) wnext[ct] = wq[(d + 1) % D][ct];
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) {
-        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t0, acc[ct][0], 0, 0, 0);
-        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t1, acc[ct][1], 0, 0, 0);
-        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t2, acc[ct][2], 0, 0, 0);
-        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], t3, acc[ct][3], 0, 0, 0);
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[ct], tcur[0], acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[ct], tcur[1], acc[ct][1], 0, 0, 0);
+        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[ct], tcur[2], acc[ct][2], 0, 0, 0);
+        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[ct], tcur[3], acc[ct][3], 0, 0, 0);
       }
+#pragma unroll
+      for (int i = 0; i < 4 * CT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // then a slice of the VALU work
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) tcur[j] = tnext[j];
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++) wcur[ct] = wnext[ct];
     }
   }
   if (SK > 1) {

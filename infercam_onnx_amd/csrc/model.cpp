@@ -9,6 +9,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +34,13 @@ namespace ufd {
 namespace {
 
 thread_local std::string g_create_error;
+
+struct Ctx;
+// Per-thread view of the handle: API threads use context 0 and the handle's pool; each context's
+// worker thread uses its own context and pool.
+thread_local Ctx* tl_cur = nullptr;
+thread_local ThreadPool* tl_pool = nullptr;
+thread_local bool tl_prof = true;  // record kernel events for the batch being issued by this thread
 
 struct Tensor {
   size_t off = 0;  // float offset in the activation arena (for the whole batch)
@@ -64,8 +75,6 @@ struct ProfEntry {
   double bytes, flops;
 };
 
-struct Ctx;
-
 struct Slot {
   bool busy = false;
   uint32_t ticket = 0, count = 0, cap = 0;
@@ -85,6 +94,24 @@ struct Slot {
   std::vector<int32_t> st;
   hipEvent_t done = nullptr;
   Ctx* ctx = nullptr;  // context whose stream produced this slot's results
+  // asynchronous submission: the context's worker thread issues the batch
+  const uint8_t* const* job_jpegs = nullptr;
+  const size_t* job_lens = nullptr;
+  bool job_prof = true;
+  int issue_rc = 0;          // result of the worker's entropy stage + enqueue
+  std::string issue_err;
+  int state = 0;             // 0 free, 1 queued for the worker, 2 issued to the GPU (guarded by Worker::mu)
+};
+
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Slot*> q;
+  bool stop = false;
+  Ctx* ctx = nullptr;
+  std::unique_ptr<ThreadPool> pool;
+  unsigned host_threads = 1;
 };
 
 // Device-side working set of one in-flight batch.  A handle owns kNumCtx of them and alternates
@@ -116,7 +143,7 @@ struct Ctx {
   float4* d_spill = nullptr;
   uint32_t last_forward_count = 0;
 };
-constexpr int kNumCtx = 2;
+constexpr int kMaxCtx = 4;
 
 constexpr uint32_t kDetCopy = 256;  // detections per frame copied back with the batch
 
@@ -139,10 +166,14 @@ struct ufd_model {
   int W = 0, H = 0, K = 0;
   uint32_t B = 0;
   uint32_t max_w = 0, max_h = 0;
-  Ctx ctx[kNumCtx];
-  Ctx* cur = &ctx[0];  // context of the call in progress (set under the handle lock)
+  Ctx ctx[kMaxCtx];
+  Worker workers[kMaxCtx];
+  int num_ctx = 2;
   int next_ctx = 0;
+  std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
+  std::mutex err_mu;     // error string
   std::unique_ptr<ThreadPool> pool;
+  unsigned host_threads = 1;
 
   // resident model
   float* d_weights = nullptr;
@@ -174,13 +205,13 @@ struct ufd_model {
   // profiling
   bool profile = false;
   uint32_t prof_every = 1, prof_batch = 0;
-  bool prof_active = true;
   std::vector<std::string> prof_names;
   std::vector<ufd_kernel_stat> prof_stats;
   std::vector<ProfEntry> prof_pending;
   std::vector<hipEvent_t> prof_free;
 
   int fail(int code, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(err_mu);
     err = msg;
     return code;
   }
@@ -224,23 +255,28 @@ struct ProfScope {
   bool on;
   hipStream_t st;
   ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
-      : m(mm), on(mm->profile && mm->prof_active), st(stream ? stream : mm->cur->stream) {
+      : m(mm), on(mm->profile && tl_prof), st(stream ? stream : tl_cur->stream) {
     if (!on) return;
-    pe.name_id = prof_name_id(m, name);
+    {
+      std::lock_guard<std::mutex> lk(m->shared_mu);
+      pe.name_id = prof_name_id(m, name);
+      pe.e0 = prof_event(m);
+      pe.e1 = prof_event(m);
+    }
     pe.bytes = bytes;
     pe.flops = flops;
-    pe.e0 = prof_event(m);
-    pe.e1 = prof_event(m);
     (void)hipEventRecord(pe.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(pe.e1, st);
+    std::lock_guard<std::mutex> lk(m->shared_mu);
     m->prof_pending.push_back(pe);
   }
 };
 
 void prof_flush(ufd_model* m) {
+  std::lock_guard<std::mutex> lk(m->shared_mu);
   for (auto& pe : m->prof_pending) {
     float ms = 0;
     if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
@@ -499,6 +535,7 @@ int build_axis_taps(ufd_model* m, int S, int D, TapsDev* out) {
 }
 
 int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
+  std::lock_guard<std::mutex> lk(m->shared_mu);
   auto key = std::make_pair(sw, sh);
   auto it = m->taps.find(key);
   if (it == m->taps.end()) {
@@ -515,14 +552,14 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 }
 
 // ---------------------------------------------------------------- GPU stages
-float* tensor_ptr(ufd_model* m, int t) { return m->cur->d_arena + m->tensors[t].off; }
+float* tensor_ptr(ufd_model* m, int t) { return tl_cur->d_arena + m->tensors[t].off; }
 
 // one conv layer for frames [f0, f0 + count) of the batch
 void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   const Layer& L = m->layers[i];
   if (L.kind == kKindFusedAway && !L.materialize) return;
   auto in_ptr = [&](int t, int ih, int iw) -> const float* {
-    if (t < 0) return m->cur->d_input + (size_t)f0 * 3 * ih * iw;
+    if (t < 0) return tl_cur->d_input + (size_t)f0 * 3 * ih * iw;
     return tensor_ptr(m, t) + (size_t)f0 * m->tensors[t].per_frame();
   };
   ConvArgs a{};
@@ -561,10 +598,10 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
                L.flops_per_frame * count);
   switch (L.kind) {
-    case kKindPointwise: launch_conv_pointwise_mfma(a, m->cur->stream); break;
-    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, m->cur->stream); break;
-    case kKindConv3x3: launch_conv3x3_mfma(a, m->cur->stream); break;
-    default: launch_conv_direct(a, m->cur->stream); break;
+    case kKindPointwise: launch_conv_pointwise_mfma(a, tl_cur->stream); break;
+    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, tl_cur->stream); break;
+    case kKindConv3x3: launch_conv3x3_mfma(a, tl_cur->stream); break;
+    default: launch_conv_direct(a, tl_cur->stream); break;
   }
 }
 
@@ -581,7 +618,7 @@ void enqueue_forward(ufd_model* m, uint32_t count) {
   for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
     for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
   for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
-  m->cur->last_forward_count = count;
+  tl_cur->last_forward_count = count;
 }
 
 void enqueue_heads(ufd_model* m, uint32_t count) {
@@ -597,35 +634,46 @@ void enqueue_heads(ufd_model* m, uint32_t count) {
     base += h.plane[i] * kHeadAnchors[i];
   }
   h.base[4] = base;
-  (void)hipMemsetAsync(m->cur->d_counts, 0, sizeof(uint32_t) * count, m->cur->stream);
+  (void)hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream);
   ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 6 + 4) * 4, 0);
-  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, m->cur->d_scores, m->cur->d_boxes, m->cur->d_keys, m->key_stride,
-                     m->cur->d_counts, m->cur->stream);
+  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, tl_cur->d_scores, tl_cur->d_boxes, tl_cur->d_keys, m->key_stride,
+                     tl_cur->d_counts, tl_cur->stream);
 }
 
 void enqueue_nms(ufd_model* m, uint32_t count) {
   ProfScope ps(m, "sort_nms", 0, 0);
-  launch_sort_nms(m->cur->d_keys, m->key_stride, m->cur->d_counts, m->cur->d_boxes, m->K, m->cfg.max_iou, m->cur->d_dets, m->K, m->cur->d_ndet,
-                  m->cur->d_spill, count, m->cur->stream);
+  launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, tl_cur->d_dets, m->K, tl_cur->d_ndet,
+                  tl_cur->d_spill, count, tl_cur->stream);
 }
 
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
-  HIPC(m, hipMemcpyAsync(s.h_ndet, m->cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->cur->stream));
+  HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
   if (s.gpu_entropy)
-    HIPC(m, hipMemcpyAsync(s.h_gpu_status, m->cur->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, m->cur->stream));
-  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, m->cur->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
-                           hipMemcpyDeviceToHost, m->cur->stream));
-  HIPC(m, hipEventRecord(s.done, m->cur->stream));
-  s.ctx = m->cur;
+    HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
+  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, tl_cur->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
+                           hipMemcpyDeviceToHost, tl_cur->stream));
+  HIPC(m, hipEventRecord(s.done, tl_cur->stream));
+  s.ctx = tl_cur;
   return UFD_OK;
 }
 
 // waits for the slot's batch and hands results to the caller's arrays
 int finish_slot(ufd_model* m, Slot& s) {
+  if (s.issue_rc != UFD_OK) {  // the worker could not issue the batch
+    const int rc = s.issue_rc;
+    m->fail(rc, s.issue_err);
+    s.busy = false;
+    return rc;
+  }
   HIPC(m, hipEventSynchronize(s.done));
   // timing events are resolved lazily (ufd_profile_read): querying ~100 events per batch here
   // would stall the submit/wait pipeline
-  if (m->prof_pending.size() > 16384) prof_flush(m);
+  bool flush = false;
+  {
+    std::lock_guard<std::mutex> lk(m->shared_mu);
+    flush = m->prof_pending.size() > 16384;
+  }
+  if (flush) prof_flush(m);
   int rc = UFD_OK;
   for (uint32_t i = 0; i < s.count; i++) {
     int32_t st = s.st[i];
@@ -669,6 +717,7 @@ int status_from_jpeg(int st) {
 
 // Index of this frame's Huffman table set in d_luts (uploading it first if it is new), or -1.
 int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
+  std::lock_guard<std::mutex> lk(m->shared_mu);
   for (size_t i = 0; i < m->lut_sets.size(); i++)
     if (!std::memcmp(m->lut_sets[i].data(), luts, sizeof(HuffLut) * 4)) return (int)i;
   if ((int)m->lut_sets.size() >= ufd_model::kMaxLutSets) return -1;
@@ -687,10 +736,10 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
 //   host path:   Huffman decoding on host workers, coefficient slabs H2D
 int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, int* buf_out,
                   bool* any_ok_out) {
-  Ctx& c = *m->cur;
+  Ctx& c = *tl_cur;
   bool device_path = m->gpu_entropy_enabled;
   if (device_path) {
-    m->pool->parallel_for(count, [&](unsigned i) {
+    tl_pool->parallel_for(count, [&](unsigned i) {
       JpegFrameDesc* d = &s.h_descs[i];
       int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
       if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
@@ -743,7 +792,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         }
       }
       if (device_path) {
-        m->pool->parallel_for(count, [&](unsigned i) {
+        tl_pool->parallel_for(count, [&](unsigned i) {
           if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
         });
         bool any_ok = false;
@@ -789,7 +838,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   }
   // ---- host entropy decoding
   s.gpu_entropy = false;
-  m->pool->parallel_for(count, [&](unsigned i) {
+  tl_pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_decode_coefficients(jpegs[i], lens[i], d, s.h_coef + (size_t)i * m->coef_stride,
                                                                m->coef_stride)
@@ -827,7 +876,6 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
   int rc = alloc_slot(m, s);
   if (rc) return rc;
   s.count = count;
-  m->prof_active = (m->prof_batch++ % m->prof_every) == 0;
   int buf = 0;
   bool any_ok = false;
   rc = entropy_stage(m, s, jpegs, lens, count, &buf, &any_ok);
@@ -843,38 +891,38 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     if (d.width != m->W || d.height != m->H) all_model_size = false;
   }
   if (any_ok) {
-    JpegFrameDesc* d_descs = m->cur->d_descs_buf[buf];
-    int16_t* d_coef = m->cur->d_coef_buf[buf];
+    JpegFrameDesc* d_descs = tl_cur->d_descs_buf[buf];
+    int16_t* d_coef = tl_cur->d_coef_buf[buf];
     {
       ProfScope ps(m, "idct", 0, 0);
-      launch_idct(d_descs, d_coef, m->coef_stride, m->cur->d_planes, m->plane_stride, max_blocks, count, m->cur->stream);
+      launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, tl_cur->stream);
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
       ProfScope ps(m, "upsample_norm", 0, 0);
-      launch_upsample_norm(d_descs, m->cur->d_planes, m->plane_stride, m->d_lut, m->cur->d_input, m->W, m->H, count, m->cur->stream);
-      HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
-      m->cur->consumed_valid[buf] = true;
+      launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
+      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+      tl_cur->consumed_valid[buf] = true;
     } else {
       {
         ProfScope ps(m, "upsample_rgb", 0, 0);
-        launch_upsample_rgb(d_descs, m->cur->d_planes, m->plane_stride, m->cur->d_rgb, m->rgb_stride, mw, mh, count, m->cur->stream);
+        launch_upsample_rgb(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
       }
-      HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
-      m->cur->consumed_valid[buf] = true;
+      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+      tl_cur->consumed_valid[buf] = true;
       for (uint32_t i = 0; i < count; i++) {
         if (s.st[i] != UFD_OK) continue;
         const JpegFrameDesc& d = s.h_descs[i];
-        float* dst = m->cur->d_input + (size_t)i * 3 * m->W * m->H;
-        const uint8_t* src = m->cur->d_rgb + (size_t)i * m->rgb_stride;
+        float* dst = tl_cur->d_input + (size_t)i * 3 * m->W * m->H;
+        const uint8_t* src = tl_cur->d_rgb + (size_t)i * m->rgb_stride;
         ProfScope ps(m, "resize_norm", 0, 0);
         if (d.width == m->W && d.height == m->H) {
-          launch_norm_only(src, d.width, d.height, d.width * 3, 0, m->d_lut, dst, 1, m->cur->stream);
+          launch_norm_only(src, d.width, d.height, d.width * 3, 0, m->d_lut, dst, 1, tl_cur->stream);
         } else {
           ResizeTaps v, h;
           rc = get_taps(m, d.width, d.height, &v, &h);
           if (rc) return rc;
-          launch_resize_norm(src, d.width, d.height, d.width * 3, 0, v, h, m->d_lut, dst, m->W, m->H, 1, m->cur->stream);
+          launch_resize_norm(src, d.width, d.height, d.width * 3, 0, v, h, m->d_lut, dst, m->W, m->H, 1, tl_cur->stream);
         }
       }
     }
@@ -890,12 +938,12 @@ int run_rgb_on_device(ufd_model* m, Slot& s, uint32_t w, uint32_t h, uint32_t co
   {
     ProfScope ps(m, "resize_norm", 0, 0);
     if ((int)w == m->W && (int)h == m->H) {
-      launch_norm_only(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->cur->d_input, count, m->cur->stream);
+      launch_norm_only(tl_cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, tl_cur->d_input, count, tl_cur->stream);
     } else {
       ResizeTaps v, hz;
       int rc = get_taps(m, w, h, &v, &hz);
       if (rc) return rc;
-      launch_resize_norm(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->cur->d_input, m->W, m->H, count, m->cur->stream);
+      launch_resize_norm(tl_cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
     }
   }
   enqueue_forward(m, count);
@@ -909,9 +957,62 @@ int upload_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_
   if (w > m->max_w || h > m->max_h) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
   if (count > m->B) return m->fail(UFD_E_TOO_LARGE, "batch larger than max_batch");
   for (uint32_t i = 0; i < count; i++)
-    HIPC(m, hipMemcpy2DAsync(m->cur->d_rgb + (size_t)i * m->rgb_stride, (size_t)w * 3, rgb + (size_t)i * h * pitch, pitch,
-                             (size_t)w * 3, h, hipMemcpyHostToDevice, m->cur->stream));
+    HIPC(m, hipMemcpy2DAsync(tl_cur->d_rgb + (size_t)i * m->rgb_stride, (size_t)w * 3, rgb + (size_t)i * h * pitch, pitch,
+                             (size_t)w * 3, h, hipMemcpyHostToDevice, tl_cur->stream));
   return UFD_OK;
+}
+
+// Worker of one context: issues queued batches (host entropy stage + every GPU enqueue) so that
+// the caller's submit returns at once and the host work of consecutive batches runs in parallel
+// on the two contexts.
+void worker_main(ufd_model* m, Worker* w) {
+  (void)hipSetDevice(m->cfg.device_id);
+  tl_cur = w->ctx;
+  tl_pool = w->pool.get();
+  for (;;) {
+    Slot* s = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); });
+      if (w->q.empty()) return;  // stop requested and nothing left to issue
+      s = w->q.front();
+    }
+    tl_prof = s->job_prof;
+    int rc = UFD_OK;
+    try {
+      rc = submit_jpegs(m, *s, s->job_jpegs, s->job_lens, s->count);
+    } catch (const std::exception& e) {
+      rc = m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
+    } catch (...) {
+      rc = m->fail(UFD_E_DEVICE, "unknown exception");
+    }
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      s->issue_rc = rc;
+      if (rc != UFD_OK) {
+        std::lock_guard<std::mutex> lk2(m->err_mu);
+        s->issue_err = m->err;
+      }
+      s->state = 2;
+      w->q.pop_front();
+    }
+    w->cv.notify_all();
+  }
+}
+
+// Blocks until the worker has issued the slot's batch (state 2).
+void wait_issued(ufd_model* m, Slot& s) {
+  Worker& w = m->workers[s.ctx - m->ctx];
+  std::unique_lock<std::mutex> lk(w.mu);
+  w.cv.wait(lk, [&] { return s.state != 1; });
+}
+
+// Synchronous entry points run on context 0 from the calling thread: wait until its worker has
+// nothing queued (stream order then protects the context's buffers).
+void drain_worker0(ufd_model* m) {
+  Worker& w = m->workers[0];
+  std::unique_lock<std::mutex> lk(w.mu);
+  w.cv.wait(lk, [&] { return w.q.empty(); });
 }
 
 std::string default_weights_path(int variant) {
@@ -929,6 +1030,15 @@ std::string default_weights_path(int variant) {
 
 void destroy(ufd_model* m) {
   if (!m) return;
+  for (Worker& w : m->workers) {
+    if (!w.th.joinable()) continue;
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.stop = true;
+    }
+    w.cv.notify_all();
+    w.th.join();
+  }
   for (Ctx& c : m->ctx) {
     if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
     if (c.stream) (void)hipStreamSynchronize(c.stream);
@@ -1009,7 +1119,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->max_h = std::max<uint32_t>(m->max_h, m->H);
   m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
   unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-  m->pool.reset(new ThreadPool(threads));
+  m->pool.reset(new ThreadPool(std::min(threads, 8u)));  // synchronous entry points and taps
+  m->host_threads = threads;
 #define HIPB(expr)                                                                      \
   do {                                                                                  \
     hipError_t e_ = (expr);                                                             \
@@ -1027,7 +1138,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
-  for (Ctx& c : m->ctx) {
+  if (const char* e = std::getenv("UFD_CTX")) m->num_ctx = std::max(1, std::min(kMaxCtx, std::atoi(e)));  // tuning knob
+  for (int ci = 0; ci < m->num_ctx; ci++) {
+    Ctx& c = m->ctx[ci];
     HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
   }
@@ -1100,7 +1213,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->iv_cap = (uint32_t)B * 160;
   m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
   HIPB(hipMalloc(&m->d_luts, sizeof(HuffLut) * 4 * ufd_model::kMaxLutSets));
-  for (Ctx& c : m->ctx) {
+  for (int ci = 0; ci < m->num_ctx; ci++) {
+    Ctx& c = m->ctx[ci];
     HIPB(hipMalloc(&c.d_status, sizeof(uint32_t) * B));
     HIPB(hipMemset(c.d_status, 0, sizeof(uint32_t) * B));
     HIPB(hipMalloc(&c.d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
@@ -1127,6 +1241,12 @@ int create(const ufd_config* cfg, ufd_model** out) {
   }
   HIPB(hipDeviceSynchronize());
 #undef HIPB
+  for (int ci = 0; ci < m->num_ctx; ci++) {
+    Worker& w = m->workers[ci];
+    w.ctx = &m->ctx[ci];
+    w.pool.reset(new ThreadPool(std::max(1u, m->host_threads / (unsigned)m->num_ctx)));
+    w.th = std::thread(worker_main, m, &w);
+  }
   *out = m;
   return UFD_OK;
 }
@@ -1137,7 +1257,9 @@ int guarded(ufd_model* m, F&& f) {
   std::lock_guard<std::mutex> lk(m->mu);
   try {
     if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
-    m->cur = &m->ctx[0];  // batch submissions switch to the next context themselves
+    tl_cur = &m->ctx[0];  // synchronous calls and taps run on context 0 from the calling thread
+    tl_pool = m->pool.get();
+    tl_prof = true;
     return f();
   } catch (const std::exception& e) {
     return m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
@@ -1184,6 +1306,7 @@ int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32
 int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t count,
                         ufd_det* out, uint32_t cap, uint32_t* n) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     int rc = check_outputs(m, out, cap, n);
     if (rc) return rc;
     if (!count) return UFD_OK;
@@ -1216,25 +1339,52 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
     Slot* s = find_free_slot(m);
     if (!s) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
-    s->cap = cap, s->out = out, s->n = n, s->status = status;
-    m->cur = &m->ctx[m->next_ctx];  // alternate contexts: consecutive batches overlap on the GPU
-    m->next_ctx = (m->next_ctx + 1) % kNumCtx;
-    rc = submit_jpegs(m, *s, jpegs, lens, count);
+    rc = alloc_slot(m, *s);
     if (rc) return rc;
+    // alternate contexts: consecutive batches overlap on the GPU, and their host stages run in
+    // parallel on the contexts' worker threads
+    Worker& w = m->workers[m->next_ctx];
+    m->next_ctx = (m->next_ctx + 1) % m->num_ctx;
+    s->cap = cap, s->out = out, s->n = n, s->status = status;
+    s->count = count;
+    s->job_jpegs = jpegs, s->job_lens = lens;
+    s->job_prof = (m->prof_batch++ % m->prof_every) == 0;
+    s->issue_rc = UFD_OK;
+    s->ctx = w.ctx;
     s->busy = true;
     s->ticket = m->next_ticket++;
     if (!m->next_ticket) m->next_ticket = 1;
     *ticket = s->ticket;
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      s->state = 1;
+      w.q.push_back(s);
+    }
+    w.cv.notify_all();
     return UFD_OK;
   });
 }
 
 int ufd_wait(ufd_model* m, uint32_t ticket) {
-  return guarded(m, [&]() -> int {
-    for (auto& s : m->slots)
-      if (s.busy && s.ticket == ticket) return finish_slot(m, s);
-    return m->fail(UFD_E_STATE, "unknown ticket");
-  });
+  if (!m) return UFD_E_ARG;
+  Slot* s = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (auto& c : m->slots)
+      if (c.busy && c.ticket == ticket) s = &c;
+    if (!s) return m->fail(UFD_E_STATE, "unknown ticket");
+  }
+  // not holding the handle lock while the worker and the GPU finish: other threads may submit
+  wait_issued(m, *s);
+  try {
+    if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
+    if (s->issue_rc == UFD_OK && hipEventSynchronize(s->done) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipEventSynchronize failed");
+    std::lock_guard<std::mutex> lk(m->mu);
+    tl_cur = s->ctx;
+    return finish_slot(m, *s);
+  } catch (...) {
+    return m->fail(UFD_E_DEVICE, "unknown exception");
+  }
 }
 
 int ufd_infer_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
@@ -1282,6 +1432,7 @@ int ufd_infer_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, ufd_det* out, 
 int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes, uint32_t* w,
                           uint32_t* h) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     if (!jpeg || !len || !rgb) return m->fail(UFD_E_ARG, "null argument");
     Slot* s = find_free_slot(m);
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
@@ -1300,16 +1451,16 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
     if (h) *h = d->height;
     const size_t bytes = (size_t)d->width * d->height * 3;
     if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
-    launch_idct(m->cur->d_descs_buf[buf], m->cur->d_coef_buf[buf], m->coef_stride, m->cur->d_planes, m->plane_stride,
-                d->total_blocks, 1, m->cur->stream);
-    launch_upsample_rgb(m->cur->d_descs_buf[buf], m->cur->d_planes, m->plane_stride, m->cur->d_rgb, m->rgb_stride, d->width,
-                        d->height, 1, m->cur->stream);
-    HIPC(m, hipEventRecord(m->cur->ev_consumed[buf], m->cur->stream));
-    m->cur->consumed_valid[buf] = true;
+    launch_idct(tl_cur->d_descs_buf[buf], tl_cur->d_coef_buf[buf], m->coef_stride, tl_cur->d_planes, m->plane_stride,
+                d->total_blocks, 1, tl_cur->stream);
+    launch_upsample_rgb(tl_cur->d_descs_buf[buf], tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, d->width,
+                        d->height, 1, tl_cur->stream);
+    HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+    tl_cur->consumed_valid[buf] = true;
     if (s->gpu_entropy)
-      HIPC(m, hipMemcpyAsync(s->h_gpu_status, m->cur->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipMemcpyAsync(rgb, m->cur->d_rgb, bytes, hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+      HIPC(m, hipMemcpyAsync(s->h_gpu_status, tl_cur->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipMemcpyAsync(rgb, tl_cur->d_rgb, bytes, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     if (s->gpu_entropy && s->h_gpu_status[0]) return m->fail(UFD_E_DECODE, "corrupt JPEG");
     return UFD_OK;
   });
@@ -1317,34 +1468,36 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
 
 int ufd_debug_preproc_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, float* out_nchw) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     if (!out_nchw) return m->fail(UFD_E_ARG, "null argument");
     int rc = upload_rgb(m, rgb, w, h, pitch, 1);
     if (rc) return rc;
     if ((int)w == m->W && (int)h == m->H) {
-      launch_norm_only(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, m->cur->d_input, 1, m->cur->stream);
+      launch_norm_only(tl_cur->d_rgb, w, h, w * 3, m->rgb_stride, m->d_lut, tl_cur->d_input, 1, tl_cur->stream);
     } else {
       ResizeTaps v, hz;
       rc = get_taps(m, w, h, &v, &hz);
       if (rc) return rc;
-      launch_resize_norm(m->cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, m->cur->d_input, m->W, m->H, 1, m->cur->stream);
+      launch_resize_norm(tl_cur->d_rgb, w, h, w * 3, m->rgb_stride, v, hz, m->d_lut, tl_cur->d_input, m->W, m->H, 1, tl_cur->stream);
     }
-    HIPC(m, hipMemcpyAsync(out_nchw, m->cur->d_input, sizeof(float) * 3 * m->W * m->H, hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    HIPC(m, hipMemcpyAsync(out_nchw, tl_cur->d_input, sizeof(float) * 3 * m->W * m->H, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     return UFD_OK;
   });
 }
 
 int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, float* scores, float* boxes) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     if (!input_nchw || !scores || !boxes) return m->fail(UFD_E_ARG, "null argument");
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
     const size_t in_floats = (size_t)count * 3 * m->W * m->H;
-    HIPC(m, hipMemcpyAsync(m->cur->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, m->cur->stream));
+    HIPC(m, hipMemcpyAsync(tl_cur->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, tl_cur->stream));
     enqueue_forward(m, count);
     enqueue_heads(m, count);
-    HIPC(m, hipMemcpyAsync(scores, m->cur->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipMemcpyAsync(boxes, m->cur->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    HIPC(m, hipMemcpyAsync(scores, tl_cur->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipMemcpyAsync(boxes, tl_cur->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     prof_flush(m);
     return UFD_OK;
   });
@@ -1352,16 +1505,17 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
 
 int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats, size_t* floats) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     if (!(m->cfg.flags & UFD_FLAG_KEEP_LAYERS)) return m->fail(UFD_E_STATE, "needs UFD_FLAG_KEEP_LAYERS");
-    if (layer >= (uint32_t)kNumConv || frame >= m->cur->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
+    if (layer >= (uint32_t)kNumConv || frame >= tl_cur->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
     const Layer& L = m->layers[layer];
     const Tensor& t = m->tensors[L.out_tensor];
     const size_t plane = (size_t)L.oh * L.ow, nf = (size_t)L.spec.cout * plane;
     if (floats) *floats = nf;
     if (!out || cap_floats < nf) return m->fail(UFD_E_ARG, "output buffer too small");
     const float* src = tensor_ptr(m, L.out_tensor) + ((size_t)frame * t.c + L.out_coff) * plane;
-    HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, m->cur->stream));
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     return UFD_OK;
   });
 }
@@ -1369,6 +1523,7 @@ int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* 
 int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, uint32_t count, ufd_det* out, uint32_t cap,
                        uint32_t* n) {
   return guarded(m, [&]() -> int {
+    drain_worker0(m);
     int rc = check_outputs(m, out, cap, n);
     if (rc) return rc;
     if (!scores || !boxes) return m->fail(UFD_E_ARG, "null argument");
@@ -1377,10 +1532,10 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
     rc = alloc_slot(m, *s);
     if (rc) return rc;
-    HIPC(m, hipMemcpyAsync(m->cur->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, m->cur->stream));
-    HIPC(m, hipMemcpyAsync(m->cur->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, m->cur->stream));
-    HIPC(m, hipMemsetAsync(m->cur->d_counts, 0, sizeof(uint32_t) * count, m->cur->stream));
-    launch_threshold(m->cur->d_scores, m->K, count, m->cfg.min_confidence, m->cur->d_keys, m->key_stride, m->cur->d_counts, m->cur->stream);
+    HIPC(m, hipMemcpyAsync(tl_cur->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, tl_cur->stream));
+    HIPC(m, hipMemcpyAsync(tl_cur->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, tl_cur->stream));
+    HIPC(m, hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream));
+    launch_threshold(tl_cur->d_scores, m->K, count, m->cfg.min_confidence, tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->stream);
     enqueue_nms(m, count);
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
     s->gpu_entropy = false;
@@ -1436,7 +1591,7 @@ int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size
 
 int ufd_profile_reset(ufd_model* m) {
   return guarded(m, [&]() -> int {
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     prof_flush(m);
     for (auto& st : m->prof_stats) st.launches = 0, st.total_ms = 0, st.bytes = 0, st.flops = 0;
     return UFD_OK;
@@ -1448,7 +1603,6 @@ int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
     if (!every_n) return m->fail(UFD_E_ARG, "every_n must be >= 1");
     m->prof_every = every_n;
     m->prof_batch = 0;
-    m->prof_active = true;
     return UFD_OK;
   });
 }
@@ -1456,7 +1610,7 @@ int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
 int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n) {
   return guarded(m, [&]() -> int {
     if (!n) return m->fail(UFD_E_ARG, "null argument");
-    HIPC(m, hipStreamSynchronize(m->cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
     prof_flush(m);
     *n = (uint32_t)m->prof_stats.size();
     for (uint32_t i = 0; i < std::min<uint32_t>(cap, *n); i++) stats[i] = m->prof_stats[i];

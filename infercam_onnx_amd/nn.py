@@ -19,7 +19,7 @@ UFD_OK = 0
 UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
 UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY = 1, 2, 4
-UFD_MAX_SLOTS = 4
+UFD_MAX_SLOTS = 8
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
                  -5: "UFD_E_DEVICE", -6: "UFD_E_WEIGHTS", -7: "UFD_E_STATE", -8: "UFD_E_TOO_LARGE"}
