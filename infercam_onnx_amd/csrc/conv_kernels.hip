@@ -106,9 +106,11 @@ __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red
 #pragma unroll
       for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 4; j++) {
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[ct][j][r] += src[((ct * 4 + j) * 16 + r) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later slices from being hoisted (register pressure)
+        }
     }
   }
 }
@@ -191,34 +193,54 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
 // Lane l owns 4 consecutive output pixels (oy, ox..ox+3) and, per k-step, input channel
 // ci = 2*ks + (l>>5): it computes the depthwise result of that channel for its 4 pixels from a
 // 3 x (4*S+2) input window (aligned float4 row segments + edge scalars) and feeds it directly as
-// the B operand.  Needs ow % 4 == 0 and iw % 4 == 0.  a.w2/a.bias2 = depthwise weights [cin][9]
-// and bias [cin]; a.w/a.bias = packed pointwise weights and bias.
+// the B operand.  Needs ow % 4 == 0 and iw % 4 == 0.  a.w2 = depthwise weights packed [cin][12]
+// (9 taps, bias, pad; pack_depthwise_weights); a.w/a.bias = packed pointwise weights and bias.
 template <int S>
-struct DwWindow {  // raw 3 x (4*S+2) input window of one channel for 4 output pixels
+struct DwWindow {  // raw 3 x 4*S input window of one channel for 4 output pixels
   float4 m0[3];
   float4 m1[3];  // stride 2 only
-  float l[3];
-  float r[3];    // stride 1 only
 };
+
+// Each 32-lane half of the wave holds 32 consecutive pixel groups of which the first and the last
+// are halo providers only: tiles advance by kDwGroups = 30 groups and overlap by two, so the
+// column left / right of a lane's group always comes from the neighbouring lane by shuffle and the
+// kernel issues exactly three 16-byte loads per k-step (stride 1) -- measured on MI355X, the
+// per-lane scalar gathers for the halo columns cost more than all arithmetic of this kernel.
+constexpr int kDwGroups = 30;
 
 template <int CT, int S, int D, int SK>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
-  extern __shared__ float s_dw[];  // [cin][12]: 9 taps, bias, pad; then the split-K reduction buffer
+  // LDS: depthwise weights [cin][12] | pointwise weights of this cout tile [ksteps][64] | split-K buffer
+  extern __shared__ float s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
   if (!remap_block(a, &tile, &ctile)) return;  // whole block, before the barrier
-  for (int i = threadIdx.x; i < a.cin * 12; i += 256) {
-    const int c = i / 12, t = i - c * 12;
-    s_dw[i] = t < 9 ? a.w2[c * 9 + t] : (t == 9 ? a.bias2[c] : 0.0f);
+  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
+  float* s_dw = s_mem;
+  float* s_w = s_mem + a.cin * 12;
+  float* s_red = s_w + CT * ksteps * 64;
+  {  // straight 16-byte copies, all in flight at once (a.w2 is pre-packed [cin][12])
+    const float4* src = reinterpret_cast<const float4*>(a.w2);
+    float4* dst = reinterpret_cast<float4*>(s_dw);
+    const int n4 = a.cin * 3;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
+    float4* wdst = reinterpret_cast<float4*>(s_w);
+    const int w4 = CT * ksteps * 16;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < w4; i += 256) wdst[i] = wsrc[i];
   }
   __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * 32 + (lane & 31);
-  const bool live = g < (long)a.B * gpf;
-  const size_t frame = live ? g / gpf : 0;
-  const int rem = live ? (int)(g - (long)frame * gpf) : 0;
+  const int j32 = lane & 31;
+  const long total = (long)a.B * gpf;
+  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * kDwGroups + j32 - 1;
+  const bool inrange = g >= 0 && g < total;
+  const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;  // lanes that own an output group
+  const size_t frame = inrange ? g / gpf : 0;
+  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
-  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
   const int ihw = a.ih * a.iw;
 
   floatx16 acc[CT][4];
@@ -233,9 +255,9 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
         for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
   }
 
-  // input window: rows iy0..iy0+2, columns ix0-1 .. ix0+4*S (ix0 = ox*S is a multiple of 4).
-  // Loads are unconditional from clamped (always valid) addresses and zeroed by select, and D
-  // k-steps of windows are kept in flight in a register ring.
+  // input window: rows iy0..iy0+2, columns ix0 .. ix0+4*S-1 (ix0 = ox*S, a multiple of 4).
+  // Loads are unconditional from clamped (always valid) addresses and zeroed by select; D k-steps
+  // of windows are kept in flight in a register ring.
   const int iy0 = oy * S - 1, ix0 = ox * S;
   bool rowok[3];
   uint32_t rowoff[3];  // 32-bit element offsets from the wave-uniform base a.in (< 2^32 bytes, launcher-checked)
@@ -245,11 +267,9 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
     rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
     rowoff[r] = lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0);
   }
-  const bool leftok = ix0 > 0;
+  const bool leftok = ix0 > 0;                        // else: image border, the tap is zero padding
   const bool rightok = (S == 1) && (ix0 + 4 < a.iw);  // stride 2 never needs column ix0+8
-  const uint32_t loff = leftok ? 0xffffffffu : 0u, roff = rightok ? 4u : 0u;  // -1 / +4 elements
   const float* __restrict__ in = a.in;
-  const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
   const uint32_t chan_step = 2u * (uint32_t)ihw;
 
   auto load_window = [&](int ks, DwWindow<S>& win) {
@@ -259,8 +279,6 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
       const uint32_t o = rowoff[r] + c;
       win.m0[r] = *reinterpret_cast<const float4*>(in + o);
       if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(in + (o + 4u));
-      win.l[r] = in[o + loff];
-      if (S == 1) win.r[r] = in[o + roff];
     }
   };
 
@@ -274,9 +292,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
       const bool ok = rowok[r];
       if (S == 1) {
         float4 m = win.m0[r];
+        const float from_prev = __shfl_up(m.w, 1), from_next = __shfl_down(m.x, 1);
         m.x = ok ? m.x : 0.f, m.y = ok ? m.y : 0.f, m.z = ok ? m.z : 0.f, m.w = ok ? m.w : 0.f;
-        const float l = (ok && leftok) ? win.l[r] : 0.f;
-        const float rr = (ok && rightok) ? win.r[r] : 0.f;
+        const float l = (ok && leftok) ? from_prev : 0.f;
+        const float rr = (ok && rightok) ? from_next : 0.f;
         // per pixel, taps in kx order: x-1, x, x+1
         t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
         t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
@@ -284,9 +303,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
         t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
       } else {
         float4 m0 = win.m0[r], m1 = win.m1[r];
+        const float from_prev = __shfl_up(m1.w, 1);
         m0.x = ok ? m0.x : 0.f, m0.y = ok ? m0.y : 0.f, m0.z = ok ? m0.z : 0.f, m0.w = ok ? m0.w : 0.f;
         m1.x = ok ? m1.x : 0.f, m1.y = ok ? m1.y : 0.f, m1.z = ok ? m1.z : 0.f, m1.w = ok ? m1.w : 0.f;
-        const float l = (ok && leftok) ? win.l[r] : 0.f;
+        const float l = (ok && leftok) ? from_prev : 0.f;
         // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
         t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
         t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
@@ -299,35 +319,24 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
 
   // Software pipeline: while the matrix pipe works through the MFMAs of k-step ks, the vector ALU
   // computes the depthwise result of k-step ks+1 (sched_group_barrier pins "1 MFMA, then a slice
-  // of VALU work" so the in-order wave does not queue four MFMAs back to back and stall behind
-  // them); input windows are prefetched D steps ahead in a register ring.
+  // of VALU work"); input windows are prefetched D steps ahead in a register ring.
   DwWindow<S> ring[D];
-  float wq[D][CT];
 #pragma unroll
-  for (int d = 0; d < D; d++) {
-    load_window(min(kbeg + d, kend - 1), ring[d]);
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + min(kbeg + d, kend - 1)) * 64];
-  }
-  float tcur[4], wcur[CT];
+  for (int d = 0; d < D; d++) load_window(min(kbeg + d, kend - 1), ring[d]);
+  float tcur[4];
   dw_compute(ring[0], kbeg, tcur);
-#pragma unroll
-  for (int ct = 0; ct < CT; ct++) wcur[ct] = wq[0][ct];
   for (int ks0 = kbeg; ks0 < kend; ks0 += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int ks = ks0 + d;
       // slot d held step ks (already consumed into tcur): refill it with step ks + D
-      const int kn = min(ks + D, kend - 1);
-      load_window(kn, ring[d]);
+      load_window(min(ks + D, kend - 1), ring[d]);
+      float wcur[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
+      for (int ct = 0; ct < CT; ct++) wcur[ct] = s_w[(ct * ksteps + ks) * 64 + lane];
       // next step's depthwise values from slot (d+1)%D, beside this step's MFMAs
-      float tnext[4], wnext[CT];
-      const int ksn = min(ks + 1, kend - 1);
-      dw_compute(ring[(d + 1) % D], ksn, tnext);
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) wnext[ct] = wq[(d + 1) % D][ct];
+      float tnext[4];
+      dw_compute(ring[(d + 1) % D], min(ks + 1, kend - 1), tnext);
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) {
         acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[ct], tcur[0], acc[ct][0], 0, 0, 0);
@@ -342,12 +351,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) tcur[j] = tnext[j];
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) wcur[ct] = wnext[ct];
     }
   }
   if (SK > 1) {
-    splitk_reduce<CT>(acc, s_dw + a.cin * 12, wave, lane);
+    splitk_reduce<CT>(acc, s_red, wave, lane);
     if (wave > 0) return;
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
@@ -516,6 +523,16 @@ void pack_pointwise_weights(const float* w, int cin, int cout, float* packed) {
       }
 }
 
+size_t depthwise_packed_floats(int c) { return (size_t)c * 12; }
+
+void pack_depthwise_weights(const float* w, const float* bias, int c, float* packed) {
+  for (int i = 0; i < c; i++) {
+    for (int t = 0; t < 9; t++) packed[i * 12 + t] = w[i * 9 + t];
+    packed[i * 12 + 9] = bias[i];
+    packed[i * 12 + 10] = packed[i * 12 + 11] = 0.0f;
+  }
+}
+
 size_t conv3x3_packed_floats(int cin) { return (size_t)cin * 3 * 64; }
 
 void pack_conv3x3_weights(const float* w, int cin, int cout, float* packed) {
@@ -569,10 +586,10 @@ void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
 void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
   ConvArgs a = a0;
   const long groups = (long)a.B * (a.oh * a.ow / 4);
-  const long wave_tiles = (groups + 31) / 32;
+  const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
   a.cts = (a.cout + 31) / 32;
   const int ksteps = a.cin >> 1;
-  const size_t lds = (size_t)a.cin * 12 * sizeof(float);
+  const size_t lds = ((size_t)a.cin * 12 + (size_t)ksteps * 64) * sizeof(float);
   if (want_splitk(wave_tiles, a.cts, ksteps)) {
     a.tiles = (int)wave_tiles;
     const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
@@ -582,7 +599,7 @@ void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
       hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 4>), grid, dim3(256), lds + kSplitKBytes, s, a);
     return;
   }
-  a.tiles = (int)((groups + 127) / 128);
+  a.tiles = (int)((wave_tiles + 3) / 4);
   const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
   const bool deep = ksteps % 4 == 0;
   if (stride == 1) {

@@ -51,11 +51,12 @@ struct ConvArgs {
   const float* bias;  // [cout]
   float* out;         // [B][out_ctotal][oh][ow], written at channel offset out_coff
   const float* res;   // optional residual [B][cout][oh][ow]: out = relu(conv + res)
-  const float* w2;    // fused dw->pw kernel: depthwise weights [cin][9]
-  const float* bias2; // fused dw->pw kernel: depthwise bias [cin]
+  const float* w2;    // fused dw->pw kernel: depthwise weights packed [cin][12] (taps, bias, pad)
+  const float* bias2; // unused by the fused kernel (bias is inside w2)
   int32_t B, cin, cout, ih, iw, oh, ow;
   int32_t k, stride, pad, dil, depthwise, relu;
   int32_t in_ctotal, out_ctotal, out_coff;
+  int32_t dbg;         // ablation switches (UFD_CONV_DBG), timing experiments only
   int32_t tiles, cts;  // MFMA kernels: pixel tiles (blocks) and 32-cout tiles, set by the launcher
 };
 // Reference-order direct convolution (any layer).  w: [cout][cin/g][k][k].
@@ -69,6 +70,8 @@ void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, f
 // in/ih/iw/cin = depthwise input, oh/ow/cout = pointwise output, w/bias = packed pointwise
 // weights, w2/bias2 = depthwise weights; relu applies to the pointwise output.
 bool dwpw_supported(const ConvArgs& a, int stride);
+size_t depthwise_packed_floats(int c);
+void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c, float* packed /*[c][12]*/);
 void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s);
 // Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
 void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s);

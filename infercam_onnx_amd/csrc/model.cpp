@@ -65,6 +65,7 @@ struct Layer {
   int fused_dw = -1;       // kKindDwPw: index of the depthwise layer
   bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
   const float* d_w = nullptr;  // kernel-specific packing
+  const float* d_w_dwpack = nullptr;  // depthwise layers: [c][12] image for the fused dw->pw kernel
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
 };
@@ -441,7 +442,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
 int upload_weights(ufd_model* m, const float* blob) {
   const ConvSpec* specs = conv_specs();
   std::vector<float> img;
-  std::vector<size_t> w_off(kNumConv), b_off(kNumConv);
+  std::vector<size_t> w_off(kNumConv), b_off(kNumConv), dw_off(kNumConv, (size_t)-1);
   const float* p = blob;
   for (int i = 0; i < kNumConv; i++) {
     const ConvSpec& s = specs[i];
@@ -464,6 +465,12 @@ int upload_weights(ufd_model* m, const float* blob) {
     while (img.size() % 64) img.push_back(0.f);
     b_off[i] = img.size();
     img.insert(img.end(), p, p + s.cout);
+    if (s.groups > 1 && s.k == 3) {  // depthwise: also the [c][12] image the fused kernel copies into LDS
+      while (img.size() % 64) img.push_back(0.f);
+      dw_off[i] = img.size();
+      img.resize(img.size() + depthwise_packed_floats(s.cout));
+      pack_depthwise_weights(p - nw, p, s.cout, img.data() + dw_off[i]);
+    }
     p += s.cout;
   }
   HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
@@ -471,6 +478,7 @@ int upload_weights(ufd_model* m, const float* blob) {
   for (int i = 0; i < kNumConv; i++) {
     m->layers[i].d_w = m->d_weights + w_off[i];
     m->layers[i].d_b = m->d_weights + b_off[i];
+    if (dw_off[i] != (size_t)-1) m->layers[i].d_w_dwpack = m->d_weights + dw_off[i];
   }
   return UFD_OK;
 }
@@ -587,7 +595,7 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
       a.in = in_ptr(D.in_tensor, D.ih, D.iw);
       a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
       a.ih = D.ih, a.iw = D.iw;
-      a.w2 = D.d_w, a.bias2 = D.d_b;
+      a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
       dw_stride = D.spec.stride;
       break;
     }
