@@ -89,29 +89,28 @@ __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][
 // fill the chip (feature maps <= 30x40), so the serial k-chain per wave is 4x shorter.
 template <int CT>
 __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red, int wave, int lane) {
-  if (wave > 0) {
-    float* dst = red + (size_t)(wave - 1) * CT * 64 * 64;
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[((ct * 4 + j) * 16 + r) * 64 + lane] = acc[ct][j][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int w = 0; w < 3; w++) {
-      const float* src = red + (size_t)w * CT * 64 * 64;
+  // one partial tile at a time through a single 16 KiB buffer: fixed order w = 1, 2, 3
+  // (deterministic), barriers keep the compiler from hoisting 192 LDS reads into registers
+#pragma unroll 1
+  for (int w = 1; w < 4; w++) {
+    if (wave == w) {
 #pragma unroll
       for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) acc[ct][j][r] += src[((ct * 4 + j) * 16 + r) * 64 + lane];
-          __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later slices from being hoisted (register pressure)
-        }
+          for (int r = 0; r < 16; r++) red[((ct * 4 + j) * 16 + r) * 64 + lane] = acc[ct][j][r];
     }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[ct][j][r] += red[((ct * 4 + j) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
   }
 }
 
@@ -125,16 +124,28 @@ __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red
 // trip per k-step.  Needs ksteps % D == 0.
 template <int CT, int D, int SK>
 __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
-  extern __shared__ float s_dyn[];  // split-K reduction buffer (SK == 4)
+  // LDS: weights of this cout tile [ksteps][64] (one vector-memory instruction per k-step is left:
+  // the activation load) | split-K reduction buffer
+  extern __shared__ float s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
   if (!remap_block(a, &tile, &ctile)) return;
+  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
+  float* s_w = s_mem;
+  float* s_red = s_mem + CT * ksteps * 64;
+  {
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
+    float4* wdst = reinterpret_cast<float4*>(s_w);
+    const int w4 = CT * ksteps * 16;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < w4; i += 256) wdst[i] = wsrc[i];
+  }
+  __syncthreads();
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
   const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * 32 + (lane & 31);
   const bool live = g < (long)a.B * gpf;
   const size_t frame = live ? g / gpf : 0;
   const int pix = live ? (int)(g - (long)frame * gpf) * 4 : 0;
-  const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
@@ -147,42 +158,31 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
   }
-  // wave-uniform base pointer + 32-bit per-lane element offsets (tensors are < 2^32 bytes, checked
-  // by the launcher): lets the compiler use scalar-base addressing instead of 64-bit VALU adds
+  // wave-uniform base pointer + 32-bit per-lane element offsets (tensors are < 2^32 bytes)
   const float* __restrict__ in = a.in;
   const uint32_t in_off = (uint32_t)((frame * a.in_ctotal + half) * hw + pix);
-  const float* wp = a.w + (size_t)ct0 * ksteps * 64 + lane;
   const uint32_t in_step = 2u * (uint32_t)hw;
   float4 bq[D];
-  float wq[D][CT];
 #pragma unroll
-  for (int d = 0; d < D; d++) {
-    bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)(kbeg + d) * in_step));
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kbeg + d) * 64];
-  }
+  for (int d = 0; d < D; d++) bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)min(kbeg + d, kend - 1) * in_step));
   for (int ks = kbeg; ks < kend; ks += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const float4 b = bq[d];
-      float w[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) w[ct] = wq[d][ct];
       const int kn = min(ks + D + d, kend - 1);  // refill the slot (tail: harmless re-read)
       bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)kn * in_step));
 #pragma unroll
-      for (int ct = 0; ct < CT; ct++) wq[d][ct] = wp[((size_t)ct * ksteps + kn) * 64];
-#pragma unroll
       for (int ct = 0; ct < CT; ct++) {
-        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.x, acc[ct][0], 0, 0, 0);
-        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.y, acc[ct][1], 0, 0, 0);
-        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.z, acc[ct][2], 0, 0, 0);
-        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ct], b.w, acc[ct][3], 0, 0, 0);
+        const float w = s_w[(ct * ksteps + ks + d) * 64 + lane];
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.x, acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.y, acc[ct][1], 0, 0, 0);
+        acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.z, acc[ct][2], 0, 0, 0);
+        acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.w, acc[ct][3], 0, 0, 0);
       }
     }
   }
   if (SK > 1) {
-    splitk_reduce<CT>(acc, s_dyn, wave, lane);
+    splitk_reduce<CT>(acc, s_red, wave, lane);
     if (wave > 0) return;
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, pix, hw);
@@ -561,7 +561,7 @@ static bool want_splitk(long wave_tiles, int cts, int ksteps) {
   // chain length (15x20 maps, 64->4/8 heads at 30x40, the 256-channel layers); costs otherwise
   return wave_tiles * cts < 6L * ksteps;
 }
-constexpr size_t kSplitKBytes = 3 * 64 * 64 * sizeof(float);  // CT = 1
+constexpr size_t kSplitKBytes = 64 * 64 * sizeof(float);  // CT = 1: one partial tile at a time
 
 void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
@@ -569,18 +569,19 @@ void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
   const long wave_tiles = (groups + 31) / 32;
   a.cts = (a.cout + 31) / 32;
   const int ksteps = a.cin >> 1;
+  const size_t wlds = (size_t)ksteps * 64 * sizeof(float);
   if (want_splitk(wave_tiles, a.cts, ksteps)) {
     a.tiles = (int)wave_tiles;
     const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid), dim3(256), kSplitKBytes, s, a);
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid), dim3(256), wlds + kSplitKBytes, s, a);
     return;
   }
   a.tiles = (int)((groups + 127) / 128);
   const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
   if (ksteps % 4 == 0)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid), dim3(256), wlds, s, a);
   else
-    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid), dim3(256), wlds, s, a);
 }
 
 void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
