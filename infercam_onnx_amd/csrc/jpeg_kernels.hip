@@ -281,6 +281,72 @@ __global__ __launch_bounds__(256) void k_upsample_norm(const JpegFrameDesc* __re
   }
 }
 
+// 4:2:0 YCbCr fast path of the same stage (the camera-stream case): 8 output pixels per thread,
+// 8-byte luma load, 4-byte chroma loads, column sums shared between the 8 pixels; the edge
+// formulas of jdsample.c h2v2_fancy_upsample fall out of clamping the neighbour column
+// ((3s + s + 8) >> 4 == (4s + 8) >> 4).  Bit-identical to k_upsample_norm.
+__global__ __launch_bounds__(256) void k_upsample_norm_420(const JpegFrameDesc* __restrict__ descs,
+                                                           const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                           const float* __restrict__ lut, float* __restrict__ out, int W,
+                                                           int H) {
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
+  __syncthreads();
+  const int frame = blockIdx.y;
+  const JpegFrameDesc& d = descs[frame];
+  if (d.width != W || d.height != H) return;  // failed / skipped frame
+  const int gw = W >> 3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= gw * H) return;
+  const int y = t / gw, x0 = (t - y * gw) * 8;
+  const uint8_t* fp = planes + (size_t)frame * plane_stride;
+  const int ypitch = d.wblk[0] * 8, cpitch = d.wblk[1] * 8;
+  const int dw = d.dw[1], dh = d.dh[1];
+  const uint2 yy = *reinterpret_cast<const uint2*>(fp + d.plane_off[0] + (size_t)y * ypitch + x0);
+  const int iy = y >> 1, ny = max(0, min(dh - 1, (y & 1) ? iy + 1 : iy - 1));
+  const int c0 = x0 >> 1, cl = max(c0 - 1, 0), cr = min(c0 + 4, dw - 1);
+  int s[2][6];  // column sums 3*near + far for chroma columns c0-1 .. c0+4 (clamped)
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const uint8_t* p0 = fp + d.plane_off[1 + c] + (size_t)iy * cpitch;
+    const uint8_t* p1 = fp + d.plane_off[1 + c] + (size_t)ny * cpitch;
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(p0 + c0), b = *reinterpret_cast<const uint32_t*>(p1 + c0);
+    s[c][0] = 3 * p0[cl] + p1[cl];
+    s[c][5] = 3 * p0[cr] + p1[cr];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[c][1 + i] = 3 * (int)((a >> (8 * i)) & 255) + (int)((b >> (8 * i)) & 255);
+  }
+  float r[8], g[8], bl[8];
+  const int bias = 0;
+  (void)bias;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = 1 + (j >> 1);  // chroma column of this pixel inside s[]
+    int cbv, crv;
+    if (j & 1) {
+      cbv = (s[0][i] * 3 + s[0][i + 1] + 7) >> 4;
+      crv = (s[1][i] * 3 + s[1][i + 1] + 7) >> 4;
+    } else {
+      cbv = (s[0][i] * 3 + s[0][i - 1] + 8) >> 4;
+      crv = (s[1][i] * 3 + s[1][i - 1] + 8) >> 4;
+    }
+    const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
+    const int cb = cbv - 128, crr = crv - 128;
+    const int rr = clamp255(yv + ((91881 * crr + 32768) >> 16));
+    const int gg = clamp255(yv + ((-22554 * cb + 32768 - 46802 * crr) >> 16));
+    const int bb = clamp255(yv + ((116130 * cb + 32768) >> 16));
+    r[j] = s_lut[rr], g[j] = s_lut[256 + gg], bl[j] = s_lut[512 + bb];
+  }
+  const size_t hw = (size_t)W * H;
+  float* o = out + (size_t)frame * 3 * hw + (size_t)y * W + x0;
+  *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+  *reinterpret_cast<float4*>(o + hw) = make_float4(g[0], g[1], g[2], g[3]);
+  *reinterpret_cast<float4*>(o + hw + 4) = make_float4(g[4], g[5], g[6], g[7]);
+  *reinterpret_cast<float4*>(o + 2 * hw) = make_float4(bl[0], bl[1], bl[2], bl[3]);
+  *reinterpret_cast<float4*>(o + 2 * hw + 4) = make_float4(bl[4], bl[5], bl[6], bl[7]);
+}
+
 }  // namespace
 
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
@@ -295,6 +361,15 @@ void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, 
   if (!count) return;
   dim3 grid((max_w + 1023) / 1024, max_h, count);
   hipLaunchKernelGGL(k_upsample_rgb, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
+}
+
+void launch_upsample_norm_420(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
+                              const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count,
+                              hipStream_t s) {
+  if (!count) return;
+  dim3 grid(((W / 8) * H + 255) / 256, count);
+  hipLaunchKernelGGL(k_upsample_norm_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
+                     (int)W, (int)H);
 }
 
 void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,

@@ -29,6 +29,12 @@ void launch_huffman_rst(const uint8_t* d_blob, const HuffScan* d_scans, const Hu
                         const HuffLut* d_luts, const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride,
                         uint32_t* d_status, hipStream_t s);
 
+// 4:2:0 YCbCr specialisation (every frame of the batch: 3 components, 2x2 luma sampling, fancy
+// upsampling applicable, W % 8 == 0): same results, 8 pixels per thread with wide loads.
+void launch_upsample_norm_420(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
+                              const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count,
+                              hipStream_t s);
+
 // ---------------- A2-A4: Triangle resize + normalise (preproc_kernels.hip) ----------------
 struct ResizeTaps {          // device pointers, one table per axis
   const int32_t* left;       // [D]

@@ -907,8 +907,20 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
-      ProfScope ps(m, "upsample_norm", 0, 0);
-      launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
+      // camera streams are 4:2:0 YCbCr: specialised kernel when every decoded frame qualifies
+      bool all_420 = (m->W % 8) == 0;
+      for (uint32_t i = 0; i < count && all_420; i++) {
+        if (s.st[i] != UFD_OK) continue;
+        const JpegFrameDesc& d = s.h_descs[i];
+        all_420 = d.ncomp == 3 && d.color == kColorYCbCr && d.h[0] == 2 && d.v[0] == 2 && d.h[1] == 1 && d.v[1] == 1 &&
+                  d.h[2] == 1 && d.v[2] == 1 && d.dw[1] > 2;
+      }
+      const double bytes = (double)count * (m->W * m->H * 1.5 + m->W * m->H * 12.0);
+      ProfScope ps(m, all_420 ? "upsample_norm_420" : "upsample_norm", bytes, 0);
+      if (all_420)
+        launch_upsample_norm_420(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
+      else
+        launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
       HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
       tl_cur->consumed_valid[buf] = true;
     } else {
