@@ -29,6 +29,8 @@ KERNEL_FUNCS = {
     "conv_pw_mfma": "k_pw_mfma",
     "conv_dwpw_mfma": "k_dwpw_mfma",
     "conv3x3_mfma": "k_conv3x3_mfma",
+    "conv3x3_rows_mfma": "k_conv3x3_rows_mfma",
+    "upsample_norm_420": "k_upsample_norm_420",
     "conv_direct_dw": "k_conv_direct<1, true>",
     "conv_direct_full": "k_conv_direct<16|4, false>",
     "idct": "k_idct",
@@ -156,7 +158,7 @@ def main():
         d = kern[dom]
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv3x3_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv3x3_mfma", "conv3x3_rows_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
             roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
         else:

@@ -462,6 +462,140 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense 3x3 "row" kernel (stem s2, RFB 3x3 with dilation 1/2/3/5): v_mfma_f32_16x16x4_f32 with
+// 4 input channels per instruction.  Lane (q = l>>4, j = l&15) owns the 4 output pixels of pixel
+// group j of its wave tile for input channel 4*kc + q; per channel chunk it loads its three input
+// rows as 16-byte segments (one per row, two for stride 2) and every tap is a register select or
+// a cross-lane shuffle of those rows -- no per-tap gathers (the gather kernel above issues one
+// scalar load per tap, which is what bounds it).  The first / last HL lanes of each 16-lane
+// quad are halo providers (tiles overlap by 2*HL groups).  Needs ow % 4 == 0, iw % 4 == 0,
+// cout <= 16.  Accumulation order: channel chunks of 4, taps inside (not the oracle's order;
+// the difference is fp32 rounding, ~1e-7 relative).
+// a.w: packed [ceil(cin/4)][9][64] (lane l: W[l&15][4*kc + (l>>4)][tap], zero padded).
+template <int S, int DIL>
+__global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs a) {
+  constexpr int HL = (S == 1) ? (DIL + 3) / 4 : 1;  // halo lanes on each side of a quad
+  constexpr int NG = 16 - 2 * HL;                   // output pixel groups per wave tile
+  extern __shared__ float s_w[];                    // packed weights when they fit (a.dbg = 1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j16 = lane & 15;
+  const int cin4 = (a.cin + 3) >> 2;
+  const bool w_in_lds = a.dbg != 0;
+  if (w_in_lds) {
+    const float4* src = reinterpret_cast<const float4*>(a.w);
+    float4* dst = reinterpret_cast<float4*>(s_w);
+    const int n4 = cin4 * 9 * 16;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
+  const long total = (long)a.B * gpf;
+  const long g = ((long)blockIdx.x * 4 + wave) * NG + j16 - HL;
+  const bool inrange = g >= 0 && g < total;
+  const bool live = inrange && j16 >= HL && j16 < 16 - HL;
+  const size_t frame = inrange ? g / gpf : 0;
+  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const int ihw = a.ih * a.iw;
+
+  floatx4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = 4 * q + r;
+      acc[j][r] = co < a.cout ? a.bias[co] : 0.0f;
+    }
+
+  const int ix0 = ox * S;
+  bool rowok[3];
+  uint32_t rowoff[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int iy = oy * S + (r - 1) * DIL;
+    rowok[r] = iy >= 0 && iy < a.ih;
+    rowoff[r] = (uint32_t)(frame * a.in_ctotal * (size_t)ihw) + (uint32_t)(min(max(iy, 0), a.ih - 1) * a.iw + ix0);
+  }
+  // column validity of the shifted taps (stride 1: x + j -/+ DIL inside the row; stride 2: left edge)
+  bool lok[4], rok[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    lok[j] = S == 1 ? (ox + j - DIL >= 0) : (j > 0 || ix0 > 0);
+    rok[j] = S == 1 ? (ox + j + DIL < a.ow) : true;
+  }
+  const float* __restrict__ in = a.in;
+  const float* wg = a.w + lane;
+
+  struct Rows {
+    float4 m0[3], m1[3];
+  };
+  auto load_rows = [&](int kc, Rows& w) {
+    const uint32_t c = (uint32_t)min(4 * kc + q, a.cin - 1) * (uint32_t)ihw;  // padded channels: weight is 0
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      w.m0[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c));
+      if (S == 2) w.m1[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c + 4u));
+    }
+  };
+  // value of this lane's row segment at column offset c (relative to its first pixel), c in [-8, 11]
+  auto col = [&](const float4& m, int c) -> float {
+    const int o = (c >= 0) ? (c >> 2) : -((3 - c) >> 2);  // lane offset, floor(c / 4)
+    const int k = c - 4 * o;
+    const float v = k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w));
+    return o == 0 ? v : __shfl(v, lane + o);
+  };
+
+  Rows cur, nxt;
+  load_rows(0, cur);
+  for (int kc = 0; kc < cin4; kc++) {
+    load_rows(min(kc + 1, cin4 - 1), nxt);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const bool ok = rowok[r];
+      float x[3][4];  // [kx][pixel]
+      if (S == 1) {
+        const float4 m = cur.m0[r];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          // shuffles first, unconditionally: a cross-lane read inside a divergent branch would
+          // see inactive source lanes
+          const float vl = col(m, j - DIL), vc = col(m, j), vr = col(m, j + DIL);
+          x[0][j] = (ok && lok[j]) ? vl : 0.0f;
+          x[1][j] = ok ? vc : 0.0f;
+          x[2][j] = (ok && rok[j]) ? vr : 0.0f;
+        }
+      } else {
+        const float4 m0 = cur.m0[r], m1 = cur.m1[r];
+        const float left = __shfl(m1.w, lane - 1);
+        x[0][0] = (ok && lok[0]) ? left : 0.0f, x[0][1] = ok ? m0.y : 0.0f, x[0][2] = ok ? m0.w : 0.0f, x[0][3] = ok ? m1.y : 0.0f;
+        x[1][0] = ok ? m0.x : 0.0f, x[1][1] = ok ? m0.z : 0.0f, x[1][2] = ok ? m1.x : 0.0f, x[1][3] = ok ? m1.z : 0.0f;
+        x[2][0] = ok ? m0.y : 0.0f, x[2][1] = ok ? m0.w : 0.0f, x[2][2] = ok ? m1.y : 0.0f, x[2][3] = ok ? m1.w : 0.0f;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int widx = (kc * 9 + r * 3 + kx) * 64;
+        const float w = w_in_lds ? s_w[widx + lane] : wg[widx];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
+      }
+    }
+    cur = nxt;
+  }
+  if (!live) return;
+  const int pix = oy * a.ow + ox;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int co = 4 * q + r;
+    if (co < a.cout) {
+      float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      if (a.relu) v = relu4(v);
+      *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Direct convolution fallback, one output pixel x COB output channels per thread.
 template <int COB, bool DW>
 __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
@@ -542,6 +676,46 @@ void pack_conv3x3_weights(const float* w, int cin, int cout, float* packed) {
         const int co = lane & 15, t = 4 * s + (lane >> 4);
         packed[((size_t)ci * 3 + s) * 64 + lane] = (co < cout && t < 9) ? w[((size_t)co * cin + ci) * 9 + t] : 0.0f;
       }
+}
+
+size_t conv3x3_rows_packed_floats(int cin) { return (size_t)((cin + 3) / 4) * 9 * 64; }
+
+void pack_conv3x3_rows_weights(const float* w, int cin, int cout, float* packed) {
+  const int cin4 = (cin + 3) / 4;
+  for (int kc = 0; kc < cin4; kc++)
+    for (int t = 0; t < 9; t++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int co = lane & 15, ci = 4 * kc + (lane >> 4);
+        packed[((size_t)kc * 9 + t) * 64 + lane] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + t] : 0.0f;
+      }
+}
+
+bool conv3x3_rows_supported(const ConvArgs& a) {
+  if (a.k != 3 || a.cout > 16 || a.depthwise || a.res) return false;
+  if ((a.ow & 3) || (a.iw & 3) || a.pad != a.dil) return false;
+  if (a.stride == 1) return (a.dil == 1 || a.dil == 2 || a.dil == 3 || a.dil == 5) && a.iw == a.ow && a.ih == a.oh;
+  return a.stride == 2 && a.dil == 1 && a.iw == 2 * a.ow;
+}
+
+void launch_conv3x3_rows_mfma(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  const long groups = (long)a.B * (a.oh * a.ow / 4);
+  const size_t wbytes = conv3x3_rows_packed_floats(a.cin) * sizeof(float);
+  const bool lds = wbytes <= 40 * 1024;
+  a.dbg = lds ? 1 : 0;  // weights staged in LDS
+  const size_t shmem = lds ? wbytes : 0;
+  auto grid = [&](int hl) { return dim3((unsigned)((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl)))); };
+  if (a.stride == 2) {
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, a);
+  } else if (a.dil == 1) {
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 1>), grid(1), dim3(256), shmem, s, a);
+  } else if (a.dil == 2) {
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 2>), grid(1), dim3(256), shmem, s, a);
+  } else if (a.dil == 3) {
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 3>), grid(1), dim3(256), shmem, s, a);
+  } else {
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 5>), grid(2), dim3(256), shmem, s, a);
+  }
 }
 
 bool dwpw_supported(const ConvArgs& a, int stride) {

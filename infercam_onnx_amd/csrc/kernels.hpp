@@ -81,6 +81,11 @@ void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c,
 void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s);
 // Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
 void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s);
+// Row variant (16-byte row loads + cross-lane shuffles instead of per-tap gathers).
+bool conv3x3_rows_supported(const ConvArgs& a);
+void launch_conv3x3_rows_mfma(const ConvArgs& a, hipStream_t s);
+size_t conv3x3_rows_packed_floats(int cin);
+void pack_conv3x3_rows_weights(const float* w /*[cout][cin][3][3]*/, int cin, int cout, float* packed);
 size_t conv3x3_packed_floats(int cin);
 void pack_conv3x3_weights(const float* w /*[cout][cin][3][3]*/, int cin, int cout, float* packed);
 

@@ -65,6 +65,7 @@ struct Layer {
   int fused_dw = -1;       // kKindDwPw: index of the depthwise layer
   bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
   const float* d_w = nullptr;  // kernel-specific packing
+  const float* d_w_rows = nullptr;    // dense 3x3 layers: packing of the row kernel
   const float* d_w_dwpack = nullptr;  // depthwise layers: [c][12] image for the fused dw->pw kernel
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
@@ -442,7 +443,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
 int upload_weights(ufd_model* m, const float* blob) {
   const ConvSpec* specs = conv_specs();
   std::vector<float> img;
-  std::vector<size_t> w_off(kNumConv), b_off(kNumConv), dw_off(kNumConv, (size_t)-1);
+  std::vector<size_t> w_off(kNumConv), b_off(kNumConv), dw_off(kNumConv, (size_t)-1), rows_off(kNumConv, (size_t)-1);
   const float* p = blob;
   for (int i = 0; i < kNumConv; i++) {
     const ConvSpec& s = specs[i];
@@ -465,6 +466,12 @@ int upload_weights(ufd_model* m, const float* blob) {
     while (img.size() % 64) img.push_back(0.f);
     b_off[i] = img.size();
     img.insert(img.end(), p, p + s.cout);
+    if (kind == kKindConv3x3) {
+      while (img.size() % 64) img.push_back(0.f);
+      rows_off[i] = img.size();
+      img.resize(img.size() + conv3x3_rows_packed_floats(s.cin));
+      pack_conv3x3_rows_weights(p - nw, s.cin, s.cout, img.data() + rows_off[i]);
+    }
     if (s.groups > 1 && s.k == 3) {  // depthwise: also the [c][12] image the fused kernel copies into LDS
       while (img.size() % 64) img.push_back(0.f);
       dw_off[i] = img.size();
@@ -479,6 +486,7 @@ int upload_weights(ufd_model* m, const float* blob) {
     m->layers[i].d_w = m->d_weights + w_off[i];
     m->layers[i].d_b = m->d_weights + b_off[i];
     if (dw_off[i] != (size_t)-1) m->layers[i].d_w_dwpack = m->d_weights + dw_off[i];
+    if (rows_off[i] != (size_t)-1) m->layers[i].d_w_rows = m->d_weights + rows_off[i];
   }
   return UFD_OK;
 }
@@ -586,6 +594,7 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   a.out_ctotal = m->tensors[L.out_tensor].c;
   a.out_coff = L.out_coff;
   int dw_stride = 1;
+  bool use_rows = false;
   const char* kind = "conv_direct_full";
   switch (L.kind) {
     case kKindPointwise: kind = "conv_pw_mfma"; break;
@@ -599,7 +608,10 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
       dw_stride = D.spec.stride;
       break;
     }
-    case kKindConv3x3: kind = "conv3x3_mfma"; break;
+    case kKindConv3x3:
+      use_rows = conv3x3_rows_supported(a) && !(std::getenv("UFD_NO_ROWS"));
+      kind = use_rows ? "conv3x3_rows_mfma" : "conv3x3_mfma";
+      break;
     case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
     case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
@@ -608,7 +620,14 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
   switch (L.kind) {
     case kKindPointwise: launch_conv_pointwise_mfma(a, tl_cur->stream); break;
     case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, tl_cur->stream); break;
-    case kKindConv3x3: launch_conv3x3_mfma(a, tl_cur->stream); break;
+    case kKindConv3x3:
+      if (use_rows) {
+        a.w = L.d_w_rows;
+        launch_conv3x3_rows_mfma(a, tl_cur->stream);
+      } else {
+        launch_conv3x3_mfma(a, tl_cur->stream);
+      }
+      break;
     default: launch_conv_direct(a, tl_cur->stream); break;
   }
 }
