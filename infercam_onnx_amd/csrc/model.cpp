@@ -122,6 +122,8 @@ struct Worker {
 struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
+  hipStream_t aux[2] = {nullptr, nullptr};  // side streams for independent branches (RFB branches, cls / reg heads)
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float* d_arena = nullptr;
   float* d_input = nullptr;
   JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
@@ -198,6 +200,7 @@ struct ufd_model {
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool gpu_entropy_enabled = true;
+  bool branch_streams = false;
 
   Slot slots[UFD_MAX_SLOTS];
   uint32_t next_ticket = 1;
@@ -571,7 +574,8 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 float* tensor_ptr(ufd_model* m, int t) { return tl_cur->d_arena + m->tensors[t].off; }
 
 // one conv layer for frames [f0, f0 + count) of the batch
-void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
+void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st = nullptr) {
+  if (!st) st = tl_cur->stream;
   const Layer& L = m->layers[i];
   if (L.kind == kKindFusedAway && !L.materialize) return;
   auto in_ptr = [&](int t, int ih, int iw) -> const float* {
@@ -616,19 +620,19 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
     case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
   ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
-               L.flops_per_frame * count);
+               L.flops_per_frame * count, st);
   switch (L.kind) {
-    case kKindPointwise: launch_conv_pointwise_mfma(a, tl_cur->stream); break;
-    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, tl_cur->stream); break;
+    case kKindPointwise: launch_conv_pointwise_mfma(a, st); break;
+    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, st); break;
     case kKindConv3x3:
       if (use_rows) {
         a.w = L.d_w_rows;
-        launch_conv3x3_rows_mfma(a, tl_cur->stream);
+        launch_conv3x3_rows_mfma(a, st);
       } else {
-        launch_conv3x3_mfma(a, tl_cur->stream);
+        launch_conv3x3_mfma(a, st);
       }
       break;
-    default: launch_conv_direct(a, tl_cur->stream); break;
+    default: launch_conv_direct(a, st); break;
   }
 }
 
@@ -638,14 +642,61 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count) {
 // tensors inside the 256 MiB Infinity Cache.  Deeper layers are small and want the whole batch
 // in one launch.
 void enqueue_forward(ufd_model* m, uint32_t count) {
-  static const int chunk_knob = std::getenv("UFD_CHUNK") ? std::atoi(std::getenv("UFD_CHUNK")) : 0;
-  static const int until_knob = std::getenv("UFD_CHUNK_LAYERS") ? std::atoi(std::getenv("UFD_CHUNK_LAYERS")) : 9;
-  const uint32_t chunk = chunk_knob > 0 ? (uint32_t)chunk_knob : count;
-  const int early_end = chunk < count ? std::min(until_knob, kNumConv) : 0;
-  for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
-    for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
-  for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
-  tl_cur->last_forward_count = count;
+  Ctx& c = *tl_cur;
+  if (!m->branch_streams) {
+    // optional: the first layers in chunks of frames, so that their large producer->consumer
+    // tensors stay inside the 256 MiB Infinity Cache (UFD_CHUNK / UFD_CHUNK_LAYERS tuning knobs)
+    static const int chunk_knob = std::getenv("UFD_CHUNK") ? std::atoi(std::getenv("UFD_CHUNK")) : 0;
+    static const int until_knob = std::getenv("UFD_CHUNK_LAYERS") ? std::atoi(std::getenv("UFD_CHUNK_LAYERS")) : 5;
+    const uint32_t chunk = chunk_knob > 0 ? (uint32_t)chunk_knob : count;
+    const int early_end = chunk < count ? std::min(until_knob, kNumConv) : 0;
+    for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
+      for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
+    for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
+    c.last_forward_count = count;
+    return;
+  }
+  // Branch-parallel issue: the RFB branches and the cls / reg heads are independent of the
+  // backbone's continuation; they go to two side streams so that their small, latency-bound
+  // kernels run beside the main chain (the arena keeps every tensor alive in this mode).
+  auto fork = [&]() {
+    (void)hipEventRecord(c.ev_fork, c.stream);
+    (void)hipStreamWaitEvent(c.aux[0], c.ev_fork, 0);
+    (void)hipStreamWaitEvent(c.aux[1], c.ev_fork, 0);
+  };
+  auto join = [&]() {
+    for (int k = 0; k < 2; k++) {
+      (void)hipEventRecord(c.ev_join[k], c.aux[k]);
+      (void)hipStreamWaitEvent(c.stream, c.ev_join[k], 0);
+    }
+  };
+  auto run = [&](std::initializer_list<int> layers, hipStream_t st) {
+    for (int i : layers) enqueue_layer(m, i, 0, count, st);
+  };
+  for (int i = 0; i <= 12; i++) enqueue_layer(m, i, 0, count);
+  fork();
+  run({13, 14, 15}, c.aux[0]);
+  run({16, 17, 18}, c.aux[1]);
+  run({19, 20, 21, 22}, c.stream);
+  join();
+  run({23, 24}, c.stream);
+  fork();
+  run({25, 26}, c.aux[0]);
+  run({27, 28}, c.aux[1]);
+  run({29, 30, 31, 32, 33, 34}, c.stream);
+  fork();  // (aux streams keep their own order: heads 1 follow heads 0)
+  run({35, 36}, c.aux[0]);
+  run({37, 38}, c.aux[1]);
+  run({39, 40, 41, 42}, c.stream);
+  fork();
+  run({43, 44}, c.aux[0]);
+  run({45, 46}, c.aux[1]);
+  run({47, 48, 49}, c.stream);
+  fork();
+  run({50}, c.aux[0]);
+  run({51}, c.stream);
+  join();
+  c.last_forward_count = count;
 }
 
 void enqueue_heads(ufd_model* m, uint32_t count) {
@@ -1115,6 +1166,11 @@ void destroy(ufd_model* m) {
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
   for (Ctx& c : m->ctx) {
     if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+    for (int k = 0; k < 2; k++) {
+      if (c.aux[k]) (void)hipStreamDestroy(c.aux[k]);
+      if (c.ev_join[k]) (void)hipEventDestroy(c.ev_join[k]);
+    }
+    if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
     if (c.stream) (void)hipStreamDestroy(c.stream);
   }
   delete m;
@@ -1182,6 +1238,11 @@ int create(const ufd_config* cfg, ufd_model** out) {
     Ctx& c = m->ctx[ci];
     HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIPB(hipStreamCreateWithFlags(&c.aux[k], hipStreamNonBlocking));
+      HIPB(hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming));
+    }
+    HIPB(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
   }
 
   // ---- weights + priors
@@ -1211,7 +1272,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_WEIGHTS);
     }
   }
-  plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0);
+  m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
+  plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0 || m->branch_streams);
   // shapes the kernels rely on (checked here once, not per launch)
   for (const Layer& L : m->layers) {
     if ((L.kind == kKindPointwise || L.kind == kKindDwPw) && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
