@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (async submit/wait)")
+    ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
     ap.add_argument("--restart-rows", type=int, default=0,
                     help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
                          ">0: restart-interval stream, entropy decoding on the GPU)")
