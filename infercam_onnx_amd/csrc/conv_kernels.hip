@@ -368,13 +368,14 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
 // is exactly ci-major / tap-minor.  A wave owns PG groups of 16 consecutive output pixels
 // (numbered over the whole batch); D: reg r, lane l -> cout 4*(l>>4) + r, pixel column l&15.
 // a.w: packed [cin][3][64] (lane l of slot s: W[l&15][ci][4s + (l>>4)], 0 for taps >= 9 / cout pad).
-template <int PG, int U>
+template <int PG, int U, int SK = 1>
 __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
+  __shared__ float s_red[SK > 1 ? 3 * 4 * PG * 64 : 1];  // split-K: partial tiles of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, quad = lane >> 4;
   const int ohw = a.oh * a.ow, ihw = a.ih * a.iw;
   const long total = (long)a.B * ohw;
-  const long p0 = (((long)blockIdx.x * 4 + wave) * PG) * 16 + col;
+  const long p0 = ((SK == 1 ? ((long)blockIdx.x * 4 + wave) : (long)blockIdx.x) * PG) * 16 + col;
 
   // per pixel group: base pointer; per (slot, group): tap offset validity
   const float* base[PG];
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int co = 4 * quad + r;
-      acc[g][r] = co < a.cout ? a.bias[co] : 0.0f;
+      acc[g][r] = (co < a.cout && (SK == 1 || wave == 0)) ? a.bias[co] : 0.0f;
     }
   const float* wp = a.w + lane;
   // U channels per iteration: their gathers are issued together (deep layers have one short
   // dependent MFMA chain per wave and would otherwise pay a memory round trip per tap).
   // Gathers are unconditional from clamped addresses; masked taps are zeroed by select.
-  for (int c0 = 0; c0 < a.cin; c0 += U) {
+  // split-K: the block's four waves share the pixel groups and take a quarter of the channels each
+  const int cper = a.cin / SK, cbeg = (SK == 1) ? 0 : wave * cper, cend = cbeg + cper;
+  for (int c0 = cbeg; c0 < cend; c0 += U) {
     float x[U][3][PG], w[U][3];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -443,6 +446,22 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
           const float xv = ((valid >> (s * PG + g)) & 1u) ? x[u][s][g] : 0.0f;
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][s], xv, acc[g], 0, 0, 0);
         }
+  }
+  if (SK > 1) {  // fixed-order reduction (w = 1, 2, 3) into wave 0
+    if (wave > 0) {
+#pragma unroll
+      for (int g = 0; g < PG; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) s_red[(((wave - 1) * PG + g) * 4 + r) * 64 + lane] = acc[g][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+      for (int g = 0; g < PG; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[g][r] += s_red[((w * PG + g) * 4 + r) * 64 + lane];
   }
 #pragma unroll
   for (int g = 0; g < PG; g++) {
@@ -798,7 +817,9 @@ void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s) {
     else
       hipLaunchKernelGGL((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   } else {
-    if (a.cin % 8 == 0)
+    if (a.cin % 32 == 0 && a.cin >= 128 && total < 16384)  // few pixels, long channel chain: split-K
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8, 4>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a);
+    else if (a.cin % 8 == 0)
       hipLaunchKernelGGL((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
     else if (a.cin % 4 == 0)
       hipLaunchKernelGGL((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
