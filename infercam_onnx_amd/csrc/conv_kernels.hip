@@ -18,6 +18,7 @@
 // Numerics: fp32 MFMA is an exact k-ordered fma chain, and every kernel keeps the order
 // "acc = bias; for ci, ky, kx: acc = fma(w, x, acc)" (zero taps add exactly 0), so results are
 // bit-identical to a plain fmaf loop nest in that order.
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -123,7 +124,8 @@ __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red
 // unconditional: dead lanes read a valid dummy address), so a wave does not pay one memory round
 // trip per k-step.  Needs ksteps % D == 0.
 template <int CT, int D, int SK>
-__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];
   // LDS: weights of this cout tile [ksteps][64] (one vector-memory instruction per k-step is left:
   // the activation load) | split-K reduction buffer
   extern __shared__ float s_mem[];
@@ -209,7 +211,8 @@ struct DwWindow {  // raw 3 x 4*S input window of one channel for 4 output pixel
 constexpr int kDwGroups = 30;
 
 template <int CT, int S, int D, int SK>
-__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];
   // LDS: depthwise weights [cin][12] | pointwise weights of this cout tile [ksteps][64] | split-K buffer
   extern __shared__ float s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs a) {
 // (numbered over the whole batch); D: reg r, lane l -> cout 4*(l>>4) + r, pixel column l&15.
 // a.w: packed [cin][3][64] (lane l of slot s: W[l&15][ci][4s + (l>>4)], 0 for taps >= 9 / cout pad).
 template <int PG, int U, int SK = 1>
-__global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];
   __shared__ float s_red[SK > 1 ? 3 * 4 * PG * 64 : 1];  // split-K: partial tiles of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, quad = lane >> 4;
@@ -756,75 +760,91 @@ static bool want_splitk(long wave_tiles, int cts, int ksteps) {
 }
 constexpr size_t kSplitKBytes = 64 * 64 * sizeof(float);  // CT = 1: one partial tile at a time
 
-void launch_conv_pointwise_mfma(const ConvArgs& a0, hipStream_t s) {
-  ConvArgs a = a0;
-  const long groups = (long)a.B * (a.oh * a.ow / 4);
+// n (<= 3) convolutions with identical shapes except cout / weights / outputs
+void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
+  ConvArgs3 p{};
+  const ConvArgs& r = args[0];
+  const long groups = (long)r.B * (r.oh * r.ow / 4);
   const long wave_tiles = (groups + 31) / 32;
-  a.cts = (a.cout + 31) / 32;
-  const int ksteps = a.cin >> 1;
+  const int ksteps = r.cin >> 1;
   const size_t wlds = (size_t)ksteps * 64 * sizeof(float);
-  if (want_splitk(wave_tiles, a.cts, ksteps)) {
-    a.tiles = (int)wave_tiles;
-    const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid), dim3(256), wlds + kSplitKBytes, s, a);
-    return;
+  int max_cts = 1;
+  for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
+  const bool sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  unsigned grid = 1;
+  for (int i = 0; i < n; i++) {
+    p.a[i] = args[i];
+    p.a[i].cts = (args[i].cout + 31) / 32;
+    p.a[i].tiles = sk ? (int)wave_tiles : (int)((groups + 127) / 128);
+    grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
   }
-  a.tiles = (int)((groups + 127) / 128);
-  const unsigned grid = (unsigned)((a.tiles + 7) / 8) * 8 * a.cts;
-  if (ksteps % 4 == 0)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid), dim3(256), wlds, s, a);
+  if (sk)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid, n), dim3(256), wlds + kSplitKBytes, s, p);
+  else if (ksteps % 4 == 0)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid, n), dim3(256), wlds, s, p);
   else
-    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid), dim3(256), wlds, s, a);
+    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid, n), dim3(256), wlds, s, p);
 }
 
-void launch_conv_dwpw_mfma(const ConvArgs& a0, int stride, hipStream_t s) {
-  ConvArgs a = a0;
-  const long groups = (long)a.B * (a.oh * a.ow / 4);
+void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t s) {
+  ConvArgs3 p{};
+  const ConvArgs& r = args[0];
+  const long groups = (long)r.B * (r.oh * r.ow / 4);
   const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
-  a.cts = (a.cout + 31) / 32;
-  const int ksteps = a.cin >> 1;
-  const size_t lds = ((size_t)a.cin * 12 + (size_t)ksteps * 64) * sizeof(float);
-  if (want_splitk(wave_tiles, a.cts, ksteps)) {
-    a.tiles = (int)wave_tiles;
-    const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
+  const int ksteps = r.cin >> 1;
+  const size_t lds = ((size_t)r.cin * 12 + (size_t)ksteps * 64) * sizeof(float);
+  int max_cts = 1;
+  for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
+  const bool sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  unsigned grid = 1;
+  for (int i = 0; i < n; i++) {
+    p.a[i] = args[i];
+    p.a[i].cts = (args[i].cout + 31) / 32;
+    p.a[i].tiles = sk ? (int)wave_tiles : (int)((wave_tiles + 3) / 4);
+    grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
+  }
+  const dim3 g(grid, n);
+  if (sk) {
     if (stride == 1)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 4>), grid, dim3(256), lds + kSplitKBytes, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 4>), g, dim3(256), lds + kSplitKBytes, s, p);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 4>), grid, dim3(256), lds + kSplitKBytes, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 4>), g, dim3(256), lds + kSplitKBytes, s, p);
     return;
   }
-  a.tiles = (int)((wave_tiles + 3) / 4);
-  const dim3 grid((unsigned)((a.tiles + 7) / 8) * 8 * a.cts);
   const bool deep = ksteps % 4 == 0;
   if (stride == 1) {
     if (deep)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 1>), g, dim3(256), lds, s, p);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1, 1>), g, dim3(256), lds, s, p);
   } else {
     if (deep)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 1>), g, dim3(256), lds, s, p);
     else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1, 1>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1, 1>), g, dim3(256), lds, s, p);
   }
 }
 
-void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s) {
+void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {
+  ConvArgs3 p{};
+  for (int i = 0; i < n; i++) p.a[i] = args[i];
+  const ConvArgs& a = args[0];
   const long total = (long)a.B * a.oh * a.ow;
+  const unsigned ny = (unsigned)n;
   if (total >= 64L * 4 * 1024) {  // enough pixels to fill the chip with 4 groups per wave
     if (a.cin % 2 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<4, 2>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
   } else {
     if (a.cin % 32 == 0 && a.cin >= 128 && total < 16384)  // few pixels, long channel chain: split-K
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8, 4>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8, 4>), dim3((unsigned)((total + 15) / 16), ny), dim3(256), 0, s, p);
     else if (a.cin % 8 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
     else if (a.cin % 4 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
   }
 }
 

@@ -65,10 +65,16 @@ struct ConvArgs {
   int32_t dbg;         // ablation switches (UFD_CONV_DBG), timing experiments only
   int32_t tiles, cts;  // MFMA kernels: pixel tiles (blocks) and 32-cout tiles, set by the launcher
 };
+// Up to three convolutions that share a launch configuration (same shapes, different weights /
+// outputs: cls+reg head pairs, the three RFB reduce convs) run as one launch, blockIdx.y selects.
+struct ConvArgs3 {
+  ConvArgs a[3];
+};
+
 // Reference-order direct convolution (any layer).  w: [cout][cin/g][k][k].
 void launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // Pointwise 1x1 on fp32 MFMA.  w: packed by pack_pointwise_weights().
-void launch_conv_pointwise_mfma(const ConvArgs& a, hipStream_t s);
+void launch_conv_pointwise_mfma(const ConvArgs* a, int n, hipStream_t s);
 // floats needed for the packed pointwise weight image of a cin->cout layer
 size_t pointwise_packed_floats(int cin, int cout);
 void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, float* packed);
@@ -78,9 +84,9 @@ void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, f
 bool dwpw_supported(const ConvArgs& a, int stride);
 size_t depthwise_packed_floats(int c);
 void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c, float* packed /*[c][12]*/);
-void launch_conv_dwpw_mfma(const ConvArgs& a, int stride, hipStream_t s);
+void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);
 // Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
-void launch_conv3x3_mfma(const ConvArgs& a, hipStream_t s);
+void launch_conv3x3_mfma(const ConvArgs* a, int n, hipStream_t s);
 // Row variant (16-byte row loads + cross-lane shuffles instead of per-tap gathers).
 bool conv3x3_rows_supported(const ConvArgs& a);
 void launch_conv3x3_rows_mfma(const ConvArgs& a, hipStream_t s);

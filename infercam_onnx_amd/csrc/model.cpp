@@ -63,6 +63,8 @@ struct Layer {
   int out_coff;
   LayerKind kind;
   int fused_dw = -1;       // kKindDwPw: index of the depthwise layer
+  int leader = -1;         // first layer of the launch this layer is issued in (itself when not merged)
+  int group[3] = {-1, -1, -1};  // leader only: members of its launch (itself first)
   bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
   const float* d_w = nullptr;  // kernel-specific packing
   const float* d_w_rows = nullptr;    // dense 3x3 layers: packing of the row kernel
@@ -390,13 +392,41 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     P.flops_per_frame += D.flops_per_frame;
     P.weight_bytes += D.weight_bytes;
   }
+  // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
+  for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
+  if (!(std::getenv("UFD_NO_MERGE"))) {
+    static const int kGroups[][3] = {{13, 16, 19}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
+    for (const auto& g : kGroups) {
+      const Layer& A = m->layers[g[0]];
+      bool ok = true;
+      for (int k = 1; k < 3 && g[k] >= 0; k++) {
+        const Layer& Bm = m->layers[g[k]];
+        ok = ok && Bm.kind == A.kind && Bm.spec.cin == A.spec.cin && Bm.ih == A.ih && Bm.iw == A.iw && Bm.oh == A.oh &&
+             Bm.ow == A.ow && Bm.spec.k == A.spec.k && Bm.spec.dil == A.spec.dil && Bm.spec.stride == A.spec.stride &&
+             (Bm.spec.cout + 31) / 32 == (A.spec.cout + 31) / 32 && Bm.res_tensor < 0 && A.res_tensor < 0;
+        // one launch at the leader's turn: every member must read the same, already produced tensor
+        const int src_a = A.kind == kKindDwPw ? m->layers[A.fused_dw].in_tensor : A.in_tensor;
+        const int src_b = Bm.kind == kKindDwPw ? m->layers[Bm.fused_dw].in_tensor : Bm.in_tensor;
+        ok = ok && src_a == src_b;
+        if (A.kind == kKindDwPw)
+          ok = ok && m->layers[Bm.fused_dw].spec.stride == m->layers[A.fused_dw].spec.stride &&
+               m->layers[Bm.fused_dw].ih == m->layers[A.fused_dw].ih;
+        if (A.kind == kKindConv3x3) ok = ok && !(A.ow % 4 == 0);  // the row kernel is single-launch
+      }
+      if (!ok) continue;
+      for (int k = 0; k < 3 && g[k] >= 0; k++) {
+        m->layers[g[k]].leader = g[0];
+        m->layers[g[0]].group[k] = g[k];
+      }
+    }
+  }
   // liveness: first writer, last reader (head outputs live until the decode kernel)
   const int nt = (int)m->tensors.size();
   std::vector<int> first(nt, kNumConv), last(nt, -1);
   for (int i = 0; i < kNumConv; i++) {
     const Layer& L = m->layers[i];
     if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
-    first[L.out_tensor] = std::min(first[L.out_tensor], i);
+    first[L.out_tensor] = std::min(first[L.out_tensor], L.leader);  // a merged layer writes at its leader's turn
     last[L.out_tensor] = std::max(last[L.out_tensor], i);
     const int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
     if (src_t >= 0) last[src_t] = std::max(last[src_t], i);
@@ -431,9 +461,15 @@ void plan_tensors(ufd_model* m, bool keep_all) {
       top += need;
     }
   };
+  std::vector<bool> allocated(nt, false);
   for (int i = 0; i < kNumConv; i++) {
-    const int t = m->layers[i].out_tensor;
-    if (first[t] == i) allocate(t);  // (a fused-away depthwise output has first == kNumConv: no storage)
+    for (int j = i; j < kNumConv; j++) {  // every tensor first written at turn i (merged members included)
+      const int tj = m->layers[j].out_tensor;
+      if (first[tj] == i && !allocated[tj]) {
+        allocate(tj);
+        allocated[tj] = true;
+      }
+    }  // (a fused-away depthwise output has first == kNumConv: no storage)
     // a buffer is recycled only after the layer that reads it last has been issued, so a
     // layer's output never aliases its own inputs
     if (!keep_all)
@@ -574,10 +610,9 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 float* tensor_ptr(ufd_model* m, int t) { return tl_cur->d_arena + m->tensors[t].off; }
 
 // one conv layer for frames [f0, f0 + count) of the batch
-void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st = nullptr) {
-  if (!st) st = tl_cur->stream;
+// Kernel arguments of conv layer i for frames [f0, f0 + count)
+ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_stride) {
   const Layer& L = m->layers[i];
-  if (L.kind == kKindFusedAway && !L.materialize) return;
   auto in_ptr = [&](int t, int ih, int iw) -> const float* {
     if (t < 0) return tl_cur->d_input + (size_t)f0 * 3 * ih * iw;
     return tensor_ptr(m, t) + (size_t)f0 * m->tensors[t].per_frame();
@@ -597,39 +632,61 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
   a.out_ctotal = m->tensors[L.out_tensor].c;
   a.out_coff = L.out_coff;
-  int dw_stride = 1;
+  *dw_stride = 1;
+  if (L.kind == kKindDwPw) {
+    const Layer& D = m->layers[L.fused_dw];
+    a.in = in_ptr(D.in_tensor, D.ih, D.iw);
+    a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
+    a.ih = D.ih, a.iw = D.iw;
+    a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
+    *dw_stride = D.spec.stride;
+  }
+  return a;
+}
+
+// Issues conv layer i -- together with the layers merged into its launch (Layer::group: cls + reg
+// head pairs and the three RFB reduce convs share shapes and run as one launch, blockIdx.y
+// selecting the member).  Non-leading members are skipped when their turn comes.
+void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st = nullptr) {
+  if (!st) st = tl_cur->stream;
+  const Layer& L = m->layers[i];
+  if (L.kind == kKindFusedAway && !L.materialize) return;
+  if (L.leader != i) return;  // issued with its group leader
+  ConvArgs args[3];
+  int n = 0, dw_stride = 1;
+  std::string names;
+  double bytes = 0, flops = 0;
+  for (int j : L.group) {
+    if (j < 0) continue;
+    const Layer& M = m->layers[j];
+    args[n++] = layer_args(m, j, f0, count, &dw_stride);
+    names += (names.empty() ? "" : "+") + std::string(M.spec.name);
+    bytes += M.bytes_per_frame * count + M.weight_bytes;
+    flops += M.flops_per_frame * count;
+  }
+  ConvArgs& a = args[0];
   bool use_rows = false;
   const char* kind = "conv_direct_full";
   switch (L.kind) {
     case kKindPointwise: kind = "conv_pw_mfma"; break;
-    case kKindDwPw: {
-      const Layer& D = m->layers[L.fused_dw];
-      kind = "conv_dwpw_mfma";
-      a.in = in_ptr(D.in_tensor, D.ih, D.iw);
-      a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
-      a.ih = D.ih, a.iw = D.iw;
-      a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
-      dw_stride = D.spec.stride;
-      break;
-    }
+    case kKindDwPw: kind = "conv_dwpw_mfma"; break;
     case kKindConv3x3:
-      use_rows = conv3x3_rows_supported(a) && !(std::getenv("UFD_NO_ROWS"));
+      use_rows = n == 1 && conv3x3_rows_supported(a);
       kind = use_rows ? "conv3x3_rows_mfma" : "conv3x3_mfma";
       break;
     case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
     case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
-  ProfScope ps(m, std::string(kind) + ":" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
-               L.flops_per_frame * count, st);
+  ProfScope ps(m, std::string(kind) + ":" + names, bytes, flops, st);
   switch (L.kind) {
-    case kKindPointwise: launch_conv_pointwise_mfma(a, st); break;
-    case kKindDwPw: launch_conv_dwpw_mfma(a, dw_stride, st); break;
+    case kKindPointwise: launch_conv_pointwise_mfma(args, n, st); break;
+    case kKindDwPw: launch_conv_dwpw_mfma(args, n, dw_stride, st); break;
     case kKindConv3x3:
       if (use_rows) {
         a.w = L.d_w_rows;
         launch_conv3x3_rows_mfma(a, st);
       } else {
-        launch_conv3x3_mfma(a, st);
+        launch_conv3x3_mfma(args, n, st);
       }
       break;
     default: launch_conv_direct(a, st); break;
