@@ -39,6 +39,7 @@ KERNEL_FUNCS = {
     "resize_norm": "k_resize_norm",
     "head_decode": "k_head_decode",
     "huffman_rst": "k_huffman_rst",
+    "huffman_sync": "k_huffman_sync",
     "sort_nms": "k_sort_nms",
 }
 
@@ -51,6 +52,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
+    ap.add_argument("--entropy", choices=["host", "device"], default="host",
+                    help="where the Huffman stage runs (device: self-synchronising decoder, JPEG bytes over PCIe)")
     ap.add_argument("--restart-rows", type=int, default=0,
                     help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
                          ">0: restart-interval stream, entropy decoding on the GPU)")
@@ -108,7 +111,7 @@ def main():
     jpegs = synth.synth_jpeg_pool(rank, args.pool, W, H, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
     model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
                               weights=weights, priors=priors, max_src=(W, H), host_threads=args.host_threads,
-                              profile=True, det_cap=256, device_entropy=args.restart_rows > 0)
+                              profile=True, det_cap=256, device_entropy=args.restart_rows > 0 or args.entropy == "device")
     nb = max(1, args.pool // B)
     batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
 
@@ -183,9 +186,11 @@ def main():
             "config": {"workload": "UltraFace-640, one 640x480 synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
                                    "frames, %s), batch=%d, seeded synthetic weights" % (
                                        args.pool, "DRI = %d MCU row(s): entropy decode on GPU" % args.restart_rows
-                                       if args.restart_rows else "no restart markers: entropy decode on host workers", B),
+                                       if args.restart_rows else "no restart markers: entropy decode on %s" % (
+                                           "GPU (self-synchronising decoder)" if args.entropy == "device" else "host workers"), B),
                        "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
-                       "timed_region": "host JPEG bytes -> host detections (host Huffman + PCIe included)",
+                       "timed_region": "host JPEG bytes -> host detections (%s + PCIe included)" % (
+                           "JPEG bytes H2D" if args.entropy == "device" or args.restart_rows else "host Huffman"),
                        "async_depth": args.depth},
             "roofline": roof,
             "gpu_ms_per_step": round(gpu_ms / prof_steps, 3),

@@ -479,8 +479,11 @@ struct Decoder {
 
   // Marker scan of one interleaved baseline scan with restart intervals: no bit is decoded.
   int plan_scan(const Scan& sc, const uint8_t* base, const uint8_t* p, const uint8_t* end) {
-    const int ri = d->restart_interval;
-    if (d->progressive || sc.ns != d->ncomp || ri <= 0) return kJpegNotEligible;
+    // without restart markers the whole scan is one interval (self-synchronising device decoder)
+    const long total_mcus = (long)d->mcux * d->mcuy;
+    const long ri = d->restart_interval > 0 ? d->restart_interval : total_mcus;
+    if (d->progressive || sc.ns != d->ncomp || total_mcus <= 0) return kJpegNotEligible;
+    if (d->ncomp == 1 && (d->h[0] != 1 || d->v[0] != 1)) return kJpegNotEligible;  // non-interleaved MCU = one block
     std::memset(&plan->scan, 0, sizeof(plan->scan));
     // table slots: at most 2 distinct DC and 2 distinct AC tables
     int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
@@ -514,7 +517,6 @@ struct Decoder {
       if (dc_ids[i] >= 0) export_lut(dc[dc_ids[i]], &plan->luts[i]);
       if (ac_ids[i] >= 0) export_lut(ac[ac_ids[i]], &plan->luts[2 + i]);
     }
-    const long total_mcus = (long)d->mcux * d->mcuy;
     const long n_iv = (total_mcus + ri - 1) / ri;
     if (n_iv > GpuScanPlan::kMaxIntervals) return kJpegNotEligible;
     // walk the entropy-coded segment: 0xFF00 = stuffing, 0xFFFF.. = fill, 0xFFD0-D7 = RSTn
@@ -545,7 +547,7 @@ struct Decoder {
       iv.nmcu = (uint32_t)std::min<long>(ri, total_mcus - k * ri);
       k++;
       if (m >= 0xD0 && m <= 0xD7) {
-        if (m != 0xD0 + next_rst) return kJpegCorrupt;
+        if (m != 0xD0 + next_rst || d->restart_interval <= 0) return kJpegCorrupt;
         next_rst = (next_rst + 1) & 7;
         begin = (uint32_t)(f + 2 - base);
         q = f + 2;

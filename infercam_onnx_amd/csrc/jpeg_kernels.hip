@@ -74,6 +74,14 @@ __device__ __forceinline__ void idct_1d(const int (&x)[8], int (&o)[8], int shif
   o[4] = descale(tmp13 - tmp0, shift);
 }
 
+// natural (row-major) coefficient index -> position in zigzag order
+__constant__ uint8_t c_nat_to_zig[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                         41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                         46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// ZZ: the blocks hold their coefficients in zigzag order (device entropy decoder without restart
+// markers) instead of natural order.
+template <bool ZZ>
 __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ descs, const int16_t* __restrict__ coef,
                                               size_t coef_stride, uint8_t* __restrict__ planes, size_t plane_stride) {
   __shared__ __attribute__((aligned(16))) int16_t s_in[kBlocksPerWG * 64];
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ 
       const uint16_t* q = d.qt[comp];
       int x[8], o[8];
 #pragma unroll
-      for (int r = 0; r < 8; r++) x[r] = (int)s_in[lb * 64 + r * 8 + c] * (int)q[r * 8 + c];
+      for (int r = 0; r < 8; r++) x[r] = (int)s_in[lb * 64 + (ZZ ? (int)c_nat_to_zig[r * 8 + c] : r * 8 + c)] * (int)q[r * 8 + c];
       idct_1d(x, o, 11);  // CONST_BITS - PASS1_BITS
 #pragma unroll
       for (int r = 0; r < 8; r++) s_ws[lb * kWsStride + r * 8 + c] = o[r];
@@ -350,10 +358,13 @@ __global__ __launch_bounds__(256) void k_upsample_norm_420(const JpegFrameDesc* 
 }  // namespace
 
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
-                 size_t plane_stride, uint32_t max_blocks, uint32_t count, hipStream_t s) {
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s) {
   if (!count || !max_blocks) return;
   dim3 grid((max_blocks + kBlocksPerWG - 1) / kBlocksPerWG, count);
-  hipLaunchKernelGGL(k_idct, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
+  if (zigzag)
+    hipLaunchKernelGGL(k_idct<true>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
+  else
+    hipLaunchKernelGGL(k_idct<false>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
 }
 
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,

@@ -13,7 +13,7 @@ namespace ufd {
 // ---------------- A1: JPEG reconstruction (jpeg_kernels.hip) ----------------
 // Dequantise + ISLOW IDCT of every 8x8 block of `count` frames into u8 sample planes.
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
-                 size_t plane_stride, uint32_t max_blocks, uint32_t count, hipStream_t s);
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s);
 // Fancy upsampling + colour conversion -> interleaved RGB8 (pitch 3*width, frame stride rgb_stride).
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
                          size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s);
@@ -28,6 +28,57 @@ void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes,
 void launch_huffman_rst(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t n_iv,
                         const HuffLut* d_luts, const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride,
                         uint32_t* d_status, hipStream_t s);
+// Streams without restart markers: self-synchronising subsequence decoding with speculation over
+// the block index (huffman_kernels.hip).  ivs[f] = the frame's single interval, nmcu = 0 skips the
+// frame.  SyncBuffers is device scratch of one context, carved from one allocation.
+// Per table set: the four lookup tables plus their state-only form (bits consumed by code word and
+// magnitude | zigzag advance << 5; 0 = code word longer than the lookup).  Built on the host when a
+// new table set is first seen (build_sync_lut_image), copied to LDS by every decoding block.
+struct SyncLutImage {
+  HuffLut lut[4];
+  uint16_t step[4][1024];
+};
+// State-only step of a symbol.  A DC symbol advances the zigzag index 0 -> 1, an AC coefficient by
+// run + 1, ZRL by 16 and EOB to 64, so the decoder state update is "z += dz" for all of them.
+__host__ __device__ inline uint16_t sync_step(int len, int sym, bool is_dc) {
+  const int sz = sym & 15, run = sym >> 4;
+  const int dz = is_dc ? 1 : (sz ? run + 1 : (run == 15 ? 16 : 64));
+  return (uint16_t)((len + sz) | (dz << 5));
+}
+inline void build_sync_lut_image(const HuffLut* luts /*[4]: dc0 dc1 ac0 ac1*/, SyncLutImage* out) {
+  for (int t = 0; t < 4; t++) {
+    out->lut[t] = luts[t];
+    for (int i = 0; i < 1024; i++) {
+      const int e = luts[t].fast[i];
+      out->step[t][i] = e ? sync_step(e >> 8, e & 0xFF, t < 2) : (uint16_t)0;
+    }
+  }
+}
+constexpr int kSyncMaxSub = 4096;  // subsequences per frame (longer streams get longer subsequences)
+struct SyncFrame {
+  uint32_t total_bits, nsub, sub_bits, pad;
+};
+struct SyncBuffers {
+  uint8_t* stream = nullptr;  // unstuffed entropy-coded segment per frame
+  size_t stream_stride = 0;
+  SyncFrame* frames = nullptr;
+  uint2* ent = nullptr;    // [frame][subsequence][slot] cached entry states (bit position, block | zigzag << 8)
+  uint2* ext = nullptr;    // ... their exit states
+  int* nm = nullptr;       // ... MCUs completed in between
+  uint8_t* cnt = nullptr;  // [2][frame][subsequence] cached pairs (double-buffered across rounds)
+  uint2* start = nullptr;  // [frame][subsequence] true entry state
+  int* mcu0 = nullptr;     // [frame][subsequence] first MCU
+  unsigned long long* map = nullptr;  // [frame][subsequence] slot -> slot of the next subsequence, 16 nibbles
+  uint32_t max_frames = 0;
+};
+// Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
+size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers* layout);
+// Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
+void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, hipStream_t s);
+void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
+                         uint32_t max_raw_bytes, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
+                         const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
+                         uint32_t* d_status, hipStream_t s);
 
 // 4:2:0 YCbCr specialisation (every frame of the batch: 3 components, 2x2 luma sampling, fancy
 // upsampling applicable, W % 8 == 0): same results, 8 pixels per thread with wide loads.

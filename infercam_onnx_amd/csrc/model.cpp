@@ -92,6 +92,7 @@ struct Slot {
   HuffInterval* h_ivs = nullptr;
   std::vector<GpuScanPlan> plans;
   bool gpu_entropy = false;
+  bool coef_zigzag = false;  // the slabs hold zigzag-ordered blocks (self-synchronising decoder)
   ufd_det* out = nullptr;
   uint32_t* n = nullptr;
   int32_t* status = nullptr;
@@ -134,6 +135,8 @@ struct Ctx {
   uint8_t* d_blob_buf[2] = {nullptr, nullptr};
   HuffScan* d_scans_buf[2] = {nullptr, nullptr};
   HuffInterval* d_ivs_buf[2] = {nullptr, nullptr};
+  uint8_t* d_sync = nullptr;  // scratch of the self-synchronising entropy decoder
+  SyncBuffers sync;
   uint32_t* d_status = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   bool consumed_valid[2] = {false, false};
@@ -199,6 +202,7 @@ struct ufd_model {
   static constexpr int kMaxLutSets = 16;
   std::vector<std::array<HuffLut, 4>> lut_sets;
   HuffLut* d_luts = nullptr;
+  SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool gpu_entropy_enabled = true;
@@ -861,6 +865,11 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
   const size_t idx = m->lut_sets.size();
   // rare (once per camera stream): blocking copy into an unused slot of the shared table array
   if (hipMemcpy(m->d_luts + idx * 4, set.data(), sizeof(HuffLut) * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  {
+    std::unique_ptr<SyncLutImage> img(new SyncLutImage);
+    build_sync_lut_image(set.data(), img.get());
+    if (hipMemcpy(m->d_sync_luts + idx, img.get(), sizeof(SyncLutImage), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  }
   m->lut_sets.push_back(set);
   return (int)idx;
 }
@@ -882,17 +891,30 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
       s.st[i] = st;
     });
     uint32_t n_iv = 0;
+    bool sync_path = true;  // no frame carries restart markers: self-synchronising decoder
     for (uint32_t i = 0; i < count && device_path; i++) {
       if (s.st[i] == kJpegNotEligible) device_path = false;
-      if (s.st[i] == kJpegOk) n_iv += s.plans[i].n_intervals;
+      if (s.st[i] == kJpegOk) {
+        n_iv += s.plans[i].n_intervals;
+        if (s.h_descs[i].restart_interval > 0) sync_path = false;
+      }
     }
-    if (n_iv > m->iv_cap) device_path = false;
+    if (!sync_path) {
+      // the restart-interval kernel needs every frame to carry restart markers
+      for (uint32_t i = 0; i < count && device_path; i++)
+        if (s.st[i] == kJpegOk && s.h_descs[i].restart_interval <= 0) device_path = false;
+      if (n_iv > m->iv_cap) device_path = false;
+    }
     if (!device_path && std::getenv("UFD_DEBUG")) std::fprintf(stderr, "[ufd] batch not eligible for device entropy decoding (n_iv %u)\n", n_iv);
     if (device_path) {
       uint32_t k = 0;
       HuffScan ref_scan{};
       bool have_ref = false;
       for (uint32_t i = 0; i < count && device_path; i++) {
+        if (sync_path) {
+          HuffInterval none{};
+          s.h_ivs[i] = none;  // nmcu = 0: the frame's workgroup exits at once
+        }
         if (s.st[i] != kJpegOk) continue;
         const int set = lut_set_for(m, s.plans[i].luts);
         if (set < 0) {
@@ -902,17 +924,10 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         HuffScan sc = s.plans[i].scan;
         sc.blob_off = 0;
         sc.lut_base = (uint32_t)set * 4;
-        // the kernel keeps ONE table set and MCU layout per wave in LDS: batches that mix them
-        // (different cameras in one batch) are decoded on the host instead
-        if (have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) {
-          if (std::getenv("UFD_DEBUG")) {
-            std::fprintf(stderr, "[ufd] frame %u: scan layout/table set differs from the batch's first frame (lut %u vs %u, bpm %u vs %u)\n",
-                         i, sc.lut_base, ref_scan.lut_base, sc.blocks_per_mcu, ref_scan.blocks_per_mcu);
-            const unsigned char* a = reinterpret_cast<const unsigned char*>(&sc);
-            const unsigned char* b = reinterpret_cast<const unsigned char*>(&ref_scan);
-            for (size_t q = 0; q < sizeof(sc); q++)
-              if (a[q] != b[q]) std::fprintf(stderr, "  byte %zu: %u vs %u\n", q, a[q], b[q]);
-          }
+        // the restart-interval kernel keeps ONE table set and MCU layout per wave in LDS: batches
+        // that mix them (different cameras in one batch) are decoded on the host instead; the
+        // self-synchronising kernel loads them per frame
+        if (!sync_path && have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) {
           device_path = false;
           break;
         }
@@ -920,12 +935,19 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         have_ref = true;
         sc.blob_off = (uint32_t)(i * m->blob_stride);
         s.h_scans[i] = sc;
-        for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
-          HuffInterval iv = s.plans[i].iv[j];
+        if (sync_path) {
+          HuffInterval iv = s.plans[i].iv[0];
           iv.frame = i;
-          s.h_ivs[k++] = iv;
+          s.h_ivs[i] = iv;
+        } else {
+          for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
+            HuffInterval iv = s.plans[i].iv[j];
+            iv.frame = i;
+            s.h_ivs[k++] = iv;
+          }
         }
       }
+      if (sync_path) k = count;
       if (device_path) {
         tl_pool->parallel_for(count, [&](unsigned i) {
           if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
@@ -943,6 +965,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
           s.st[i] = status_from_jpeg(s.st[i]);
         }
         s.gpu_entropy = true;
+        s.coef_zigzag = sync_path;
         *any_ok_out = any_ok;
         if (!any_ok) return UFD_OK;
         const int buf = c.flip;
@@ -959,10 +982,20 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         }
         HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
         // zero the slabs while the bytes are still in flight, then decode
-        HIPC(m, hipMemset2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, 0, used_coef * 2, count, c.stream));
+        launch_zero_coef(c.d_coef_buf[buf], m->coef_stride, used_coef, count, c.stream);
         HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
         HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
-        {
+        if (sync_path) {
+          ProfScope ps(m, "huffman_sync", (double)used_blob * count, 0);
+          uint32_t max_raw = 0, max_bpm = 1;
+          for (uint32_t i = 0; i < count; i++) {
+            if (s.h_ivs[i].nmcu == 0) continue;
+            max_raw = std::max(max_raw, s.h_ivs[i].end - s.h_ivs[i].begin);
+            max_bpm = std::max(max_bpm, s.h_scans[i].blocks_per_mcu);
+          }
+          launch_huffman_sync(c.d_blob_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf], count, max_raw, max_bpm, m->d_sync_luts,
+                              c.d_descs_buf[buf], c.d_coef_buf[buf], m->coef_stride, c.sync, c.d_status, c.stream);
+        } else {
           ProfScope ps(m, "huffman_rst", (double)used_blob * count, 0);
           launch_huffman_rst(c.d_blob_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf], k, m->d_luts, c.d_descs_buf[buf],
                              c.d_coef_buf[buf], m->coef_stride, c.d_status, c.stream);
@@ -973,6 +1006,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   }
   // ---- host entropy decoding
   s.gpu_entropy = false;
+  s.coef_zigzag = false;
   tl_pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_decode_coefficients(jpegs[i], lens[i], d, s.h_coef + (size_t)i * m->coef_stride,
@@ -1030,7 +1064,7 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     int16_t* d_coef = tl_cur->d_coef_buf[buf];
     {
       ProfScope ps(m, "idct", 0, 0);
-      launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, tl_cur->stream);
+      launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream);
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
@@ -1193,7 +1227,7 @@ void destroy(ufd_model* m) {
   auto dfree = [](void* p) {
     if (p) (void)hipFree(p);
   };
-  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_luts);
+  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_luts), dfree(m->d_sync_luts);
   for (Ctx& c : m->ctx) {
     dfree(c.d_arena), dfree(c.d_input), dfree(c.d_status);
     for (int i = 0; i < 2; i++) {
@@ -1202,7 +1236,7 @@ void destroy(ufd_model* m) {
       if (c.ev_copied[i]) (void)hipEventDestroy(c.ev_copied[i]);
       if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
     }
-    dfree(c.d_planes), dfree(c.d_rgb);
+    dfree(c.d_planes), dfree(c.d_rgb), dfree(c.d_sync);
     dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_dets), dfree(c.d_ndet);
     dfree(c.d_spill);
   }
@@ -1371,6 +1405,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->iv_cap = (uint32_t)B * 160;
   m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
   HIPB(hipMalloc(&m->d_luts, sizeof(HuffLut) * 4 * ufd_model::kMaxLutSets));
+  HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];
     HIPB(hipMalloc(&c.d_status, sizeof(uint32_t) * B));
@@ -1385,6 +1420,11 @@ int create(const ufd_config* cfg, ufd_model** out) {
       HIPB(hipMalloc(&c.d_ivs_buf[i], sizeof(HuffInterval) * m->iv_cap));
       HIPB(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
       HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
+    }
+    if (m->gpu_entropy_enabled) {
+      HIPB(hipMalloc(&c.d_sync, sync_buffers_bytes((uint32_t)B, m->blob_stride, nullptr)));
+      c.sync.stream = c.d_sync;
+      sync_buffers_bytes((uint32_t)B, m->blob_stride, &c.sync);
     }
     HIPB(hipMalloc(&c.d_planes, m->plane_stride * B));
     HIPB(hipMalloc(&c.d_rgb, m->rgb_stride * B));
@@ -1610,7 +1650,7 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
     const size_t bytes = (size_t)d->width * d->height * 3;
     if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
     launch_idct(tl_cur->d_descs_buf[buf], tl_cur->d_coef_buf[buf], m->coef_stride, tl_cur->d_planes, m->plane_stride,
-                d->total_blocks, 1, tl_cur->stream);
+                d->total_blocks, 1, s->coef_zigzag, tl_cur->stream);
     launch_upsample_rgb(tl_cur->d_descs_buf[buf], tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, d->width,
                         d->height, 1, tl_cur->stream);
     HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));

@@ -220,13 +220,71 @@ def test_device_entropy_decode_bit_exact(model320_dev, oracle_lib, size, subsamp
         assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (size, subsampling, kw)
 
 
+@pytest.mark.parametrize("size", [(640, 480), (641, 479), (1280, 720), (17, 9), (8, 8), (320, 240)])
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2", "4:4:4"])
+def test_device_sync_decoder_bit_exact(model320_dev, oracle_lib, size, subsampling):
+    """Streams without restart markers take the self-synchronising device decoder: same pixels
+    as the oracle at every quality (long and short symbols, optimised tables, noise)."""
+    from infercam_onnx_amd import synth
+
+    w, h = size
+    rgb = synth.synth_frame(13, w * 5 + h, w, h)
+    noise = np.random.default_rng(w * h).integers(0, 256, size=rgb.shape, dtype=np.uint8)
+    for img, kw in ((rgb, {}), (rgb, {"quality": 30}), (rgb, {"quality": 100}), (rgb, {"optimize": True}),
+                    (noise, {"quality": 95}), (np.zeros_like(rgb), {})):
+        jpeg = synth.encode_jpeg(img, subsampling=subsampling, **kw)
+        assert b"\xff\xdd" not in jpeg  # no DRI
+        got = model320_dev.debug_decode_jpeg(jpeg)
+        assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (size, subsampling, kw)
+
+
+def test_device_sync_decoder_grayscale_and_coefficients(model320_dev, oracle_lib):
+    from PIL import Image
+    import io
+    from infercam_onnx_amd import synth
+
+    rgb = synth.synth_frame(14, 3, 333, 217)
+    buf = io.BytesIO()
+    Image.fromarray(rgb).convert("L").save(buf, format="JPEG", quality=85)
+    jpeg = buf.getvalue()
+    got = model320_dev.debug_decode_jpeg(jpeg)
+    assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg))
+
+
+def test_device_sync_decoder_is_the_path_taken(weights):
+    """The profile names the kernels that ran: the sync decoder, not the host Huffman copy."""
+    from infercam_onnx_amd import synth
+
+    m = make_model(640, weights, max_batch=4, device_entropy=True, profile=True)
+    try:
+        jpegs = [synth.encode_jpeg(synth.synth_frame(75, i, 640, 480)) for i in range(4)]
+        m.profile_reset()
+        _, st = m.infer_jpeg_batch(jpegs)
+        assert st == [0] * 4
+        names = {p["name"] for p in m.profile_read()}
+        assert "huffman_sync" in names and "h2d_coef" not in names, names
+    finally:
+        m.close()
+
+
+def test_device_sync_decoder_truncated_stream_is_flagged(model640_dev, oracle_lib):
+    from infercam_onnx_amd import nn, synth
+
+    good = synth.encode_jpeg(synth.synth_frame(76, 0, 640, 480))
+    cut = good[: len(good) // 2] + b"\xff\xd9"  # half the scan data, then EOI
+    res, status = model640_dev.infer_jpeg_batch([good, cut, good])
+    assert status[0] == 0 and status[2] == 0 and res[0] == res[2]
+    assert status[1] == nn.UFD_E_DECODE
+
+
 def test_device_entropy_end_to_end_matches_host_entropy(model640, model640_dev, oracle_lib, weights):
     from infercam_onnx_amd import synth
 
-    jpegs = [synth.encode_jpeg(synth.synth_frame(73, i, 640, 480), restart_rows=1) for i in range(6)]
-    host, st_h = model640.infer_jpeg_batch(jpegs)
-    dev, st_d = model640_dev.infer_jpeg_batch(jpegs)
-    assert st_h == st_d == [0] * 6 and host == dev  # same batch size, same kernels: bit-identical
+    for kw in ({"restart_rows": 1}, {}):
+        jpegs = [synth.encode_jpeg(synth.synth_frame(73, i, 640, 480), **kw) for i in range(6)]
+        host, st_h = model640.infer_jpeg_batch(jpegs)
+        dev, st_d = model640_dev.infer_jpeg_batch(jpegs)
+        assert st_h == st_d == [0] * 6 and host == dev  # same batch size, same kernels: bit-identical
     prof = [p["name"] for p in model640_dev.profile_read()] if False else None  # (profiling is per-handle opt-in)
 
 
