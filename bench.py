@@ -52,8 +52,14 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
-    ap.add_argument("--entropy", choices=["host", "device"], default="host",
-                    help="where the Huffman stage runs (device: self-synchronising decoder, JPEG bytes over PCIe)")
+    ap.add_argument("--input", choices=["hbm", "host"], default="hbm",
+                    help="hbm: the JPEG bytes of every batch are staged in HBM before the clock starts "
+                         "(ufd_stage_jpeg_batch / ufd_submit_staged; implies --entropy device); "
+                         "host: the timed region starts from host buffers (PCIe-inclusive)")
+    ap.add_argument("--entropy", choices=["host", "device"], default="device",
+                    help="where the Huffman stage runs (device: self-synchronising decoder kernels; "
+                         "host: worker threads, coefficient slabs over PCIe)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the PCIe-inclusive comparison runs")
     ap.add_argument("--restart-rows", type=int, default=0,
                     help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
                          ">0: restart-interval stream, entropy decoding on the GPU)")
@@ -109,22 +115,32 @@ def main():
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
     jpegs = synth.synth_jpeg_pool(rank, args.pool, W, H, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
+    device_entropy = args.restart_rows > 0 or args.entropy == "device" or args.input == "hbm"
     model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
                               weights=weights, priors=priors, max_src=(W, H), host_threads=args.host_threads,
-                              profile=True, det_cap=256, device_entropy=args.restart_rows > 0 or args.entropy == "device")
+                              profile=True, det_cap=256, device_entropy=device_entropy)
     nb = max(1, args.pool // B)
-    batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+    if args.input == "hbm":
+        # inputs resident in HBM before the clock starts: bytes + parsed headers of every batch
+        batches = [model.stage_jpeg_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+    else:
+        batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+    depth = min(args.depth, nb) if args.input == "hbm" else args.depth  # a staged batch is in flight once at a time
 
-    def run_steps(k):
+    def run_steps(k, mdl=None, bts=None, staged=None):
+        mdl = mdl or model
+        bts = bts or batches
+        staged = (args.input == "hbm") if staged is None else staged
         inflight = []
         dets = 0
         for s in range(k):
-            if len(inflight) >= args.depth:
-                cnt, _ = model.wait(inflight.pop(0), collect=False)
+            if len(inflight) >= depth:
+                cnt, _ = mdl.wait(inflight.pop(0), collect=False)
                 dets += sum(cnt)
-            inflight.append(model.submit_jpeg_batch(batches[s % nb]))
+            b = bts[s % len(bts)]
+            inflight.append(mdl.submit_staged(b) if staged else mdl.submit_jpeg_batch(b))
         for t in inflight:
-            cnt, _ = model.wait(t, collect=False)
+            cnt, _ = mdl.wait(t, collect=False)
             dets += sum(cnt)
         return dets
 
@@ -143,6 +159,29 @@ def main():
     el = time.perf_counter() - t0
     el = parallel.max_over_ranks(el, dist, device=torch.device("cuda", local_rank))
     stats = model.profile_read()
+
+    # ---- the same workload over the reference's own boundary (host buffers in, PCIe inside the
+    # timed region): reported beside `value`, never as `value`
+    variants = {}
+    if world == 1 and args.input == "hbm" and not args.no_variants:
+        hb = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+        run_steps(args.warmup, bts=hb, staged=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, bts=hb, staged=False)
+        torch.cuda.synchronize()
+        variants["host_bytes_device_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
+        m2 = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
+                               priors=priors, max_src=(W, H), host_threads=args.host_threads, det_cap=256,
+                               device_entropy=False)
+        hb2 = [m2._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+        run_steps(args.warmup, mdl=m2, bts=hb2, staged=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, mdl=m2, bts=hb2, staged=False)
+        torch.cuda.synchronize()
+        variants["host_bytes_host_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
+        m2.close()
 
     if rank == 0:
         frames = world * B * args.steps
@@ -185,13 +224,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UltraFace-640, one 640x480 synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
                                    "frames, %s), batch=%d, seeded synthetic weights" % (
-                                       args.pool, "DRI = %d MCU row(s): entropy decode on GPU" % args.restart_rows
-                                       if args.restart_rows else "no restart markers: entropy decode on %s" % (
-                                           "GPU (self-synchronising decoder)" if args.entropy == "device" else "host workers"), B),
+                                       args.pool, "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows
+                                       else "no restart markers", B),
                        "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
-                       "timed_region": "host JPEG bytes -> host detections (%s + PCIe included)" % (
-                           "JPEG bytes H2D" if args.entropy == "device" or args.restart_rows else "host Huffman"),
-                       "async_depth": args.depth},
+                       "entropy_decode": "GPU kernels" if device_entropy else "host worker threads",
+                       "timed_region": ("JPEG bytes resident in HBM (headers parsed at staging) -> detections in host memory"
+                                        if args.input == "hbm" else
+                                        "host JPEG bytes -> host detections (%s + PCIe included)" % (
+                                            "JPEG bytes H2D" if device_entropy else "host Huffman, coefficient slabs H2D")),
+                       "async_depth": depth, "pcie_inclusive": variants or None},
             "roofline": roof,
             "gpu_ms_per_step": round(gpu_ms / prof_steps, 3),
             "kernels_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},

@@ -115,6 +115,21 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
                           ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket);
 int ufd_wait(ufd_model* m, uint32_t ticket);
 
+/* Device-resident input.  ufd_stage_jpeg_batch parses the headers of `count` JPEGs on the host
+ * and places their bytes, frame descriptors and scan plans in HBM (blocking; needs
+ * UFD_FLAG_DEVICE_ENTROPY; UFD_E_UNSUPPORTED if a frame cannot take the device entropy decoder).
+ * ufd_submit_staged then runs the whole path -- entropy decode, IDCT, upsampling, colour,
+ * normalisation, the network, NMS -- from those HBM buffers: no input crosses PCIe, only the
+ * detections come back.  Same ticket / ufd_wait protocol and outputs as ufd_submit_jpeg_batch
+ * (the reference has no such call: its ring slots are host Vec<u8>, lib.rs:32; this is the form a
+ * capture card or NIC writing straight into GPU memory would use, and the one bench.py times).
+ * A staged batch may be submitted any number of times; free it after its last ufd_wait. */
+typedef struct ufd_staged ufd_staged;
+int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_staged** staged);
+int ufd_submit_staged(ufd_model* m, const ufd_staged* staged, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status,
+                      uint32_t* ticket);
+void ufd_staged_free(ufd_model* m, ufd_staged* staged);
+
 /* ---- stage taps (parity tests call the path stage by stage through these) ---- */
 /* A1 only: decode on the GPU and copy the interleaved RGB8 frame back (cap_bytes >= h*w*3). */
 int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes,

@@ -102,6 +102,7 @@ struct Slot {
   // asynchronous submission: the context's worker thread issues the batch
   const uint8_t* const* job_jpegs = nullptr;
   const size_t* job_lens = nullptr;
+  const ufd_staged* job_staged = nullptr;  // non-null: the batch is resident in HBM
   bool job_prof = true;
   int issue_rc = 0;          // result of the worker's entropy stage + enqueue
   std::string issue_err;
@@ -227,6 +228,30 @@ struct ufd_model {
     return code;
   }
 };
+
+struct DevicePlan {
+  bool ok = false;         // every decodable frame of the batch can take the device decoder
+  bool sync_path = false;  // no restart markers: self-synchronising decoder (else one lane per interval)
+  bool any_ok = false;
+  uint32_t n_iv = 0;       // intervals in h_ivs
+  size_t used_blob = 0, used_coef = 0;
+  uint32_t max_raw = 0, max_bpm = 1;
+};
+
+
+// A batch whose JPEG bytes, frame descriptors and scan plans are resident in HBM
+// (ufd_stage_jpeg_batch): submitting it moves no input over PCIe.
+struct ufd_staged {
+  uint32_t count = 0;
+  DevicePlan plan;
+  std::vector<JpegFrameDesc> h_descs;
+  std::vector<int32_t> st;
+  uint8_t* d_blob = nullptr;
+  JpegFrameDesc* d_descs = nullptr;
+  HuffScan* d_scans = nullptr;
+  HuffInterval* d_ivs = nullptr;
+};
+
 
 namespace {
 
@@ -874,134 +899,139 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
   return (int)idx;
 }
 
+// Host half of the device entropy path: header / marker scan of every frame (no bit is decoded),
+// scan layouts, table sets and intervals into the slot's pinned arrays, JPEG bytes into h_blob.
+DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
+  DevicePlan p;
+  tl_pool->parallel_for(count, [&](unsigned i) {
+    JpegFrameDesc* d = &s.h_descs[i];
+    int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
+    if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
+    if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
+    s.st[i] = st;
+  });
+  bool device_path = true;
+  uint32_t n_iv = 0;
+  bool sync_path = true;  // no frame carries restart markers: self-synchronising decoder
+  for (uint32_t i = 0; i < count && device_path; i++) {
+    if (s.st[i] == kJpegNotEligible) device_path = false;
+    if (s.st[i] == kJpegOk) {
+      n_iv += s.plans[i].n_intervals;
+      if (s.h_descs[i].restart_interval > 0) sync_path = false;
+    }
+  }
+  if (!sync_path) {
+    // the restart-interval kernel needs every frame to carry restart markers
+    for (uint32_t i = 0; i < count && device_path; i++)
+      if (s.st[i] == kJpegOk && s.h_descs[i].restart_interval <= 0) device_path = false;
+    if (n_iv > m->iv_cap) device_path = false;
+  }
+  if (!device_path && std::getenv("UFD_DEBUG"))
+    std::fprintf(stderr, "[ufd] batch not eligible for device entropy decoding (n_iv %u)\n", n_iv);
+  if (!device_path) return p;
+  uint32_t k = 0;
+  HuffScan ref_scan{};
+  bool have_ref = false;
+  for (uint32_t i = 0; i < count; i++) {
+    if (sync_path) {
+      HuffInterval none{};
+      s.h_ivs[i] = none;  // nmcu = 0: the frame's workgroup exits at once
+    }
+    if (s.st[i] != kJpegOk) continue;
+    const int set = lut_set_for(m, s.plans[i].luts);
+    if (set < 0) return p;
+    HuffScan sc = s.plans[i].scan;
+    sc.blob_off = 0;
+    sc.lut_base = (uint32_t)set * 4;
+    // the restart-interval kernel keeps ONE table set and MCU layout per wave in LDS: batches
+    // that mix them (different cameras in one batch) are decoded on the host instead; the
+    // self-synchronising kernels load them per frame
+    if (!sync_path && have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) return p;
+    ref_scan = sc;
+    have_ref = true;
+    sc.blob_off = (uint32_t)(i * m->blob_stride);
+    s.h_scans[i] = sc;
+    if (sync_path) {
+      HuffInterval iv = s.plans[i].iv[0];
+      iv.frame = i;
+      s.h_ivs[i] = iv;
+      p.max_raw = std::max(p.max_raw, iv.end - iv.begin);
+      p.max_bpm = std::max(p.max_bpm, sc.blocks_per_mcu);
+    } else {
+      for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
+        HuffInterval iv = s.plans[i].iv[j];
+        iv.frame = i;
+        s.h_ivs[k++] = iv;
+      }
+    }
+  }
+  if (sync_path) k = count;
+  tl_pool->parallel_for(count, [&](unsigned i) {
+    if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
+  });
+  for (uint32_t i = 0; i < count; i++) {
+    if (s.st[i] == kJpegOk) {
+      p.any_ok = true;
+      p.used_blob = std::max(p.used_blob, (lens[i] + 15) & ~(size_t)15);
+      p.used_coef = std::max(p.used_coef, (size_t)s.h_descs[i].coef_total);
+    } else {
+      std::memset(&s.h_descs[i], 0, sizeof(JpegFrameDesc));
+    }
+    s.st[i] = status_from_jpeg(s.st[i]);
+  }
+  p.ok = true;
+  p.sync_path = sync_path;
+  p.n_iv = k;
+  return p;
+}
+
+// Device half: zeroes the coefficient slabs and decodes into them on the context's stream.  All
+// pointers are device memory (the context's double buffers, or a staged batch).
+int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t count, const uint8_t* d_blob,
+                           const JpegFrameDesc* d_descs, const HuffScan* d_scans, const HuffInterval* d_ivs, int16_t* d_coef) {
+  launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.stream);
+  HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
+  if (p.sync_path) {
+    ProfScope ps(m, "huffman_sync", (double)p.used_blob * count, 0);
+    launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_raw, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
+                        c.sync, c.d_status, c.stream);
+  } else {
+    ProfScope ps(m, "huffman_rst", (double)p.used_blob * count, 0);
+    launch_huffman_rst(d_blob, d_scans, d_ivs, p.n_iv, m->d_luts, d_descs, d_coef, m->coef_stride, c.d_status, c.stream);
+  }
+  return UFD_OK;
+}
+
 // Stage 1 of row A1 for `count` JPEGs: leaves quantised coefficient slabs in d_coef_buf[*buf] and
 // frame descriptors in d_descs_buf[*buf], ordered before later work on the context's stream.
-//   device path: header/marker scan on host workers, JPEG bytes H2D, one lane per restart interval
+//   device path: header/marker scan on host workers, JPEG bytes H2D, entropy decoding kernels
 //   host path:   Huffman decoding on host workers, coefficient slabs H2D
 int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, int* buf_out,
                   bool* any_ok_out) {
   Ctx& c = *tl_cur;
-  bool device_path = m->gpu_entropy_enabled;
-  if (device_path) {
-    tl_pool->parallel_for(count, [&](unsigned i) {
-      JpegFrameDesc* d = &s.h_descs[i];
-      int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
-      if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
-      if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
-      s.st[i] = st;
-    });
-    uint32_t n_iv = 0;
-    bool sync_path = true;  // no frame carries restart markers: self-synchronising decoder
-    for (uint32_t i = 0; i < count && device_path; i++) {
-      if (s.st[i] == kJpegNotEligible) device_path = false;
-      if (s.st[i] == kJpegOk) {
-        n_iv += s.plans[i].n_intervals;
-        if (s.h_descs[i].restart_interval > 0) sync_path = false;
+  if (m->gpu_entropy_enabled) {
+    const DevicePlan p = plan_device_entropy(m, s, jpegs, lens, count);
+    if (p.ok) {
+      s.gpu_entropy = true;
+      s.coef_zigzag = p.sync_path;
+      *any_ok_out = p.any_ok;
+      if (!p.any_ok) return UFD_OK;
+      const int buf = c.flip;
+      c.flip ^= 1;
+      *buf_out = buf;
+      if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
+      HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
+      HIPC(m, hipMemcpyAsync(c.d_scans_buf[buf], s.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice, c.copy_stream));
+      HIPC(m, hipMemcpyAsync(c.d_ivs_buf[buf], s.h_ivs, sizeof(HuffInterval) * p.n_iv, hipMemcpyHostToDevice, c.copy_stream));
+      {
+        ProfScope ps(m, "h2d_jpeg", (double)p.used_blob * count, 0, c.copy_stream);
+        HIPC(m, hipMemcpy2DAsync(c.d_blob_buf[buf], m->blob_stride, s.h_blob, m->blob_stride, p.used_blob, count,
+                                 hipMemcpyHostToDevice, c.copy_stream));
       }
-    }
-    if (!sync_path) {
-      // the restart-interval kernel needs every frame to carry restart markers
-      for (uint32_t i = 0; i < count && device_path; i++)
-        if (s.st[i] == kJpegOk && s.h_descs[i].restart_interval <= 0) device_path = false;
-      if (n_iv > m->iv_cap) device_path = false;
-    }
-    if (!device_path && std::getenv("UFD_DEBUG")) std::fprintf(stderr, "[ufd] batch not eligible for device entropy decoding (n_iv %u)\n", n_iv);
-    if (device_path) {
-      uint32_t k = 0;
-      HuffScan ref_scan{};
-      bool have_ref = false;
-      for (uint32_t i = 0; i < count && device_path; i++) {
-        if (sync_path) {
-          HuffInterval none{};
-          s.h_ivs[i] = none;  // nmcu = 0: the frame's workgroup exits at once
-        }
-        if (s.st[i] != kJpegOk) continue;
-        const int set = lut_set_for(m, s.plans[i].luts);
-        if (set < 0) {
-          device_path = false;
-          break;
-        }
-        HuffScan sc = s.plans[i].scan;
-        sc.blob_off = 0;
-        sc.lut_base = (uint32_t)set * 4;
-        // the restart-interval kernel keeps ONE table set and MCU layout per wave in LDS: batches
-        // that mix them (different cameras in one batch) are decoded on the host instead; the
-        // self-synchronising kernel loads them per frame
-        if (!sync_path && have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) {
-          device_path = false;
-          break;
-        }
-        ref_scan = sc;
-        have_ref = true;
-        sc.blob_off = (uint32_t)(i * m->blob_stride);
-        s.h_scans[i] = sc;
-        if (sync_path) {
-          HuffInterval iv = s.plans[i].iv[0];
-          iv.frame = i;
-          s.h_ivs[i] = iv;
-        } else {
-          for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
-            HuffInterval iv = s.plans[i].iv[j];
-            iv.frame = i;
-            s.h_ivs[k++] = iv;
-          }
-        }
-      }
-      if (sync_path) k = count;
-      if (device_path) {
-        tl_pool->parallel_for(count, [&](unsigned i) {
-          if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
-        });
-        bool any_ok = false;
-        size_t used_blob = 0, used_coef = 0;
-        for (uint32_t i = 0; i < count; i++) {
-          if (s.st[i] == kJpegOk) {
-            any_ok = true;
-            used_blob = std::max(used_blob, (lens[i] + 15) & ~(size_t)15);
-            used_coef = std::max(used_coef, (size_t)s.h_descs[i].coef_total);
-          } else {
-            std::memset(&s.h_descs[i], 0, sizeof(JpegFrameDesc));
-          }
-          s.st[i] = status_from_jpeg(s.st[i]);
-        }
-        s.gpu_entropy = true;
-        s.coef_zigzag = sync_path;
-        *any_ok_out = any_ok;
-        if (!any_ok) return UFD_OK;
-        const int buf = c.flip;
-        c.flip ^= 1;
-        *buf_out = buf;
-        if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
-        HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
-        HIPC(m, hipMemcpyAsync(c.d_scans_buf[buf], s.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice, c.copy_stream));
-        HIPC(m, hipMemcpyAsync(c.d_ivs_buf[buf], s.h_ivs, sizeof(HuffInterval) * k, hipMemcpyHostToDevice, c.copy_stream));
-        {
-          ProfScope ps(m, "h2d_jpeg", (double)used_blob * count, 0, c.copy_stream);
-          HIPC(m, hipMemcpy2DAsync(c.d_blob_buf[buf], m->blob_stride, s.h_blob, m->blob_stride, used_blob, count,
-                                   hipMemcpyHostToDevice, c.copy_stream));
-        }
-        HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
-        // zero the slabs while the bytes are still in flight, then decode
-        launch_zero_coef(c.d_coef_buf[buf], m->coef_stride, used_coef, count, c.stream);
-        HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
-        HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
-        if (sync_path) {
-          ProfScope ps(m, "huffman_sync", (double)used_blob * count, 0);
-          uint32_t max_raw = 0, max_bpm = 1;
-          for (uint32_t i = 0; i < count; i++) {
-            if (s.h_ivs[i].nmcu == 0) continue;
-            max_raw = std::max(max_raw, s.h_ivs[i].end - s.h_ivs[i].begin);
-            max_bpm = std::max(max_bpm, s.h_scans[i].blocks_per_mcu);
-          }
-          launch_huffman_sync(c.d_blob_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf], count, max_raw, max_bpm, m->d_sync_luts,
-                              c.d_descs_buf[buf], c.d_coef_buf[buf], m->coef_stride, c.sync, c.d_status, c.stream);
-        } else {
-          ProfScope ps(m, "huffman_rst", (double)used_blob * count, 0);
-          launch_huffman_rst(c.d_blob_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf], k, m->d_luts, c.d_descs_buf[buf],
-                             c.d_coef_buf[buf], m->coef_stride, c.d_status, c.stream);
-        }
-        return UFD_OK;
-      }
+      HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
+      HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+      return enqueue_device_entropy(m, c, p, count, c.d_blob_buf[buf], c.d_descs_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf],
+                                    c.d_coef_buf[buf]);
     }
   }
   // ---- host entropy decoding
@@ -1041,6 +1071,8 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   return UFD_OK;
 }
 
+int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFrameDesc* d_descs, int16_t* d_coef, int buf);
+
 int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
   int rc = alloc_slot(m, s);
   if (rc) return rc;
@@ -1049,6 +1081,35 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
   bool any_ok = false;
   rc = entropy_stage(m, s, jpegs, lens, count, &buf, &any_ok);
   if (rc) return rc;
+  return run_decoded(m, s, count, any_ok, tl_cur->d_descs_buf[buf], tl_cur->d_coef_buf[buf], buf);
+}
+
+int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
+  int rc = alloc_slot(m, s);
+  if (rc) return rc;
+  Ctx& c = *tl_cur;
+  const uint32_t count = g.count;
+  s.count = count;
+  std::memcpy(s.h_descs, g.h_descs.data(), sizeof(JpegFrameDesc) * count);
+  for (uint32_t i = 0; i < count; i++) s.st[i] = g.st[i];
+  s.gpu_entropy = true;
+  s.coef_zigzag = g.plan.sync_path;
+  int buf = 0;
+  if (g.plan.any_ok) {
+    buf = c.flip;
+    c.flip ^= 1;
+    // the slab is written on the context's own stream: ordered behind its previous readers; a
+    // host-path batch that reuses it later waits for ev_consumed as usual
+    rc = enqueue_device_entropy(m, c, g.plan, count, g.d_blob, g.d_descs, g.d_scans, g.d_ivs, c.d_coef_buf[buf]);
+    if (rc) return rc;
+  }
+  return run_decoded(m, s, count, g.plan.any_ok, g.d_descs, c.d_coef_buf[buf], buf);
+}
+
+// Coefficient slabs -> detections: IDCT, upsampling + colour + normalisation (+ resize), the
+// network, head decode, NMS and the result copy, all on the context's stream.
+int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFrameDesc* d_descs_in, int16_t* d_coef_in, int buf) {
+  int rc = UFD_OK;
   uint32_t max_blocks = 0, mw = 0, mh = 0;
   bool all_model_size = true;
   for (uint32_t i = 0; i < count; i++) {
@@ -1060,8 +1121,8 @@ int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_
     if (d.width != m->W || d.height != m->H) all_model_size = false;
   }
   if (any_ok) {
-    JpegFrameDesc* d_descs = tl_cur->d_descs_buf[buf];
-    int16_t* d_coef = tl_cur->d_coef_buf[buf];
+    const JpegFrameDesc* d_descs = d_descs_in;
+    int16_t* d_coef = d_coef_in;
     {
       ProfScope ps(m, "idct", 0, 0);
       launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream);
@@ -1161,7 +1222,7 @@ void worker_main(ufd_model* m, Worker* w) {
     tl_prof = s->job_prof;
     int rc = UFD_OK;
     try {
-      rc = submit_jpegs(m, *s, s->job_jpegs, s->job_lens, s->count);
+      rc = s->job_staged ? submit_staged(m, *s, *s->job_staged) : submit_jpegs(m, *s, s->job_jpegs, s->job_lens, s->count);
     } catch (const std::exception& e) {
       rc = m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
     } catch (...) {
@@ -1528,12 +1589,12 @@ int ufd_infer_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint
   return ufd_infer_rgb_batch(m, rgb, w, h, pitch, 1, out, cap, n);
 }
 
-int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
-                          uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
+static int submit_common(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, const ufd_staged* staged, uint32_t count,
+                         ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
   return guarded(m, [&]() -> int {
     int rc = check_outputs(m, out, cap, n);
     if (rc) return rc;
-    if (!jpegs || !lens || !ticket) return m->fail(UFD_E_ARG, "null argument");
+    if ((!staged && (!jpegs || !lens)) || !ticket) return m->fail(UFD_E_ARG, "null argument");
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
     Slot* s = find_free_slot(m);
     if (!s) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
@@ -1545,7 +1606,7 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
     m->next_ctx = (m->next_ctx + 1) % m->num_ctx;
     s->cap = cap, s->out = out, s->n = n, s->status = status;
     s->count = count;
-    s->job_jpegs = jpegs, s->job_lens = lens;
+    s->job_jpegs = jpegs, s->job_lens = lens, s->job_staged = staged;
     s->job_prof = (m->prof_batch++ % m->prof_every) == 0;
     s->issue_rc = UFD_OK;
     s->ctx = w.ctx;
@@ -1561,6 +1622,67 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
     w.cv.notify_all();
     return UFD_OK;
   });
+}
+
+int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
+                          uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
+  return submit_common(m, jpegs, lens, nullptr, count, out, cap, n, status, ticket);
+}
+
+int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_staged** staged) {
+  if (staged) *staged = nullptr;
+  return guarded(m, [&]() -> int {
+    if (!jpegs || !lens || !staged) return m->fail(UFD_E_ARG, "null argument");
+    if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
+    if (!m->gpu_entropy_enabled) return m->fail(UFD_E_STATE, "staging needs UFD_FLAG_DEVICE_ENTROPY (the device entropy decoder)");
+    drain_worker0(m);
+    // host plan in the pinned arrays of a free slot, then blocking uploads into the staged batch
+    Slot* fs = find_free_slot(m);
+    if (!fs) return m->fail(UFD_E_STATE, "all slots busy: call ufd_wait first");
+    int rc = alloc_slot(m, *fs);
+    if (rc) return rc;
+    Slot& tmp = *fs;
+    std::unique_ptr<ufd_staged> g(new ufd_staged);
+    auto release = [] {};
+    const DevicePlan p = plan_device_entropy(m, tmp, jpegs, lens, count);
+    if (!p.ok) {
+      release();
+      return m->fail(UFD_E_UNSUPPORTED, "batch not eligible for the device entropy decoder (progressive, multi-scan or oversized frame)");
+    }
+    g->count = count;
+    g->plan = p;
+    g->h_descs.assign(tmp.h_descs, tmp.h_descs + count);
+    g->st.assign(tmp.st.begin(), tmp.st.begin() + count);
+    const uint32_t n_iv = std::max(p.n_iv, 1u);
+    bool ok = hipMalloc(&g->d_blob, m->blob_stride * count) == hipSuccess &&
+              hipMalloc(&g->d_descs, sizeof(JpegFrameDesc) * count) == hipSuccess &&
+              hipMalloc(&g->d_scans, sizeof(HuffScan) * count) == hipSuccess &&
+              hipMalloc(&g->d_ivs, sizeof(HuffInterval) * n_iv) == hipSuccess;
+    ok = ok && hipMemcpy(g->d_blob, tmp.h_blob, m->blob_stride * count, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(g->d_descs, tmp.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(g->d_scans, tmp.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(g->d_ivs, tmp.h_ivs, sizeof(HuffInterval) * p.n_iv, hipMemcpyHostToDevice) == hipSuccess;
+    release();
+    if (!ok) {
+      (void)hipFree(g->d_blob), (void)hipFree(g->d_descs), (void)hipFree(g->d_scans), (void)hipFree(g->d_ivs);
+      return m->fail(UFD_E_DEVICE, "staging a batch in device memory failed");
+    }
+    *staged = g.release();
+    return UFD_OK;
+  });
+}
+
+int ufd_submit_staged(ufd_model* m, const ufd_staged* staged, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status,
+                      uint32_t* ticket) {
+  if (m && !staged) return m->fail(UFD_E_ARG, "null staged batch");
+  return submit_common(m, nullptr, nullptr, staged, staged ? staged->count : 0, out, cap, n, status, ticket);
+}
+
+void ufd_staged_free(ufd_model* m, ufd_staged* staged) {
+  if (!staged) return;
+  if (m) (void)hipSetDevice(m->cfg.device_id);
+  (void)hipFree(staged->d_blob), (void)hipFree(staged->d_descs), (void)hipFree(staged->d_scans), (void)hipFree(staged->d_ivs);
+  delete staged;
 }
 
 int ufd_wait(ufd_model* m, uint32_t ticket) {

@@ -49,6 +49,7 @@ ABI_SYMBOLS = (
     "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
     "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
+    "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
 )
 
 _lib = None
@@ -83,6 +84,10 @@ def load_library():
     L.ufd_infer_rgb_batch.argtypes = [vp, vp, u32, u32, u32, u32, vp, u32, vp]
     L.ufd_submit_jpeg_batch.argtypes = [vp, vp, vp, u32, vp, u32, vp, vp, pu32]
     L.ufd_wait.argtypes = [vp, u32]
+    L.ufd_stage_jpeg_batch.argtypes = [vp, vp, vp, u32, ctypes.POINTER(vp)]
+    L.ufd_submit_staged.argtypes = [vp, vp, vp, u32, vp, vp, pu32]
+    L.ufd_staged_free.argtypes = [vp, vp]
+    L.ufd_staged_free.restype = None
     L.ufd_debug_decode_jpeg.argtypes = [vp, vp, sz, vp, sz, pu32, pu32]
     L.ufd_debug_preproc_rgb.argtypes = [vp, vp, u32, u32, u32, vp]
     L.ufd_debug_forward.argtypes = [vp, vp, u32, vp, vp]
@@ -251,7 +256,7 @@ class UltrafaceModel(InferModel):
         return _dets_to_list(out, min(n.value, self.det_cap))
 
     class _Batch:
-        __slots__ = ("bufs", "ptrs", "lens", "out", "cnt", "status", "count", "ticket")
+        __slots__ = ("bufs", "ptrs", "lens", "out", "cnt", "status", "count", "ticket", "staged")
 
     def _prep_batch(self, jpegs):
         b = UltrafaceModel._Batch()
@@ -289,6 +294,29 @@ class UltrafaceModel(InferModel):
         b.ticket = t.value
         self._pending[t.value] = b
         return t.value
+
+    def stage_jpeg_batch(self, jpegs):
+        """Places a batch in HBM (headers parsed, bytes uploaded): -> staged batch for `submit_staged`.
+        Needs device_entropy=True.  Free with `free_staged` after the last wait."""
+        b = self._prep_batch(jpegs)
+        h = ctypes.c_void_p()
+        self._check(self._lib.ufd_stage_jpeg_batch(self._h, b.ptrs, b.lens, b.count, ctypes.byref(h)))
+        b.staged = h
+        return b
+
+    def submit_staged(self, b):
+        """Runs the path on a staged (HBM-resident) batch; returns a ticket for `wait`.  A staged
+        batch can be in flight once at a time (its output arrays are reused)."""
+        t = ctypes.c_uint32()
+        self._check(self._lib.ufd_submit_staged(self._h, b.staged, b.out, self.det_cap, b.cnt, b.status, ctypes.byref(t)))
+        b.ticket = t.value
+        self._pending[t.value] = b
+        return t.value
+
+    def free_staged(self, b):
+        if getattr(b, "staged", None):
+            self._lib.ufd_staged_free(self._h, b.staged)
+            b.staged = None
 
     def wait(self, ticket, collect=True):
         b = self._pending.pop(ticket)

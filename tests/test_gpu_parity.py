@@ -318,3 +318,46 @@ def test_mixed_batch_falls_back_to_host_entropy(model640_dev, oracle_lib):
     b = synth.encode_jpeg(f)  # no DRI: not eligible for the device decoder
     res, status = model640.infer_jpeg_batch([a, b, a])
     assert status == [0, 0, 0] and res[0] == res[1] == res[2]
+
+
+def test_staged_batch_matches_host_boundary(model640_dev, weights):
+    """HBM-resident input (ufd_stage_jpeg_batch / ufd_submit_staged) gives the detections of the
+    host-buffer boundary, and a staged batch can be submitted repeatedly."""
+    from infercam_onnx_amd import nn, synth
+
+    jpegs = [synth.encode_jpeg(synth.synth_frame(81, i, 640, 480)) for i in range(5)]
+    jpegs[2] = jpegs[2][: len(jpegs[2]) // 3]  # no EOI: skipped at staging
+    ref, st_ref = model640_dev.infer_jpeg_batch(jpegs)
+    b = model640_dev.stage_jpeg_batch(jpegs)
+    try:
+        for _ in range(3):
+            got, st = model640_dev.wait(model640_dev.submit_staged(b))
+            assert st == st_ref and st[2] == nn.UFD_E_DECODE
+            assert got == ref
+    finally:
+        model640_dev.free_staged(b)
+
+
+def test_staged_batch_with_restart_markers(model640_dev):
+    from infercam_onnx_amd import synth
+
+    jpegs = [synth.encode_jpeg(synth.synth_frame(82, i, 640, 480), restart_rows=1) for i in range(3)]
+    ref, st_ref = model640_dev.infer_jpeg_batch(jpegs)
+    b = model640_dev.stage_jpeg_batch(jpegs)
+    try:
+        got, st = model640_dev.wait(model640_dev.submit_staged(b))
+        assert st == st_ref == [0, 0, 0] and got == ref
+    finally:
+        model640_dev.free_staged(b)
+
+
+def test_staging_rejects_ineligible_input(model640, model640_dev):
+    from infercam_onnx_amd import nn, synth
+
+    prog = synth.encode_jpeg(synth.synth_frame(83, 0, 640, 480), progressive=True)
+    with pytest.raises(nn.UfdError) as e:
+        model640_dev.stage_jpeg_batch([prog])
+    assert e.value.code == nn.UFD_E_UNSUPPORTED
+    with pytest.raises(nn.UfdError) as e:  # handle without the device entropy decoder
+        model640.stage_jpeg_batch([synth.encode_jpeg(synth.synth_frame(83, 1, 640, 480))])
+    assert e.value.code == nn.UFD_E_STATE
