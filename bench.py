@@ -115,10 +115,11 @@ def main():
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
     jpegs = synth.synth_jpeg_pool(rank, args.pool, W, H, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
-    device_entropy = args.restart_rows > 0 or args.entropy == "device" or args.input == "hbm"
+    device_entropy = args.entropy == "device" or args.input == "hbm"
     model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
                               weights=weights, priors=priors, max_src=(W, H), host_threads=args.host_threads,
-                              profile=True, det_cap=256, device_entropy=device_entropy)
+                              profile=True, det_cap=256, device_entropy=device_entropy and args.restart_rows > 0,
+                              host_entropy=not device_entropy)
     nb = max(1, args.pool // B)
     if args.input == "hbm":
         # inputs resident in HBM before the clock starts: bytes + parsed headers of every batch
@@ -173,7 +174,7 @@ def main():
         variants["host_bytes_device_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
         m2 = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
                                priors=priors, max_src=(W, H), host_threads=args.host_threads, det_cap=256,
-                               device_entropy=False)
+                               host_entropy=True)
         hb2 = [m2._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
         run_steps(args.warmup, mdl=m2, bts=hb2, staged=False)
         torch.cuda.synchronize()

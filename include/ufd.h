@@ -72,9 +72,12 @@ typedef struct ufd_config {
 
 #define UFD_FLAG_KEEP_LAYERS 1u /* keep every conv output resident for ufd_debug_layer_output */
 #define UFD_FLAG_PROFILE 2u     /* record HIP events around every kernel (ufd_profile_read) */
-#define UFD_FLAG_DEVICE_ENTROPY 4u /* Huffman-decode restart-interval streams on the GPU (one lane per
-                                      interval) instead of on host workers; JPEG bytes cross PCIe, not
-                                      coefficient slabs.  Off by default: see DESIGN.md section 4 */
+/* Entropy (Huffman) stage of the JPEG decode.  Default (neither flag): baseline single-scan
+ * streams WITHOUT restart markers are decoded by the GPU kernels (self-synchronising parallel
+ * decoder: the host only scans headers and markers); streams with restart markers, progressive
+ * and multi-scan files are decoded by the handle's host worker threads. */
+#define UFD_FLAG_DEVICE_ENTROPY 4u /* also decode restart-interval streams on the GPU (one lane per interval: slow) */
+#define UFD_FLAG_HOST_ENTROPY 8u   /* never use the GPU entropy kernels */
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
@@ -116,8 +119,8 @@ int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_
 int ufd_wait(ufd_model* m, uint32_t ticket);
 
 /* Device-resident input.  ufd_stage_jpeg_batch parses the headers of `count` JPEGs on the host
- * and places their bytes, frame descriptors and scan plans in HBM (blocking; needs
- * UFD_FLAG_DEVICE_ENTROPY; UFD_E_UNSUPPORTED if a frame cannot take the device entropy decoder).
+ * and places their bytes, frame descriptors and scan plans in HBM (blocking; UFD_E_STATE with
+ * UFD_FLAG_HOST_ENTROPY; UFD_E_UNSUPPORTED if a frame cannot take the device entropy decoder).
  * ufd_submit_staged then runs the whole path -- entropy decode, IDCT, upsampling, colour,
  * normalisation, the network, NMS -- from those HBM buffers: no input crosses PCIe, only the
  * detections come back.  Same ticket / ufd_wait protocol and outputs as ufd_submit_jpeg_batch

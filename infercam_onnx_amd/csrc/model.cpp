@@ -206,7 +206,8 @@ struct ufd_model {
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   uint32_t iv_cap = 0;      // restart intervals per batch
-  bool gpu_entropy_enabled = true;
+  bool gpu_entropy_enabled = true;   // device entropy kernels for streams without restart markers
+  bool gpu_entropy_restart = false;  // ... and (slow) for restart-interval streams
   bool branch_streams = false;
 
   Slot slots[UFD_MAX_SLOTS];
@@ -921,6 +922,7 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     }
   }
   if (!sync_path) {
+    if (!m->gpu_entropy_restart) device_path = false;  // restart-interval streams: host workers unless asked for
     // the restart-interval kernel needs every frame to carry restart markers
     for (uint32_t i = 0; i < count && device_path; i++)
       if (s.st[i] == kJpegOk && s.h_descs[i].restart_interval <= 0) device_path = false;
@@ -1464,7 +1466,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
   // a JPEG is rarely larger than one byte per pixel; bigger frames take the host entropy path
   m->blob_stride = (((size_t)m->max_w * m->max_h) + 64 + 4095) & ~(size_t)4095;
   m->iv_cap = (uint32_t)B * 160;
-  m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
+  m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_HOST_ENTROPY) == 0;
+  m->gpu_entropy_restart = m->gpu_entropy_enabled && (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
   HIPB(hipMalloc(&m->d_luts, sizeof(HuffLut) * 4 * ufd_model::kMaxLutSets));
   HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
@@ -1634,7 +1637,7 @@ int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t
   return guarded(m, [&]() -> int {
     if (!jpegs || !lens || !staged) return m->fail(UFD_E_ARG, "null argument");
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
-    if (!m->gpu_entropy_enabled) return m->fail(UFD_E_STATE, "staging needs UFD_FLAG_DEVICE_ENTROPY (the device entropy decoder)");
+    if (!m->gpu_entropy_enabled) return m->fail(UFD_E_STATE, "staging needs the device entropy decoder (handle created with UFD_FLAG_HOST_ENTROPY)");
     drain_worker0(m);
     // host plan in the pinned arrays of a free slot, then blocking uploads into the staged batch
     Slot* fs = find_free_slot(m);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libufacehip.so")
 UFD_OK = 0
 UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
 UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
-UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY = 1, 2, 4
+UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
 UFD_MAX_SLOTS = 8
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
@@ -165,11 +165,14 @@ class UltrafaceModel(InferModel):
     `UltrafaceModel(variant, max_iou, min_confidence)` as in the reference; keyword arguments add
     placement (`device_id`, `max_batch`) and the weight source (`weights_path` = .onnx, or a packed
     f32 `weights` blob + optional `priors`; default = the reference's cache path, nn.rs:144-156).
+    Entropy stage: by default the GPU kernels decode streams without restart markers and the host
+    workers everything else; `device_entropy=True` also sends restart-interval streams to the GPU,
+    `host_entropy=True` keeps the whole Huffman stage on the host workers.
     """
 
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
                  weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
-                 device_entropy=False):
+                 device_entropy=False, host_entropy=False):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -185,7 +188,7 @@ class UltrafaceModel(InferModel):
         cfg.max_src_width, cfg.max_src_height = int(max_src[0]), int(max_src[1])
         cfg.host_threads = int(host_threads)
         cfg.flags = ((UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0) |
-                     (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0))
+                     (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()
@@ -297,7 +300,7 @@ class UltrafaceModel(InferModel):
 
     def stage_jpeg_batch(self, jpegs):
         """Places a batch in HBM (headers parsed, bytes uploaded): -> staged batch for `submit_staged`.
-        Needs device_entropy=True.  Free with `free_staged` after the last wait."""
+        Not available with host_entropy=True.  Free with `free_staged` after the last wait."""
         b = self._prep_batch(jpegs)
         h = ctypes.c_void_p()
         self._check(self._lib.ufd_stage_jpeg_batch(self._h, b.ptrs, b.lens, b.count, ctypes.byref(h)))

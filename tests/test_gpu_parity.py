@@ -21,14 +21,14 @@ def make_model(variant, weights, **kw):
 
 @pytest.fixture(scope="module")
 def model320(weights):
-    m = make_model(320, weights, max_batch=4, keep_layers=True)
+    m = make_model(320, weights, max_batch=4, keep_layers=True, host_entropy=True)  # Huffman on host workers
     yield m
     m.close()
 
 
 @pytest.fixture(scope="module")
 def model640(weights):
-    m = make_model(640, weights, max_batch=8)
+    m = make_model(640, weights, max_batch=8, host_entropy=True)
     yield m
     m.close()
 
@@ -267,6 +267,31 @@ def test_device_sync_decoder_is_the_path_taken(weights):
         m.close()
 
 
+def test_default_handle_routes_entropy_by_stream_kind(weights, oracle_lib):
+    """No flags: streams without restart markers take the GPU entropy kernels, restart-interval
+    and progressive streams the host workers; all of them decode to the oracle's detections."""
+    from infercam_onnx_amd import synth
+
+    m = make_model(640, weights, max_batch=4, profile=True)
+    try:
+        frames = [synth.synth_frame(77, i, 640, 480) for i in range(3)]
+        seen = []
+        results = []
+        for kw in ({}, {"restart_rows": 1}, {"progressive": True}):
+            jpegs = [synth.encode_jpeg(f, **kw) for f in frames]
+            m.profile_reset()
+            res, st = m.infer_jpeg_batch(jpegs)
+            assert st == [0] * 3
+            seen.append({p["name"] for p in m.profile_read() if p["launches"] > 0})
+            results.append(res)
+        assert "huffman_sync" in seen[0] and "h2d_coef" not in seen[0]
+        assert "h2d_coef" in seen[1] and "huffman_sync" not in seen[1] and "huffman_rst" not in seen[1]
+        assert "h2d_coef" in seen[2]
+        assert results[0] == results[1]  # same pixels (baseline, same quantisation), same kernels
+    finally:
+        m.close()
+
+
 def test_device_sync_decoder_truncated_stream_is_flagged(model640_dev, oracle_lib):
     from infercam_onnx_amd import nn, synth
 
@@ -351,13 +376,18 @@ def test_staged_batch_with_restart_markers(model640_dev):
         model640_dev.free_staged(b)
 
 
-def test_staging_rejects_ineligible_input(model640, model640_dev):
+def test_staging_rejects_ineligible_input(model640_dev, weights):
     from infercam_onnx_amd import nn, synth
+
+    model640 = make_model(640, weights, max_batch=2, host_entropy=True)
 
     prog = synth.encode_jpeg(synth.synth_frame(83, 0, 640, 480), progressive=True)
     with pytest.raises(nn.UfdError) as e:
         model640_dev.stage_jpeg_batch([prog])
     assert e.value.code == nn.UFD_E_UNSUPPORTED
-    with pytest.raises(nn.UfdError) as e:  # handle without the device entropy decoder
-        model640.stage_jpeg_batch([synth.encode_jpeg(synth.synth_frame(83, 1, 640, 480))])
-    assert e.value.code == nn.UFD_E_STATE
+    try:
+        with pytest.raises(nn.UfdError) as e:  # handle without the device entropy decoder
+            model640.stage_jpeg_batch([synth.encode_jpeg(synth.synth_frame(83, 1, 640, 480))])
+        assert e.value.code == nn.UFD_E_STATE
+    finally:
+        model640.close()
