@@ -28,6 +28,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 KERNEL_FUNCS = {
     "conv_pw_mfma": "k_pw_mfma",
     "conv_dwpw_mfma": "k_dwpw_mfma",
+    "conv_dwpw2_mfma": "k_dwpw2_mfma",
     "conv3x3_mfma": "k_conv3x3_mfma",
     "conv3x3_rows_mfma": "k_conv3x3_rows_mfma",
     "upsample_norm_420": "k_upsample_norm_420",

@@ -364,6 +364,215 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two depthwise->pointwise blocks in one launch:
+//   [dw 3x3 s1 (C1 ch, +bias, ReLU) -> pw C1->32 (+bias, act)] -> [dw 3x3 s2 (32 ch, +bias, ReLU) -> pw 32->cout<=32]
+// The tensor between the blocks (X1: 32 channels at full resolution, 315 MB per 32-frame batch for
+// m1 -> m2 of the 640x480 model, written once and read once) never exists in memory.
+// A group of 4 output pixels (oy, ox..ox+3) of the second block reads rows 2oy-1..2oy+1 and columns
+// 2ox-1..2ox+7 of X1.  Two neighbouring lane columns share an output group: column parity s = 0
+// owns X1 columns 2ox..2ox+3 and output pixels 0,1; s = 1 owns X1 columns 2ox+4..2ox+7 and output
+// pixels 2,3.  So the lane columns of a wave are 32 consecutive 4-pixel groups of an X1 row, and
+// the first block is exactly the stride-1 k_dwpw_mfma inner loop (three 16-byte loads per k-step,
+// halo columns by shuffle, 4 MFMAs), run once per X1 row.  The D layout leaves the lane with 16
+// of the 32 X1 channels of its 4 pixels (the other 16 sit in lane l^32); the second depthwise
+// conv is per channel, so each row is folded straight into the lane's 16 x 2 second-block sums:
+//   pixel A: taps (left lane's x3, x0, x1)      pixel B: taps (x1, x2, x3)
+// for both parities.  The fma order is the unfused one (bias; rows top to bottom; taps left to
+// right).  Rows 2oy+1 and 2(oy+1)-1 coincide, so the first block is computed 1.5x: it is the
+// cheap one (K = C1).  Before the second pointwise conv the halves exchange channels so that
+// k-step s multiplies channels (2s, 2s+1) in ascending order like k_dwpw_mfma.
+// Tiles advance by 30 lane columns = 15 output groups; columns 0 and 31 only provide halos.
+// a[0]: first block (in, w2 = dw [C1][12], w = packed pw, bias, relu); a[1]: second block
+// (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0.
+template <int C1>
+__global__ __launch_bounds__(256) void k_dwpw2_mfma(ConvArgs3 p3) {
+  const ConvArgs& a1 = p3.a[0];
+  const ConvArgs& a2 = p3.a[1];
+  constexpr int KS1 = C1 / 2, KS2 = 16;
+  extern __shared__ float s_mem[];
+  float* s_dw1 = s_mem;             // [C1][12]
+  float* s_w1 = s_dw1 + C1 * 12;    // [KS1][64]
+  float* s_dw2 = s_w1 + KS1 * 64;   // [32][12]
+  float* s_w2 = s_dw2 + 32 * 12;    // [KS2][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  if (tile >= a2.tiles) return;  // whole block, before the barrier
+  {
+    auto copy4 = [&](float* dst, const float* src, int n4) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int i = threadIdx.x; i < n4; i += 256) d4[i] = s4[i];
+    };
+    copy4(s_dw1, a1.w2, C1 * 3);
+    copy4(s_w1, a1.w, KS1 * 16);
+    copy4(s_dw2, a2.w2, 32 * 3);
+    copy4(s_w2, a2.w, KS2 * 16);
+  }
+  __syncthreads();
+  const int half = lane >> 5, j32 = lane & 31;
+  const int ohw = a2.oh * a2.ow, gpf = ohw >> 2, gpr = a2.ow >> 2;
+  const long total = 2L * a2.B * gpf;  // X1 half-groups
+  const long q = ((long)tile * 4 + wave) * kDwGroups + j32 - 1;
+  const bool inrange = q >= 0 && q < total;
+  const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;
+  const int sub = inrange ? (int)(q & 1) : 0;
+  const long g = inrange ? (q >> 1) : 0;
+  const size_t frame = (size_t)(g / gpf);
+  const int rem = (int)(g - (long)frame * gpf);
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const int H1 = a1.ih, W1 = a1.iw, ihw = H1 * W1;
+  const int x0 = 2 * ox + 4 * sub;            // first X1 / input column of the lane
+  const bool leftok = x0 > 0;                 // column x0 - 1 exists (else zero padding)
+  const bool rightok = x0 + 4 < W1;           // column x0 + 4 exists
+  const float* __restrict__ in = a1.in;
+  const uint32_t lane_base = (uint32_t)((frame * a1.in_ctotal + half) * ihw);
+  const uint32_t chan_step = 2u * (uint32_t)ihw;
+
+  // second block: depthwise sums of the lane's 16 channels x 2 output pixels
+  float t2[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t2[r][0] = t2[r][1] = s_dw2[((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 9];
+
+#pragma unroll 1
+  for (int row = 0; row < 3; row++) {
+    const int y1 = 2 * oy - 1 + row;  // X1 row
+    const bool row1ok = y1 >= 0 && y1 < H1;
+    bool ok0[3];
+    uint32_t rowoff[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int y0 = y1 - 1 + k;
+      ok0[k] = y0 >= 0 && y0 < H1;
+      rowoff[k] = lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0);
+    }
+    floatx16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float bb = a1.bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+      for (int p = 0; p < 4; p++) acc[p][r] = bb;
+    }
+    // input windows: 3 rows x 4 columns of channel 2*ks + half, two k-steps in flight
+    float4 win[2][3];
+    auto load_window = [&](int ks, float4 (&m)[3]) {
+      const uint32_t c = (uint32_t)ks * chan_step;
+#pragma unroll
+      for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(in + (rowoff[k] + c));
+    };
+    // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
+    // zero padding: their weights are zeroed instead of the pixels (fma(0, x, t) == t).
+    auto dw_compute = [&](const float4 (&m3)[3], int ks, float (&t)[4]) {
+      const float* wd = s_dw1 + (2 * ks + half) * 12;
+      float t0 = wd[9], t1 = t0, t2_ = t0, t3 = t0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const bool ok = ok0[k];
+        const float w0 = ok ? wd[3 * k] : 0.f, w1 = ok ? wd[3 * k + 1] : 0.f, w2 = ok ? wd[3 * k + 2] : 0.f;
+        const float4 m = m3[k];
+        const float from_prev = __shfl_up(m.w, 1), from_next = __shfl_down(m.x, 1);
+        const float l = leftok ? from_prev : 0.f, rr = rightok ? from_next : 0.f;
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+        t2_ = fmaf(w0, m.y, t2_), t2_ = fmaf(w1, m.z, t2_), t2_ = fmaf(w2, m.w, t2_);
+        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+      }
+      t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
+    };
+    load_window(0, win[0]);
+    load_window(1, win[1]);
+    // software pipeline: the MFMAs of k-step ks run beside the depthwise arithmetic of ks + 1
+    float tcur[4];
+    dw_compute(win[0], 0, tcur);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS1; ks0 += 2) {
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const int ks = ks0 + d;
+        // slot d held step ks (already consumed into tcur): refill it with step ks + 2
+        load_window(min(ks + 2, KS1 - 1), win[d]);
+        const float w = s_w1[ks * 64 + lane];
+        float tnext[4];
+        dw_compute(win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
+#pragma unroll
+        for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, tcur[p], acc[p], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // then a slice of the VALU work
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) tcur[p] = tnext[p];
+      }
+    }
+    // X1 row of the lane's 16 channels -> second depthwise sums (row `row` of the 3x3 taps)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float* wd2 = s_dw2 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 3 * row;
+      // an X1 row outside the image is zero padding: zero weights (fma(0, x, t) == t)
+      const float w0 = row1ok ? wd2[0] : 0.f, w1 = row1ok ? wd2[1] : 0.f, w2 = row1ok ? wd2[2] : 0.f;
+      float x[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) x[p] = a1.relu ? fmaxf(acc[p][r], 0.f) : acc[p][r];
+      const float from_prev = __shfl_up(x[3], 1);
+      const float l = leftok ? from_prev : 0.f;
+      t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
+      t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
+    }
+  }
+
+  // second pointwise conv.  The lane holds channels qq + 8b + 4*half (qq = r&3, b = r>>2); k-step
+  // s = 4b + u needs channel 8b + 2u from the half-0 lanes and 8b + 2u + 1 from the half-1 lanes:
+  //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
+  //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
+  floatx16 acc2[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float bb = co < a2.cout ? a2.bias[co] : 0.0f;
+    acc2[0][r] = acc2[1][r] = bb;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    float own[4][2], got[2][2];
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) own[qq][j] = fmaxf(t2[4 * b + qq][j], 0.f);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      // half 0 sends qq = 1, 3; half 1 sends qq = 0, 2
+      const float s0 = half ? own[0][j] : own[1][j], s1 = half ? own[2][j] : own[3][j];
+      got[0][j] = __shfl_xor(s0, 32), got[1][j] = __shfl_xor(s1, 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float w = s_w2[(4 * b + u) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        float v;
+        if (u == 0) v = half ? got[0][j] : own[0][j];
+        else if (u == 1) v = half ? got[1][j] : own[2][j];
+        else if (u == 2) v = half ? own[1][j] : got[0][j];
+        else v = half ? own[3][j] : got[1][j];
+        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc2[j], 0, 0, 0);
+      }
+    }
+  }
+  if (live) {
+    const int pix = oy * a2.ow + ox + 2 * sub;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a2.cout) {
+        float2 v = make_float2(acc2[0][r], acc2[1][r]);
+        if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+        *reinterpret_cast<float2*>(a2.out + (frame * a2.out_ctotal + a2.out_coff + co) * ohw + pix) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense 3x3 (any stride / dilation, pad = dilation, cout <= 16) as implicit GEMM on
 // v_mfma_f32_16x16x4_f32.  K runs over (input channel, tap) with the 9 taps of a channel padded
 // to 12 = 3 instructions of 4 taps: lane l supplies tap 4*s + (l>>4) of channel ci for pixel
@@ -823,6 +1032,24 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     else
       hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1, 1>), g, dim3(256), lds, s, p);
   }
+}
+
+bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
+  return first.cin == 16 && first.cout == 32 && second.cin == 32 && second.cout <= 32 && first.iw % 8 == 0 &&
+         first.iw == first.ow && first.ih == first.oh && second.ow % 4 == 0 && first.ow == 2 * second.ow &&
+         first.oh == 2 * second.oh && first.res == nullptr && second.res == nullptr;
+}
+
+void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipStream_t s) {
+  ConvArgs3 p{};
+  p.a[0] = first;
+  p.a[1] = second;
+  const long half_groups = 2L * second.B * (second.oh * second.ow / 4);  // one lane column per 2 output pixels
+  const long wave_tiles = (half_groups + kDwGroups - 1) / kDwGroups;
+  p.a[1].tiles = (int)((wave_tiles + 3) / 4);
+  p.a[1].cts = 1;
+  const size_t lds = ((size_t)16 * 12 + 8 * 64 + 32 * 12 + 16 * 64) * sizeof(float);
+  hipLaunchKernelGGL((k_dwpw2_mfma<16>), dim3((unsigned)p.a[1].tiles), dim3(256), lds, s, p);
 }
 
 void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {

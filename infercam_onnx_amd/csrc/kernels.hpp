@@ -133,6 +133,10 @@ void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, f
 // in/ih/iw/cin = depthwise input, oh/ow/cout = pointwise output, w/bias = packed pointwise
 // weights, w2/bias2 = depthwise weights; relu applies to the pointwise output.
 bool dwpw_supported(const ConvArgs& a, int stride);
+// Two consecutive dw->pw blocks (stride 1 then stride 2, 16 -> 32 -> <=32 channels) in one launch:
+// `first` / `second` are the ConvArgs of the two pointwise layers as for launch_conv_dwpw_mfma.
+bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second);
+void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipStream_t s);
 size_t depthwise_packed_floats(int c);
 void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c, float* packed /*[c][12]*/);
 void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);

@@ -51,6 +51,7 @@ struct Tensor {
 enum LayerKind {
   kKindPointwise,  // 1x1 on fp32 MFMA
   kKindDwPw,       // 1x1 whose depthwise producer is fused in (the dw layer itself is kKindFusedAway)
+  kKindDwPw2,      // second 1x1 of two chained dw->pw blocks run as one launch (Layer::chain_first)
   kKindFusedAway,  // depthwise layer computed inside the following kKindDwPw launch
   kKindConv3x3,    // dense 3x3 implicit GEMM on fp32 MFMA
   kKindDirect,     // VALU fallback
@@ -62,7 +63,9 @@ struct Layer {
   int in_tensor, out_tensor, res_tensor;
   int out_coff;
   LayerKind kind;
-  int fused_dw = -1;       // kKindDwPw: index of the depthwise layer
+  int fused_dw = -1;       // kKindDwPw / kKindDwPw2: index of the depthwise layer
+  int chain_first = -1;    // kKindDwPw2: the kKindDwPw layer of the first block
+  bool chained = false;    // kKindDwPw layer computed inside a later kKindDwPw2 launch: its output never exists
   int leader = -1;         // first layer of the launch this layer is issued in (itself when not merged)
   int group[3] = {-1, -1, -1};  // leader only: members of its launch (itself first)
   bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
@@ -422,6 +425,35 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     P.flops_per_frame += D.flops_per_frame;
     P.weight_bytes += D.weight_bytes;
   }
+  // chain two dw->pw blocks into one launch where the tensor between them is the big one
+  // (m1 -> m2: 32 channels at half the input resolution) and nothing else reads it
+  if (!keep_all && !std::getenv("UFD_NO_FUSE2")) {
+    for (int i = 0; i < kNumConv; i++) {
+      Layer& P2 = m->layers[i];
+      if (P2.kind != kKindDwPw) continue;
+      const Layer& D2 = m->layers[P2.fused_dw];
+      const int p1 = D2.spec.src;
+      if (p1 < 0 || m->layers[p1].kind != kKindDwPw || m->layers[p1].chained) continue;
+      Layer& P1 = m->layers[p1];
+      const Layer& D1 = m->layers[P1.fused_dw];
+      bool only_reader = true;
+      for (int j = 0; j < kNumConv; j++)
+        if (j != P2.fused_dw && m->layers[j].spec.src == p1) only_reader = false;
+      for (int h = 0; h < 4; h++)
+        if (kHeadCls[h] == p1 || kHeadReg[h] == p1) only_reader = false;
+      if (!only_reader || D1.spec.stride != 1 || D2.spec.stride != 2) continue;
+      ConvArgs f{}, g{};
+      f.cin = P1.spec.cin, f.cout = P1.spec.cout, f.ih = D1.ih, f.iw = D1.iw, f.oh = P1.oh, f.ow = P1.ow;
+      g.cin = P2.spec.cin, g.cout = P2.spec.cout, g.ih = D2.ih, g.iw = D2.iw, g.oh = P2.oh, g.ow = P2.ow;
+      if (!dwpw2_supported(f, g)) continue;
+      P2.kind = kKindDwPw2;
+      P2.chain_first = p1;
+      P1.chained = true;
+      P2.bytes_per_frame = (double)D1.spec.cin * D1.ih * D1.iw * 4 + (double)P2.spec.cout * P2.oh * P2.ow * 4;
+      P2.flops_per_frame += P1.flops_per_frame;
+      P2.weight_bytes += P1.weight_bytes;
+    }
+  }
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
   if (!(std::getenv("UFD_NO_MERGE"))) {
@@ -456,11 +488,13 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   for (int i = 0; i < kNumConv; i++) {
     const Layer& L = m->layers[i];
     if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
+    if (L.chained) continue;                                     // computed inside a later launch
     first[L.out_tensor] = std::min(first[L.out_tensor], L.leader);  // a merged layer writes at its leader's turn
     last[L.out_tensor] = std::max(last[L.out_tensor], i);
-    const int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
+    int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
+    if (L.kind == kKindDwPw2) src_t = m->layers[m->layers[L.chain_first].fused_dw].in_tensor;
     if (src_t >= 0) last[src_t] = std::max(last[src_t], i);
-    if (L.in_tensor >= 0 && L.kind != kKindDwPw) last[L.in_tensor] = std::max(last[L.in_tensor], i);
+    if (L.in_tensor >= 0 && L.kind != kKindDwPw && L.kind != kKindDwPw2) last[L.in_tensor] = std::max(last[L.in_tensor], i);
     if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], i);
   }
   for (int h = 0; h < 4; h++) {
@@ -520,7 +554,7 @@ int upload_weights(ufd_model* m, const float* blob) {
     while (img.size() % 64) img.push_back(0.f);
     w_off[i] = img.size();
     const LayerKind kind = m->layers[i].kind;
-    if (kind == kKindPointwise || kind == kKindDwPw) {
+    if (kind == kKindPointwise || kind == kKindDwPw || kind == kKindDwPw2) {
       const size_t np = pointwise_packed_floats(s.cin, s.cout);
       img.resize(img.size() + np);
       pack_pointwise_weights(p, s.cin, s.cout, img.data() + w_off[i]);
@@ -651,7 +685,7 @@ ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_st
   a.in = in_ptr(L.in_tensor, L.ih, L.iw);
   a.w = L.d_w;
   a.bias = L.d_b;
-  a.out = tensor_ptr(m, L.out_tensor) + (size_t)f0 * m->tensors[L.out_tensor].per_frame();
+  a.out = L.chained ? nullptr : tensor_ptr(m, L.out_tensor) + (size_t)f0 * m->tensors[L.out_tensor].per_frame();
   a.res = L.res_tensor >= 0 ? in_ptr(L.res_tensor, 0, 0) : nullptr;
   a.B = (int)count;
   a.cin = L.spec.cin, a.cout = L.spec.cout;
@@ -663,6 +697,13 @@ ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_st
   a.out_ctotal = m->tensors[L.out_tensor].c;
   a.out_coff = L.out_coff;
   *dw_stride = 1;
+  if (L.kind == kKindDwPw2) {  // second block of a chain: its input tensor does not exist
+    const Layer& D = m->layers[L.fused_dw];
+    a.in = nullptr;
+    a.ih = D.ih, a.iw = D.iw;
+    a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
+    *dw_stride = D.spec.stride;
+  }
   if (L.kind == kKindDwPw) {
     const Layer& D = m->layers[L.fused_dw];
     a.in = in_ptr(D.in_tensor, D.ih, D.iw);
@@ -681,7 +722,18 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   if (!st) st = tl_cur->stream;
   const Layer& L = m->layers[i];
   if (L.kind == kKindFusedAway && !L.materialize) return;
+  if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
   if (L.leader != i) return;  // issued with its group leader
+  if (L.kind == kKindDwPw2) {
+    int s1 = 1, s2 = 2;
+    const Layer& F = m->layers[L.chain_first];
+    const ConvArgs first = layer_args(m, L.chain_first, f0, count, &s1);
+    const ConvArgs second = layer_args(m, i, f0, count, &s2);
+    ProfScope ps(m, std::string("conv_dwpw2_mfma:") + F.spec.name + "+" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
+                 L.flops_per_frame * count, st);
+    launch_conv_dwpw2_mfma(first, second, st);
+    return;
+  }
   ConvArgs args[3];
   int n = 0, dw_stride = 1;
   std::string names;
@@ -700,6 +752,7 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   switch (L.kind) {
     case kKindPointwise: kind = "conv_pw_mfma"; break;
     case kKindDwPw: kind = "conv_dwpw_mfma"; break;
+    case kKindDwPw2: break;  // issued above
     case kKindConv3x3:
       use_rows = n == 1 && conv3x3_rows_supported(a);
       kind = use_rows ? "conv3x3_rows_mfma" : "conv3x3_mfma";
@@ -1430,7 +1483,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0 || m->branch_streams);
   // shapes the kernels rely on (checked here once, not per launch)
   for (const Layer& L : m->layers) {
-    if ((L.kind == kKindPointwise || L.kind == kKindDwPw) && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
+    if ((L.kind == kKindPointwise || L.kind == kKindDwPw || L.kind == kKindDwPw2) && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {
       m->err = std::string("layer ") + L.spec.name + ": pointwise kernel needs H*W % 4 == 0 and even Cin";
       return bail(UFD_E_WEIGHTS);
     }

@@ -391,3 +391,36 @@ def test_staging_rejects_ineligible_input(model640_dev, weights):
         assert e.value.code == nn.UFD_E_STATE
     finally:
         model640.close()
+
+
+@pytest.mark.parametrize("variant", [320, 640])
+def test_chained_blocks_kernel_is_bit_identical_to_the_unfused_pair(weights, oracle_lib, variant):
+    """m1 -> m2 run as one launch (k_dwpw2_mfma, the 32-channel tensor between them never exists)
+    keeps the unfused fma order: scores and boxes are bit-identical to the two-launch path, for
+    frames whose borders exercise the zero padding, and at batch sizes that leave dead lanes."""
+    import os
+    from infercam_onnx_amd import synth
+
+    W, H = (640, 480) if variant == 640 else (320, 240)
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(91, i, W, H)) for i in range(3)])
+    os.environ["UFD_NO_FUSE2"] = "1"
+    try:
+        ref_model = make_model(variant, weights, max_batch=3, profile=True)
+    finally:
+        del os.environ["UFD_NO_FUSE2"]
+    fused_model = make_model(variant, weights, max_batch=3, profile=True)
+    try:
+        for count in (3, 1):
+            s0, b0 = ref_model.debug_forward(x[:count])
+            s1, b1 = fused_model.debug_forward(x[:count])
+            if count == 3:  # (at batch 1 the unfused m2 launch is split-K: fp32 rounding apart)
+                assert np.array_equal(s0, s1) and np.array_equal(b0, b1)
+            else:
+                assert np.abs(s0 - s1).max() <= 1e-6 and np.abs(b0 - b1).max() <= 1e-6
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names_fused = {p["name"] for p in fused_model.profile_read() if p["launches"]}
+        assert any(n.startswith("conv_dwpw2_mfma:") for n in names_fused), names_fused
+        assert not any(n.startswith("conv_dwpw2_mfma:") for n in names_ref)
+    finally:
+        ref_model.close()
+        fused_model.close()
