@@ -29,6 +29,20 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Neighbouring lane's value through the DPP crossbar (one VALU instruction; __shfl_up/down
+// compile to ds_bpermute_b32, an LDS-pipe instruction plus an address register).  Lane 0 of
+// lane_prev / lane 63 of lane_next get 0: those lanes are halo providers only.
+__device__ __forceinline__ float lane_prev(float x) {  // value of lane - 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float x) {  // value of lane + 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+// ReLU of a value that comes out of an MFMA: fmaxf() costs a canonicalising v_max first (the
+// compiler cannot know the accumulator is not a signalling NaN); for non-NaN floats the integer
+// maximum with 0 is the same function (negative floats, -0 included, are negative integers).
+__device__ __forceinline__ float relu_acc(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
@@ -286,30 +300,32 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   };
 
   // depthwise result of one k-step (4 pixels of channel 2*ks + half), from a loaded window
+  // Rows outside the image are zero padding: their three weights are zeroed instead of the 4 or 8
+  // loaded pixels (fma(0, x, t) == t for finite x; the loads come from clamped, valid addresses).
   auto dw_compute = [&](const DwWindow<S>& win, int ks, float (&t)[4]) {
-    const float* wd = s_dw + (2 * ks + half) * 12;
+    // (unconditional 16-byte LDS reads first: a select on a load becomes a predicated load)
+    const float4* wq = reinterpret_cast<const float4*>(s_dw + (2 * ks + half) * 12);
+    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
+    const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
     float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
       const bool ok = rowok[r];
+      const float w0 = ok ? wd[3 * r] : 0.f, w1 = ok ? wd[3 * r + 1] : 0.f, w2 = ok ? wd[3 * r + 2] : 0.f;
       if (S == 1) {
-        float4 m = win.m0[r];
-        const float from_prev = __shfl_up(m.w, 1), from_next = __shfl_down(m.x, 1);
-        m.x = ok ? m.x : 0.f, m.y = ok ? m.y : 0.f, m.z = ok ? m.z : 0.f, m.w = ok ? m.w : 0.f;
-        const float l = (ok && leftok) ? from_prev : 0.f;
-        const float rr = (ok && rightok) ? from_next : 0.f;
+        const float4 m = win.m0[r];
+        const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
+        const float l = leftok ? from_prev : 0.f;
+        const float rr = rightok ? from_next : 0.f;
         // per pixel, taps in kx order: x-1, x, x+1
         t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
         t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
         t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
         t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
       } else {
-        float4 m0 = win.m0[r], m1 = win.m1[r];
-        const float from_prev = __shfl_up(m1.w, 1);
-        m0.x = ok ? m0.x : 0.f, m0.y = ok ? m0.y : 0.f, m0.z = ok ? m0.z : 0.f, m0.w = ok ? m0.w : 0.f;
-        m1.x = ok ? m1.x : 0.f, m1.y = ok ? m1.y : 0.f, m1.z = ok ? m1.z : 0.f, m1.w = ok ? m1.w : 0.f;
-        const float l = (ok && leftok) ? from_prev : 0.f;
+        const float4 m0 = win.m0[r], m1 = win.m1[r];
+        const float from_prev = lane_prev(m1.w);
+        const float l = leftok ? from_prev : 0.f;
         // output pixel j reads columns 2j-1, 2j, 2j+1 of the window
         t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
         t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
 // a[0]: first block (in, w2 = dw [C1][12], w = packed pw, bias, relu); a[1]: second block
 // (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0.
 template <int C1>
-__global__ __launch_bounds__(256) void k_dwpw2_mfma(ConvArgs3 p3) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
   const ConvArgs& a2 = p3.a[1];
   constexpr int KS1 = C1 / 2, KS2 = 16;
@@ -433,18 +449,57 @@ __global__ __launch_bounds__(256) void k_dwpw2_mfma(ConvArgs3 p3) {
 #pragma unroll
   for (int r = 0; r < 16; r++) t2[r][0] = t2[r][1] = s_dw2[((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 9];
 
+  // input rows 2oy-2 .. 2oy+2 (X1 row `row` reads rows row .. row+2 of them)
+  bool ok5[5];
+  uint32_t rowoff5[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int y0 = 2 * oy - 2 + k;
+    ok5[k] = y0 >= 0 && y0 < H1;
+    rowoff5[k] = lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0);
+  }
+  // input windows: 3 rows x 4 columns of channel 2*ks + half; two k-steps are kept in flight
+  // ACROSS the three X1 rows (the ring never drains: the first windows of the next row are loaded
+  // while the current row is folded into the second depthwise conv)
+  float4 win[2][3];
+  // (the row loop stays rolled -- unrolled, the three bodies keep 470 registers live -- so
+  // rowoff5[row + k] is a select on the wave-uniform row, not a register-array index)
+  auto pick = [](int row, auto v0, auto v1, auto v2) { return row == 0 ? v0 : (row == 1 ? v1 : v2); };
+  auto load_window = [&](int row, int ks, float4 (&m)[3]) {
+    const uint32_t c = (uint32_t)ks * chan_step;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      m[k] = *reinterpret_cast<const float4*>(in + (pick(row, rowoff5[k], rowoff5[k + 1], rowoff5[k + 2]) + c));
+  };
+  // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
+  // zero padding: their weights are zeroed instead of the pixels (fma(0, x, t) == t).
+  auto dw_compute = [&](int row, const float4 (&m3)[3], int ks, float (&t)[4]) {
+    // (unconditional 16-byte LDS reads first: a select on a load becomes a predicated load)
+    const float4* wq = reinterpret_cast<const float4*>(s_dw1 + (2 * ks + half) * 12);
+    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
+    const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+    float t0 = wd[9], t1 = t0, t2_ = t0, t3 = t0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const bool ok = pick(row, ok5[k], ok5[k + 1], ok5[k + 2]);
+      const float w0 = ok ? wd[3 * k] : 0.f, w1 = ok ? wd[3 * k + 1] : 0.f, w2 = ok ? wd[3 * k + 2] : 0.f;
+      const float4 m = m3[k];
+      const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
+      const float l = leftok ? from_prev : 0.f, rr = rightok ? from_next : 0.f;
+      t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+      t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+      t2_ = fmaf(w0, m.y, t2_), t2_ = fmaf(w1, m.z, t2_), t2_ = fmaf(w2, m.w, t2_);
+      t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+    }
+    t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
+  };
+  load_window(0, 0, win[0]);
+  load_window(0, 1, win[1]);
+
 #pragma unroll 1
   for (int row = 0; row < 3; row++) {
     const int y1 = 2 * oy - 1 + row;  // X1 row
     const bool row1ok = y1 >= 0 && y1 < H1;
-    bool ok0[3];
-    uint32_t rowoff[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int y0 = y1 - 1 + k;
-      ok0[k] = y0 >= 0 && y0 < H1;
-      rowoff[k] = lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0);
-    }
     floatx16 acc[4];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -452,47 +507,23 @@ __global__ __launch_bounds__(256) void k_dwpw2_mfma(ConvArgs3 p3) {
 #pragma unroll
       for (int p = 0; p < 4; p++) acc[p][r] = bb;
     }
-    // input windows: 3 rows x 4 columns of channel 2*ks + half, two k-steps in flight
-    float4 win[2][3];
-    auto load_window = [&](int ks, float4 (&m)[3]) {
-      const uint32_t c = (uint32_t)ks * chan_step;
-#pragma unroll
-      for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(in + (rowoff[k] + c));
-    };
-    // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
-    // zero padding: their weights are zeroed instead of the pixels (fma(0, x, t) == t).
-    auto dw_compute = [&](const float4 (&m3)[3], int ks, float (&t)[4]) {
-      const float* wd = s_dw1 + (2 * ks + half) * 12;
-      float t0 = wd[9], t1 = t0, t2_ = t0, t3 = t0;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const bool ok = ok0[k];
-        const float w0 = ok ? wd[3 * k] : 0.f, w1 = ok ? wd[3 * k + 1] : 0.f, w2 = ok ? wd[3 * k + 2] : 0.f;
-        const float4 m = m3[k];
-        const float from_prev = __shfl_up(m.w, 1), from_next = __shfl_down(m.x, 1);
-        const float l = leftok ? from_prev : 0.f, rr = rightok ? from_next : 0.f;
-        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
-        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
-        t2_ = fmaf(w0, m.y, t2_), t2_ = fmaf(w1, m.z, t2_), t2_ = fmaf(w2, m.w, t2_);
-        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
-      }
-      t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
-    };
-    load_window(0, win[0]);
-    load_window(1, win[1]);
     // software pipeline: the MFMAs of k-step ks run beside the depthwise arithmetic of ks + 1
     float tcur[4];
-    dw_compute(win[0], 0, tcur);
+    dw_compute(row, win[0], 0, tcur);
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS1; ks0 += 2) {
 #pragma unroll
       for (int d = 0; d < 2; d++) {
         const int ks = ks0 + d;
-        // slot d held step ks (already consumed into tcur): refill it with step ks + 2
-        load_window(min(ks + 2, KS1 - 1), win[d]);
+        // slot d held step ks (already consumed into tcur): refill it with step ks + 2 -- of the
+        // next X1 row once this one runs out (the last row re-reads its own last window)
+        if (ks + 2 < KS1)
+          load_window(row, ks + 2, win[d]);
+        else
+          load_window(row < 2 ? row + 1 : row, row < 2 ? ks + 2 - KS1 : KS1 - 1, win[d]);
         const float w = s_w1[ks * 64 + lane];
         float tnext[4];
-        dw_compute(win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
+        dw_compute(row, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
 #pragma unroll
         for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, tcur[p], acc[p], 0, 0, 0);
 #pragma unroll
@@ -509,11 +540,12 @@ __global__ __launch_bounds__(256) void k_dwpw2_mfma(ConvArgs3 p3) {
     for (int r = 0; r < 16; r++) {
       const float* wd2 = s_dw2 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 3 * row;
       // an X1 row outside the image is zero padding: zero weights (fma(0, x, t) == t)
-      const float w0 = row1ok ? wd2[0] : 0.f, w1 = row1ok ? wd2[1] : 0.f, w2 = row1ok ? wd2[2] : 0.f;
+      const float u0 = wd2[0], u1 = wd2[1], u2 = wd2[2];
+      const float w0 = row1ok ? u0 : 0.f, w1 = row1ok ? u1 : 0.f, w2 = row1ok ? u2 : 0.f;
       float x[4];
 #pragma unroll
-      for (int p = 0; p < 4; p++) x[p] = a1.relu ? fmaxf(acc[p][r], 0.f) : acc[p][r];
-      const float from_prev = __shfl_up(x[3], 1);
+      for (int p = 0; p < 4; p++) x[p] = a1.relu ? relu_acc(acc[p][r]) : acc[p][r];
+      const float from_prev = lane_prev(x[3]);
       const float l = leftok ? from_prev : 0.f;
       t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
       t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
