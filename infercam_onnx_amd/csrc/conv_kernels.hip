@@ -380,6 +380,182 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused depthwise 3x3 -> pointwise 1x1 for layers with several 32-cout tiles (cout >= 64).
+// In k_dwpw_mfma every cout tile is an independent wave that repeats the depthwise arithmetic and
+// the input loads of its pixels: 4x (cout 128) or 8x (cout 256) redundant VALU work and vector
+// loads, at about one wave per SIMD, so every load round trip is exposed (measured on the
+// 128-channel 30x40 layers: 82 k cycles per wave for 16 k cycles of MFMA and 24 k of VALU).
+// Here the four waves of a block are CTW cout tiles of the SAME pixel tile (x 4/CTW pixel tiles).
+// The k-loop runs in chunks of 8 k-steps: each wave computes the depthwise result of 8/CTW steps
+// of the next chunk and publishes it in LDS (one float4 per lane and k-step); after a barrier all
+// waves of the pixel tile read every step's B operand back and run their own cout tile's MFMAs.
+// Depthwise arithmetic and loads per wave drop by CTW, and a wave's own loads are a whole chunk
+// (~2 k cycles) ahead of their use.  A operand (pointwise weights) straight from global / L2 with
+// one chunk of prefetch.  fma order per output as k_dwpw_mfma.  Needs (cin/2) % 8 == 0,
+// cts % CTW == 0.
+template <int S, int CTW>
+__global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];
+  constexpr int PT = 4 / CTW;   // pixel tiles per block
+  constexpr int CH = 8;         // k-steps per chunk
+  constexpr int NS = CH / CTW;  // depthwise steps per wave and chunk
+  extern __shared__ float s_mem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pt = wave / CTW, cw = wave - pt * CTW;
+  // block -> (pixel-tile group, cout-tile group); groups of one pixel tile are 8 ids apart (same XCD)
+  const int cgroups = a.cts / CTW;
+  int tgrp, cgrp;
+  {
+    const int per = 8 * cgroups;
+    const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+    cgrp = r >> 3;
+    tgrp = grp * 8 + (r & 7);
+  }
+  if (tgrp >= a.tiles) return;  // whole block, before any barrier
+  const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
+  float* s_dw = s_mem;                                              // [cin][12]
+  float4* s_t = reinterpret_cast<float4*>(s_mem + a.cin * 12);      // [PT][3][CH][64]
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.w2);
+    float4* dst = reinterpret_cast<float4*>(s_dw);
+    const int n4 = a.cin * 3;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
+  const long total = (long)a.B * gpf;
+  const long g = ((long)tgrp * PT + pt) * kDwGroups + j32 - 1;
+  const bool inrange = g >= 0 && g < total;
+  const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;
+  const size_t frame = inrange ? g / gpf : 0;
+  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const int ihw = a.ih * a.iw;
+  const int ct = cgrp * CTW + cw;
+
+  floatx16 acc[1][4];
+  init_acc<1>(a, acc, ct, half);
+
+  const int iy0 = oy * S - 1, ix0 = ox * S;
+  bool rowok[3];
+  uint32_t rowoff[3];
+  const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
+    rowoff[r] = lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0);
+  }
+  const bool leftok = ix0 > 0;
+  const bool rightok = (S == 1) && (ix0 + 4 < a.iw);
+  const float* __restrict__ in = a.in;
+  const uint32_t chan_step = 2u * (uint32_t)ihw;
+
+  auto load_window = [&](int ks, DwWindow<S>& win) {
+    const uint32_t c = (uint32_t)ks * chan_step;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const uint32_t o = rowoff[r] + c;
+      win.m0[r] = *reinterpret_cast<const float4*>(in + o);
+      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(in + (o + 4u));
+    }
+  };
+  auto dw_compute = [&](const DwWindow<S>& win, int ks) -> float4 {
+    const float4* wq = reinterpret_cast<const float4*>(s_dw + (2 * ks + half) * 12);
+    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
+    const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+    float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const bool ok = rowok[r];
+      const float w0 = ok ? wd[3 * r] : 0.f, w1 = ok ? wd[3 * r + 1] : 0.f, w2 = ok ? wd[3 * r + 2] : 0.f;
+      if (S == 1) {
+        const float4 m = win.m0[r];
+        const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
+        const float l = leftok ? from_prev : 0.f;
+        const float rr = rightok ? from_next : 0.f;
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
+        t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
+        t2 = fmaf(w0, m.y, t2), t2 = fmaf(w1, m.z, t2), t2 = fmaf(w2, m.w, t2);
+        t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+      } else {
+        const float4 m0 = win.m0[r], m1 = win.m1[r];
+        const float from_prev = lane_prev(m1.w);
+        const float l = leftok ? from_prev : 0.f;
+        t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m0.x, t0), t0 = fmaf(w2, m0.y, t0);
+        t1 = fmaf(w0, m0.y, t1), t1 = fmaf(w1, m0.z, t1), t1 = fmaf(w2, m0.w, t1);
+        t2 = fmaf(w0, m0.w, t2), t2 = fmaf(w1, m1.x, t2), t2 = fmaf(w2, m1.y, t2);
+        t3 = fmaf(w0, m1.y, t3), t3 = fmaf(w1, m1.z, t3), t3 = fmaf(w2, m1.w, t3);
+      }
+    }
+    return make_float4(fmaxf(t0, 0.f), fmaxf(t1, 0.f), fmaxf(t2, 0.f), fmaxf(t3, 0.f));
+  };
+
+  const int nchunks = ksteps / CH;
+  float4* my_t = s_t + (size_t)pt * 3 * CH * 64;  // this pixel tile's three chunk buffers
+  const float* __restrict__ wsrc = a.w + (size_t)ct * ksteps * 64 + lane;  // A operand of step ks: wsrc[ks * 64]
+  // Schedule of iteration c (one barrier each): issue the loads of the windows of chunk c+3 and of
+  // the weights of chunk c+1 (a whole iteration before their use), compute this wave's depthwise
+  // steps of chunk c+2 into LDS buffer (c+2)%3, then multiply chunk c out of buffer c%3 -- which
+  // every wave finished writing two iterations ago, so the MFMA phase never waits for a
+  // neighbour's depthwise phase of the same iteration.
+  auto load_windows = [&](int chunk, DwWindow<S> (&w)[NS]) {
+    const int cc = min(chunk, nchunks - 1);  // past the end: harmless re-read
+#pragma unroll
+    for (int i = 0; i < NS; i++) load_window(cc * CH + cw + i * CTW, w[i]);
+  };
+  auto load_weights = [&](int chunk, float (&w)[CH]) {
+    const int cc = min(chunk, nchunks - 1);
+#pragma unroll
+    for (int kk = 0; kk < CH; kk++) w[kk] = wsrc[(cc * CH + kk) * 64];
+  };
+  auto publish = [&](int chunk, const DwWindow<S> (&w)[NS]) {
+    if (chunk >= nchunks) return;
+    float4* tn = my_t + (size_t)(chunk % 3) * CH * 64;
+#pragma unroll
+    for (int i = 0; i < NS; i++) tn[(cw + i * CTW) * 64 + lane] = dw_compute(w[i], chunk * CH + cw + i * CTW);
+  };
+  auto multiply = [&](int chunk, const float (&w)[CH]) {
+    const float4* tb = my_t + (size_t)(chunk % 3) * CH * 64;
+#pragma unroll
+    for (int kk = 0; kk < CH; kk++) {
+      const float4 b = tb[kk * 64 + lane];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.y, acc[0][1], 0, 0, 0);
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.z, acc[0][2], 0, 0, 0);
+      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.w, acc[0][3], 0, 0, 0);
+    }
+  };
+  DwWindow<S> winA[NS], winB[NS];
+  float wA[CH], wB[CH];
+  // prologue: chunks 0 and 1 published, windows of chunk 2 and weights of chunk 0 in flight
+  load_windows(0, winA);
+  load_windows(1, winB);
+  load_weights(0, wA);
+  publish(0, winA);
+  load_windows(2, winA);
+  publish(1, winB);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunks; c += 2) {
+    // even iteration: windows of chunk c+2 are in winA, weights of chunk c in wA
+    load_windows(c + 3, winB);
+    load_weights(c + 1, wB);
+    publish(c + 2, winA);
+    multiply(c, wA);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    // odd iteration: windows of chunk c+3 are in winB, weights of chunk c+1 in wB
+    load_windows(c + 4, winA);
+    load_weights(c + 2, wA);
+    publish(c + 3, winB);
+    multiply(c + 1, wB);
+    __syncthreads();
+  }
+  if (live) store_tiles<1>(a, acc, ct, half, frame, oy * a.ow + ox, ohw);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two depthwise->pointwise blocks in one launch:
 //   [dw 3x3 s1 (C1 ch, +bias, ReLU) -> pw C1->32 (+bias, act)] -> [dw 3x3 s2 (32 ch, +bias, ReLU) -> pw 32->cout<=32]
 // The tensor between the blocks (X1: 32 channels at full resolution, 315 MB per 32-frame batch for
@@ -1043,6 +1219,23 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     p.a[i].cts = (args[i].cout + 31) / 32;
     p.a[i].tiles = sk ? (int)wave_tiles : (int)((wave_tiles + 3) / 4);
     grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
+  }
+  // several cout tiles: the cooperative kernel shares the depthwise work among the waves of a block
+  static const int coop_knob = std::getenv("UFD_COOP") ? std::atoi(std::getenv("UFD_COOP")) : 1;
+  if (coop_knob && n == 1 && ksteps % 8 == 0 && (coop_knob == 2 ? max_cts % 2 == 0 : max_cts % 4 == 0)) {
+    const int ctw = (max_cts % 4 == 0) ? 4 : 2, ptiles = 4 / ctw;
+    p.a[0].cts = max_cts;
+    p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups
+    const unsigned blocks = (unsigned)((p.a[0].tiles + 7) / 8) * 8 * (max_cts / ctw);
+    const size_t clds = (size_t)r.cin * 12 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
+    if (stride == 1) {
+      if (ctw == 4) hipLaunchKernelGGL((k_dwpw_coop<1, 4>), dim3(blocks, 1), dim3(256), clds, s, p);
+      else hipLaunchKernelGGL((k_dwpw_coop<1, 2>), dim3(blocks, 1), dim3(256), clds, s, p);
+    } else {
+      if (ctw == 4) hipLaunchKernelGGL((k_dwpw_coop<2, 4>), dim3(blocks, 1), dim3(256), clds, s, p);
+      else hipLaunchKernelGGL((k_dwpw_coop<2, 2>), dim3(blocks, 1), dim3(256), clds, s, p);
+    }
+    return;
   }
   const dim3 g(grid, n);
   if (sk) {
