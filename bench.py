@@ -40,7 +40,9 @@ KERNEL_FUNCS = {
     "resize_norm": "k_resize_norm",
     "head_decode": "k_head_decode",
     "huffman_rst": "k_huffman_rst",
-    "huffman_sync": "k_huffman_sync",
+    "huff_unstuff": "k_huff_unstuff", "huff_seed": "k_huff_seed", "huff_extend": "k_huff_extend", "huff_link": "k_huff_link",
+    "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
+    "conv_dwpw_coop": "k_dwpw_coop",
     "sort_nms": "k_sort_nms",
 }
 

@@ -1203,6 +1203,13 @@ void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
     hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid, n), dim3(256), wlds, s, p);
 }
 
+bool dwpw_uses_coop(const ConvArgs* args, int n) {
+  // (4 cout tiles per block; the 2-tile form measured slower than k_dwpw_mfma -- UFD_COOP=2 selects it, 0 disables)
+  static const int coop_knob = std::getenv("UFD_COOP") ? std::atoi(std::getenv("UFD_COOP")) : 1;
+  const int cts = (args[0].cout + 31) / 32, ksteps = args[0].cin >> 1;
+  return coop_knob && n == 1 && ksteps % 8 == 0 && (coop_knob == 2 ? cts % 2 == 0 : cts % 4 == 0);
+}
+
 void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t s) {
   ConvArgs3 p{};
   const ConvArgs& r = args[0];
@@ -1221,8 +1228,7 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
   }
   // several cout tiles: the cooperative kernel shares the depthwise work among the waves of a block
-  static const int coop_knob = std::getenv("UFD_COOP") ? std::atoi(std::getenv("UFD_COOP")) : 1;
-  if (coop_knob && n == 1 && ksteps % 8 == 0 && (coop_knob == 2 ? max_cts % 2 == 0 : max_cts % 4 == 0)) {
+  if (dwpw_uses_coop(args, n)) {
     const int ctw = (max_cts % 4 == 0) ? 4 : 2, ptiles = 4 / ctw;
     p.a[0].cts = max_cts;
     p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups

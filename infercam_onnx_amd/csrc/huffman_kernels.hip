@@ -929,7 +929,7 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_raw_bytes, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
-                         uint32_t* d_status, hipStream_t s) {
+                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook) {
   if (!frames) return;
   // upper bound of the subsequence count of any frame (the kernels use the unstuffed length)
   uint32_t sub_bytes = (max_raw_bytes + kSyncMaxSub - 1) / kSyncMaxSub;
@@ -939,17 +939,29 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
   uint8_t* cnt_a = sb.cnt;
   uint8_t* cnt_b = sb.cnt + (size_t)sb.max_frames * kSyncMaxSub;
   const dim3 lanes(kSyncLaneThreads);
-  hipLaunchKernelGGL(k_huff_unstuff, dim3(frames), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb);
-  hipLaunchKernelGGL(k_huff_seed, dim3((nsub * max_blocks_per_mcu + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes,
-                     0, s, d_scans, d_luts, sb, cnt_a);
+  // (hook: per-kernel profiling scopes of the caller; begin = true before, false after the launch)
+  auto stage = [&](const char* name, auto&& launch) {
+    if (hook && *hook) (*hook)(name, true);
+    launch();
+    if (hook && *hook) (*hook)(name, false);
+  };
+  stage("huff_unstuff", [&] { hipLaunchKernelGGL(k_huff_unstuff, dim3(frames), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb); });
+  stage("huff_seed", [&] {
+    hipLaunchKernelGGL(k_huff_seed, dim3((nsub * max_blocks_per_mcu + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s,
+                       d_scans, d_luts, sb, cnt_a);
+  });
   const dim3 gext((nsub * kHypSlots + kSyncLaneThreads - 1) / kSyncLaneThreads, frames);
-  hipLaunchKernelGGL(k_huff_extend, gext, lanes, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_a, cnt_b);
-  hipLaunchKernelGGL(k_huff_extend, gext, lanes, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_b, cnt_a);
-  hipLaunchKernelGGL(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_a);
-  hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_a, d_status);
-  hipLaunchKernelGGL(k_huff_write, dim3((nsub + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
-                     d_luts, d_descs, sb, d_coef, coef_stride, d_status);
-  hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_ivs, d_descs, d_coef, coef_stride);
+  stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext, lanes, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_a, cnt_b); });
+  stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext, lanes, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_b, cnt_a); });
+  stage("huff_link", [&] { hipLaunchKernelGGL(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_a); });
+  stage("huff_resolve", [&] {
+    hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_a, d_status);
+  });
+  stage("huff_write", [&] {
+    hipLaunchKernelGGL(k_huff_write, dim3((nsub + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
+                       d_luts, d_descs, sb, d_coef, coef_stride, d_status);
+  });
+  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_ivs, d_descs, d_coef, coef_stride); });
 }
 
 }  // namespace ufd

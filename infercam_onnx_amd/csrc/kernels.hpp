@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 
 #include "jpeg_host.hpp"
 
@@ -71,6 +72,8 @@ struct SyncBuffers {
   unsigned long long* map = nullptr;  // [frame][subsequence] slot -> slot of the next subsequence, 16 nibbles
   uint32_t max_frames = 0;
 };
+// Called before (true) and after (false) each kernel of the pipeline with its short name (profiling).
+using HuffStageHook = std::function<void(const char* kernel, bool begin)>;
 // Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers* layout);
 // Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
@@ -78,7 +81,7 @@ void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, ui
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_raw_bytes, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
-                         uint32_t* d_status, hipStream_t s);
+                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook = nullptr);
 
 // 4:2:0 YCbCr specialisation (every frame of the batch: 3 components, 2x2 luma sampling, fancy
 // upsampling applicable, W % 8 == 0): same results, 8 pixels per thread with wide loads.
@@ -135,6 +138,8 @@ void pack_pointwise_weights(const float* w /*[cout][cin]*/, int cin, int cout, f
 bool dwpw_supported(const ConvArgs& a, int stride);
 // Two consecutive dw->pw blocks (stride 1 then stride 2, 16 -> 32 -> <=32 channels) in one launch:
 // `first` / `second` are the ConvArgs of the two pointwise layers as for launch_conv_dwpw_mfma.
+// True when launch_conv_dwpw_mfma runs these layers on the cooperative kernel (k_dwpw_coop).
+bool dwpw_uses_coop(const ConvArgs* args, int n);
 bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second);
 void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipStream_t s);
 size_t depthwise_packed_floats(int c);

@@ -751,7 +751,7 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   const char* kind = "conv_direct_full";
   switch (L.kind) {
     case kKindPointwise: kind = "conv_pw_mfma"; break;
-    case kKindDwPw: kind = "conv_dwpw_mfma"; break;
+    case kKindDwPw: kind = dwpw_uses_coop(args, n) ? "conv_dwpw_coop" : "conv_dwpw_mfma"; break;
     case kKindDwPw2: break;  // issued above
     case kKindConv3x3:
       use_rows = n == 1 && conv3x3_rows_supported(a);
@@ -1044,12 +1044,20 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
 // pointers are device memory (the context's double buffers, or a staged batch).
 int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t count, const uint8_t* d_blob,
                            const JpegFrameDesc* d_descs, const HuffScan* d_scans, const HuffInterval* d_ivs, int16_t* d_coef) {
-  launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.stream);
+  {
+    ProfScope ps(m, "zero_coef", (double)p.used_coef * 2 * count, 0);
+    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.stream);
+  }
   HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
   if (p.sync_path) {
-    ProfScope ps(m, "huffman_sync", (double)p.used_blob * count, 0);
+    std::unique_ptr<ProfScope> scope;
+    const double bytes = (double)p.used_blob * count;
+    const HuffStageHook hook = [&](const char* kernel, bool begin) {
+      if (begin) scope.reset(new ProfScope(m, kernel, bytes, 0));
+      else scope.reset();
+    };
     launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_raw, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
-                        c.sync, c.d_status, c.stream);
+                        c.sync, c.d_status, c.stream, &hook);
   } else {
     ProfScope ps(m, "huffman_rst", (double)p.used_blob * count, 0);
     launch_huffman_rst(d_blob, d_scans, d_ivs, p.n_iv, m->d_luts, d_descs, d_coef, m->coef_stride, c.d_status, c.stream);

@@ -262,7 +262,7 @@ def test_device_sync_decoder_is_the_path_taken(weights):
         _, st = m.infer_jpeg_batch(jpegs)
         assert st == [0] * 4
         names = {p["name"] for p in m.profile_read()}
-        assert "huffman_sync" in names and "h2d_coef" not in names, names
+        assert "huff_write" in names and "h2d_coef" not in names, names
     finally:
         m.close()
 
@@ -284,8 +284,8 @@ def test_default_handle_routes_entropy_by_stream_kind(weights, oracle_lib):
             assert st == [0] * 3
             seen.append({p["name"] for p in m.profile_read() if p["launches"] > 0})
             results.append(res)
-        assert "huffman_sync" in seen[0] and "h2d_coef" not in seen[0]
-        assert "h2d_coef" in seen[1] and "huffman_sync" not in seen[1] and "huffman_rst" not in seen[1]
+        assert "huff_write" in seen[0] and "h2d_coef" not in seen[0]
+        assert "h2d_coef" in seen[1] and "huff_write" not in seen[1] and "huffman_rst" not in seen[1]
         assert "h2d_coef" in seen[2]
         assert results[0] == results[1]  # same pixels (baseline, same quantisation), same kernels
     finally:

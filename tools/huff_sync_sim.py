@@ -1,4 +1,4 @@
-"""Host simulation of the self-synchronising subsequence decoder (huffman_kernels.hip k_huffman_sync):
+"""Host simulation of the self-synchronising subsequence decoder (huffman_kernels.hip the k_huff_* pipeline):
 how many fixed-point rounds does a frame need, and how many subsequences are re-decoded per round?
 Design aid only -- not on any product or test path."""
 import sys
