@@ -587,7 +587,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* s_dw2 = s_w1 + KS1 * 64;   // [32][12]
   float* s_w2 = s_dw2 + 32 * 12;    // [KS2][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
+  // Workgroup ids are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of
+  // tiles, so that neighbouring tiles (which share input rows) meet in the same L2 close in time.
+  const int per_xcd = (int)gridDim.x >> 3;  // the grid is a multiple of 8
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (tile >= a2.tiles) return;  // whole block, before the barrier
   {
     auto copy4 = [&](float* dst, const float* src, int n4) {
@@ -1280,7 +1283,7 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   p.a[1].tiles = (int)((wave_tiles + 3) / 4);
   p.a[1].cts = 1;
   const size_t lds = ((size_t)16 * 12 + 8 * 64 + 32 * 12 + 16 * 64) * sizeof(float);
-  hipLaunchKernelGGL((k_dwpw2_mfma<16>), dim3((unsigned)p.a[1].tiles), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_dwpw2_mfma<16>), dim3((unsigned)((p.a[1].tiles + 7) / 8 * 8)), dim3(256), lds, s, p);
 }
 
 void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {
