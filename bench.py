@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--entropy", choices=["host", "device"], default="device",
                     help="where the Huffman stage runs (device: self-synchronising decoder kernels; "
                          "host: worker threads, coefficient slabs over PCIe)")
+    ap.add_argument("--src", default="640x480", help="frame size of the synthetic stream (BASELINE config C5: 1280x720, --batch 16)")
     ap.add_argument("--no-variants", action="store_true", help="skip the PCIe-inclusive comparison runs")
     ap.add_argument("--restart-rows", type=int, default=0,
                     help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
@@ -117,10 +118,11 @@ def main():
     priors = synth.gen_priors(W, H)
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
-    jpegs = synth.synth_jpeg_pool(rank, args.pool, W, H, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
+    SW, SH = (int(v) for v in args.src.lower().split("x"))
+    jpegs = synth.synth_jpeg_pool(rank, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
     device_entropy = args.entropy == "device" or args.input == "hbm"
     model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
-                              weights=weights, priors=priors, max_src=(W, H), host_threads=args.host_threads,
+                              weights=weights, priors=priors, max_src=(SW, SH), host_threads=args.host_threads,
                               profile=True, det_cap=256, device_entropy=device_entropy and args.restart_rows > 0,
                               host_entropy=not device_entropy)
     nb = max(1, args.pool // B)
@@ -176,7 +178,7 @@ def main():
         torch.cuda.synchronize()
         variants["host_bytes_device_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
         m2 = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
-                               priors=priors, max_src=(W, H), host_threads=args.host_threads, det_cap=256,
+                               priors=priors, max_src=(SW, SH), host_threads=args.host_threads, det_cap=256,
                                host_entropy=True)
         hb2 = [m2._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
         run_steps(args.warmup, mdl=m2, bts=hb2, staged=False)
@@ -226,9 +228,9 @@ def main():
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UltraFace-640, one 640x480 synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
+            "config": {"workload": "UltraFace-640, one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
                                    "frames, %s), batch=%d, seeded synthetic weights" % (
-                                       args.pool, "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows
+                                       SW, SH, args.pool, "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows
                                        else "no restart markers", B),
                        "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
                        "entropy_decode": "GPU kernels" if device_entropy else "host worker threads",

@@ -1215,6 +1215,24 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       }
       HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
       tl_cur->consumed_valid[buf] = true;
+      // one camera stream = one frame size: the whole batch in one launch (failed frames resample
+      // stale pixels, their results are never reported); mixed sizes go frame by frame
+      bool same_size = true;
+      int sw = 0, sh = 0;
+      for (uint32_t i = 0; i < count; i++) {
+        if (s.st[i] != UFD_OK) continue;
+        const JpegFrameDesc& d = s.h_descs[i];
+        if (!sw) sw = d.width, sh = d.height;
+        if (d.width != sw || d.height != sh) same_size = false;
+      }
+      if (same_size && sw && count > 1) {
+        ResizeTaps v, h;
+        rc = get_taps(m, sw, sh, &v, &h);
+        if (rc) return rc;
+        ProfScope ps(m, "resize_norm", (double)count * (3.0 * sw * sh + 12.0 * m->W * m->H), 0);
+        launch_resize_norm(tl_cur->d_rgb, sw, sh, sw * 3, m->rgb_stride, v, h, m->d_lut, tl_cur->d_input, m->W, m->H, count,
+                           tl_cur->stream);
+      } else
       for (uint32_t i = 0; i < count; i++) {
         if (s.st[i] != UFD_OK) continue;
         const JpegFrameDesc& d = s.h_descs[i];
