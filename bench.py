@@ -123,8 +123,7 @@ def main():
     device_entropy = args.entropy == "device" or args.input == "hbm"
     model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
                               weights=weights, priors=priors, max_src=(SW, SH), host_threads=args.host_threads,
-                              profile=True, det_cap=256, device_entropy=device_entropy and args.restart_rows > 0,
-                              host_entropy=not device_entropy)
+                              profile=True, det_cap=256, host_entropy=not device_entropy)
     nb = max(1, args.pool // B)
     if args.input == "hbm":
         # inputs resident in HBM before the clock starts: bytes + parsed headers of every batch

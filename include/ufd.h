@@ -72,11 +72,11 @@ typedef struct ufd_config {
 
 #define UFD_FLAG_KEEP_LAYERS 1u /* keep every conv output resident for ufd_debug_layer_output */
 #define UFD_FLAG_PROFILE 2u     /* record HIP events around every kernel (ufd_profile_read) */
-/* Entropy (Huffman) stage of the JPEG decode.  Default (neither flag): baseline single-scan
- * streams WITHOUT restart markers are decoded by the GPU kernels (self-synchronising parallel
- * decoder: the host only scans headers and markers); streams with restart markers, progressive
- * and multi-scan files are decoded by the handle's host worker threads. */
-#define UFD_FLAG_DEVICE_ENTROPY 4u /* also decode restart-interval streams on the GPU (one lane per interval: slow) */
+/* Entropy (Huffman) stage of the JPEG decode.  By default baseline single-scan streams, with or
+ * without restart markers, are decoded by the GPU kernels (self-synchronising parallel decoder:
+ * the host only scans headers and markers); progressive and multi-scan files are decoded by the
+ * handle's host worker threads. */
+#define UFD_FLAG_DEVICE_ENTROPY 4u /* accepted for compatibility: the GPU entropy kernels are the default */
 #define UFD_FLAG_HOST_ENTROPY 8u   /* never use the GPU entropy kernels */
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */

@@ -1,11 +1,9 @@
 // huffman_kernels.hip -- entropy-decoding half of row A1 on the device (the part of
 // turbojpeg::decompress_image, infer_server/src/inferer.rs:35, that libjpeg-turbo does in
-// jdhuff.c), for baseline streams with restart intervals: every restart interval is an
-// independent Huffman stream with reset DC predictors, so one lane decodes one interval
-// (camera MJPG with one interval per MCU row: 30 intervals per 640x480 frame, 960 per 32-frame
-// batch).  Serial bit-twiddling per lane, irregular byte gathers: latency-bound integer work
-// that runs beside the other context's convolution kernels.  The coefficient slab is zeroed by a
-// memset node before the launch; lanes store only non-zero coefficients (natural order).
+// jdhuff.c) for baseline single-scan streams, with or without restart markers.  Serial
+// bit-twiddling per lane, latency-bound integer work in short launches that run beside the other
+// context's convolution kernels.  The coefficient slab is zeroed first; lanes store only non-zero
+// coefficients.
 #include "kernels.hpp"
 
 #include <algorithm>
@@ -13,196 +11,6 @@
 
 namespace ufd {
 namespace {
-
-__constant__ uint8_t c_zigzag[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33,
-                                     40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
-                                     29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54,
-                                     47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
-
-// Bit reader over one interval.  Bytes come from 8-byte aligned chunks held in registers with two
-// chunks prefetched ahead, so the lane issues one global load per 8 input bytes and never waits
-// on a byte-by-byte dependent chain; 0xFF00 unstuffing happens in registers.
-struct BitReader {
-  const uint64_t* q;      // next aligned chunk to prefetch
-  uint64_t cur, n1, n2;   // chunk being consumed + two prefetched
-  int ci;                 // next byte inside cur (0..8)
-  int remaining;          // bytes of the interval not yet consumed
-  uint64_t acc;
-  int n;                  // valid bits at the top of acc
-  int pad;                // zero bits appended past the end of the interval
-
-  __device__ __forceinline__ void init(const uint8_t* begin, const uint8_t* end) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(begin);
-    q = reinterpret_cast<const uint64_t*>(a & ~(uintptr_t)7);
-    ci = (int)(a & 7);
-    remaining = (int)(end - begin);
-    cur = q[0], n1 = q[1], n2 = q[2];  // the blob has >= 32 bytes of slack behind every frame
-    q += 3;
-    acc = 0, n = 0, pad = 0;
-  }
-  __device__ __forceinline__ unsigned next_byte() {
-    if (ci == 8) {
-      cur = n1, n1 = n2, n2 = *q++;
-      ci = 0;
-    }
-    const unsigned b = (unsigned)(cur >> (8 * ci)) & 0xFFu;
-    ci++;
-    remaining--;
-    return b;
-  }
-  __device__ __forceinline__ void fill() {
-    while (n <= 56) {
-      unsigned c = 0;
-      if (remaining > 0) {
-        c = next_byte();
-        if (c == 0xFF) {
-          if (remaining > 0 && next_byte() == 0) {
-            // stuffed zero consumed
-          } else {
-            remaining = 0;  // fill byte or marker: the interval's data is over
-            c = 0;
-            pad += 8;
-          }
-        }
-      } else {
-        pad += 8;
-      }
-      acc |= (uint64_t)c << (56 - n);
-      n += 8;
-    }
-  }
-  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (64 - k)); }
-  __device__ __forceinline__ void skip(int k) {
-    acc <<= k;
-    n -= k;
-  }
-  __device__ __forceinline__ int get(int k) {  // 1..16 bits
-    if (n < k) fill();
-    const int v = (int)peek(k);
-    skip(k);
-    return v;
-  }
-  __device__ __forceinline__ bool overrun() const { return pad > 0 && n < pad; }
-};
-
-__device__ __forceinline__ int decode_symbol(BitReader& br, const HuffLut* __restrict__ t) {
-  const int e = t->fast[br.peek(10)];
-  if (e) {
-    br.skip(e >> 8);
-    return e & 0xFF;
-  }
-  const int code = (int)br.peek(16);
-  int l = 11;
-  while (l <= 16 && code >= t->maxcode[l]) l++;
-  if (l > 16) return -1;
-  br.skip(l);
-  return t->sym[((code >> (16 - l)) + t->delta[l]) & 0xFF];
-}
-
-__device__ __forceinline__ int extend(int v, int s) { return v < (1 << (s - 1)) ? v + (int)(0xFFFFFFFFu << s) + 1 : v; }
-
-__global__ __launch_bounds__(64) void k_huffman_rst(const uint8_t* __restrict__ blob, const HuffScan* __restrict__ scans,
-                                                    const HuffInterval* __restrict__ ivs, uint32_t n_iv,
-                                                    const HuffLut* __restrict__ luts,
-                                                    const JpegFrameDesc* __restrict__ descs, int16_t* __restrict__ coef,
-                                                    size_t coef_stride, uint32_t* __restrict__ status) {
-  // the wave's table set (frames of one camera stream share it) lives in LDS: every symbol is a
-  // dependent table lookup, LDS latency instead of a global round trip
-  // (the host only takes this path when every frame of the batch uses the same table set and
-  // MCU layout, so both are wave-uniform: plain LDS addressing, no generic pointers)
-  __shared__ HuffLut s_lut[4];
-  __shared__ uint32_t s_blk[12];  // per block of the MCU: comp | bx << 8 | by << 12 | dc << 16 | ac << 20
-  const uint32_t t0 = blockIdx.x * 64;
-  {
-    const HuffScan& s0 = scans[ivs[min(t0, n_iv - 1)].frame];
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(luts + s0.lut_base);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(s_lut);
-    for (int i = threadIdx.x; i < (int)(sizeof(HuffLut) * 4 / 4); i += 64) dst[i] = src[i];
-    if (threadIdx.x < 12)
-      s_blk[threadIdx.x] = s0.blk_comp[threadIdx.x] | (s0.blk_bx[threadIdx.x] << 8) | (s0.blk_by[threadIdx.x] << 12) |
-                           (s0.blk_dc[threadIdx.x] << 16) | (s0.blk_ac[threadIdx.x] << 20);
-  }
-  __syncthreads();
-  const uint32_t t = t0 + threadIdx.x;
-  if (t >= n_iv) return;
-  const HuffInterval iv = ivs[t];
-  const HuffScan& sc = scans[iv.frame];
-  const JpegFrameDesc& d = descs[iv.frame];
-  const uint8_t* base = blob + sc.blob_off;
-  BitReader br;
-  br.init(base + iv.begin, base + iv.end);
-  int16_t* fcoef = coef + (size_t)iv.frame * coef_stride;
-  const int bpm = (int)sc.blocks_per_mcu;
-  const int mcux = d.mcux;
-  // Flat state machine, ONE symbol per loop iteration for every lane: lanes of a wave sit in
-  // different blocks / zigzag positions, and nested per-block loops would make the wave run
-  // sum-over-blocks(max-over-lanes(symbols)) iterations instead of max-over-lanes(total symbols).
-  int m = 0, j = 0, k = 0;  // MCU inside the interval, block inside the MCU, zigzag position (0 = DC next)
-  int pred0 = 0, pred1 = 0, pred2 = 0;
-  bool bad = false;
-  int16_t* blk = nullptr;
-  int comp = 0;
-  uint32_t binfo = 0;
-  bool need_block = true;
-  while (m < (int)iv.nmcu) {
-    if (need_block) {
-      const int mcu = (int)iv.mcu0 + m;
-      const int my = mcu / mcux, mx = mcu - my * mcux;
-      binfo = s_blk[j];
-      comp = binfo & 0xFF;
-      const int row = my * d.v[comp] + ((binfo >> 12) & 15), col = mx * d.h[comp] + ((binfo >> 8) & 15);
-      blk = fcoef + d.coef_off[comp] + ((size_t)row * d.wblk[comp] + col) * 64;
-      need_block = false;
-    }
-    if (br.n < 32) br.fill();  // >= 32 bits: a 16-bit code plus its 16 magnitude bits
-    const HuffLut* t = (k == 0) ? &s_lut[(binfo >> 16) & 1] : &s_lut[2 + ((binfo >> 20) & 1)];
-    const int rs = decode_symbol(br, t);
-    if (rs < 0) {
-      bad = true;
-      break;
-    }
-    if (k == 0) {
-      if (rs > 15) {
-        bad = true;
-        break;
-      }
-      int pred = comp == 0 ? pred0 : (comp == 1 ? pred1 : pred2);
-      if (rs) pred += extend((int)br.peek(rs), rs), br.skip(rs);
-      if (comp == 0) pred0 = pred; else if (comp == 1) pred1 = pred; else pred2 = pred;
-      if (pred) blk[0] = (int16_t)pred;
-      k = 1;
-    } else {
-      const int r = rs >> 4, sz = rs & 15;
-      if (sz == 0) {
-        k = (r == 15) ? k + 16 : 64;  // ZRL or EOB
-      } else {
-        k += r;
-        if (k > 63) {
-          bad = true;
-          break;
-        }
-        blk[c_zigzag[k]] = (int16_t)extend((int)br.peek(sz), sz);
-        br.skip(sz);
-        k++;
-      }
-    }
-    if (k >= 64) {  // block finished
-      k = 0;
-      need_block = true;
-      if (++j == bpm) {
-        j = 0;
-        m++;
-        if (br.overrun()) {
-          bad = true;
-          break;
-        }
-      }
-    }
-  }
-  if (br.overrun()) bad = true;
-  if (bad) atomicOr(&status[iv.frame], 1u);
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Self-synchronising parallel decoder for streams WITHOUT restart markers (the common camera
@@ -420,11 +228,6 @@ constexpr int kSyncLaneThreads = 256;  // seed / extend / write: one lane per (s
 constexpr int kHypSlots = 16;          // cached (entry -> exit) pairs per subsequence; nibble 15 = "not cached"
 constexpr int kHypAppendMax = 14;      // the speculation rounds fill slots 0..13, k_huff_resolve may use 14
 
-__device__ __forceinline__ uint32_t sync_sub_bytes(uint32_t raw_bytes) {
-  const uint32_t b = (raw_bytes + kSyncMaxSub - 1) / kSyncMaxSub;
-  return max((b + 3u) & ~3u, (uint32_t)kSyncMinBytes);
-}
-
 static_assert(sizeof(SyncLutImage) % 16 == 0 && offsetof(SyncTables, blk) == sizeof(SyncLutImage), "image layout");
 
 // Fills the block's tables: the table-set image with wide loads that are all in flight at once
@@ -465,55 +268,101 @@ __device__ __forceinline__ void load_sync_tables(SyncTables& T, const HuffScan& 
   }
 }
 
+// Unstuffs every segment of the frame into its subsequence slots (segment q starts at slot
+// ivs[q].first_sub) and fills the per-slot tables.  Two passes over the raw range with a block
+// scan each: pass 1 counts the stuffed zeros in front of every segment begin / end, pass 2 stores
+// the kept bytes at  slot offset + (position - begin) - (stuffed zeros since begin).
 __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __restrict__ blob,
                                                                const HuffScan* __restrict__ scans,
                                                                const HuffInterval* __restrict__ ivs, SyncBuffers sb) {
   __shared__ int s_wave[kSyncThreads / 64];
+  __shared__ uint32_t s_beg[kSyncMaxSeg], s_end[kSyncMaxSeg], s_zb[kSyncMaxSeg], s_ze[kSyncMaxSeg];
   const int frame = blockIdx.x, tid = threadIdx.x;
-  const HuffInterval iv = ivs[frame];
+  const HuffScan& sc = scans[frame];
   SyncFrame* fr = sb.frames + frame;
-  if (iv.nmcu == 0) {  // frame failed on the host side (uniform per block)
+  const int nseg = (int)sc.nseg;
+  if (nseg == 0) {  // frame failed on the host side (uniform per block)
     if (tid == 0) fr->total_bits = 0, fr->nsub = 0, fr->sub_bits = kSyncMinBytes * 8;
     return;
   }
-  const uint8_t* src = blob + scans[frame].blob_off;  // 16-byte aligned
+  const HuffInterval* seg = ivs + sc.seg_base;
+  for (int q = tid; q < nseg; q += kSyncThreads) s_beg[q] = seg[q].begin, s_end[q] = seg[q].end, s_zb[q] = 0, s_ze[q] = 0;
+  __syncthreads();
+  const uint8_t* src = blob + sc.blob_off;  // 16-byte aligned
   uint8_t* dst = sb.stream + (size_t)frame * sb.stream_stride;
-  uint32_t out_base = 0;
-  for (uint32_t tile = iv.begin & ~15u; tile < iv.end; tile += kSyncThreads * 16) {
-    const uint32_t off = tile + (uint32_t)tid * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    unsigned prev = 0;
-    if (off < iv.end) {
-      v = *reinterpret_cast<const uint4*>(src + off);
-      if (off > iv.begin) prev = src[off - 1];
+  const uint32_t lo = s_beg[0], hi = s_end[nseg - 1];
+  const uint32_t sub_bytes = sc.sub_bytes;
+  // first segment whose end lies behind `pos` (binary search in LDS)
+  auto seg_behind = [&](uint32_t pos) {
+    int a = 0, b = nseg;
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (s_end[mid] > pos) b = mid; else a = mid + 1;
     }
-    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-    uint32_t keep = 0;
-    unsigned pb = prev;
+    return a;
+  };
+  for (int pass = 0; pass < 2; pass++) {
+    uint32_t zbase = 0;  // stuffed zeros in front of the tile
+    for (uint32_t tile = lo & ~15u; tile <= hi; tile += kSyncThreads * 16) {
+      const uint32_t off = tile + (uint32_t)tid * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      unsigned prev = 0;
+      if (off < hi) {
+        v = *reinterpret_cast<const uint4*>(src + off);
+        if (off > lo) prev = src[off - 1];
+      }
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+      uint32_t zmask = 0;  // stuffed zero bytes of the piece (0xFF 0x00 only occurs inside segments)
+      unsigned pb = prev;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const unsigned b = (w4[j >> 2] >> (8 * (j & 3))) & 0xFF;
-      const uint32_t pos = off + j;
-      if (pos == iv.begin) pb = 0;
-      if (pos >= iv.begin && pos < iv.end && !(b == 0 && pb == 0xFF)) keep |= 1u << j;
-      pb = b;
+      for (int j = 0; j < 16; j++) {
+        const unsigned bv = (w4[j >> 2] >> (8 * (j & 3))) & 0xFF;
+        const uint32_t pos = off + j;
+        if (pos >= lo && pos < hi && bv == 0 && pb == 0xFF) zmask |= 1u << j;
+        pb = bv;
+      }
+      int total;
+      const uint32_t myz = zbase + (uint32_t)block_exscan(__popc(zmask), s_wave, &total);
+      if (off <= hi) {
+        int q = seg_behind(off > 0 ? off - 1 : 0);  // segments ending at `off` still need their end count
+        if (pass == 0) {
+          for (; q < nseg && s_beg[q] < off + 16; q++) {
+            const uint32_t bq = s_beg[q], eq = s_end[q];
+            if (bq >= off) s_zb[q] = myz + __popc(zmask & ((1u << (bq - off)) - 1));
+            if (eq >= off && eq < off + 16) s_ze[q] = myz + __popc(zmask & ((1u << (eq - off)) - 1));
+          }
+        } else {
+#pragma unroll 1
+          for (int j = 0; j < 16; j++) {
+            const uint32_t pos = off + j;
+            while (q < nseg && pos >= s_end[q]) q++;
+            if (q >= nseg) break;
+            if (pos < s_beg[q] || (zmask & (1u << j))) continue;
+            const uint32_t o = seg[q].first_sub * sub_bytes + (pos - s_beg[q]) - (myz + __popc(zmask & ((1u << j) - 1)) - s_zb[q]);
+            dst[o] = (uint8_t)((w4[j >> 2] >> (8 * (j & 3))) & 0xFF);
+          }
+        }
+      }
+      zbase += (uint32_t)total;
     }
-    const int cnt = __popc(keep);
-    int total;
-    const int my_off = block_exscan(cnt, s_wave, &total);
-    uint8_t* o = dst + out_base + my_off;
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-      if (keep & (1u << j)) *o++ = (uint8_t)((w4[j >> 2] >> (8 * (j & 3))) & 0xFF);
-    out_base += (uint32_t)total;
+    __syncthreads();
   }
-  if (tid < 48) dst[out_base + tid] = 0;  // the bit window reads up to 3 words past the last symbol
-  if (tid == 0) {
-    const uint32_t sub_bytes = sync_sub_bytes(iv.end - iv.begin);
-    fr->total_bits = out_base * 8;
-    fr->sub_bits = sub_bytes * 8;
-    fr->nsub = (out_base + sub_bytes - 1) / sub_bytes;
+  // per segment: zero slack behind the data, slot tables
+  uint32_t* lim = sb.lim + (size_t)frame * kSyncMaxSub;
+  uint16_t* sseg = sb.seg + (size_t)frame * kSyncMaxSub;
+  for (int q = tid; q < nseg; q += kSyncThreads) {
+    const uint32_t len = (s_end[q] - s_beg[q]) - (s_ze[q] - s_zb[q]);
+    const uint32_t first = seg[q].first_sub;
+    const uint32_t next = q + 1 < nseg ? seg[q + 1].first_sub : sc.nsub;
+    uint8_t* z = dst + (size_t)first * sub_bytes + len;
+    for (int k = 0; k < 32; k++) z[k] = 0;  // the bit window reads a few words past the last symbol
+    const uint32_t end_bits = (first * sub_bytes + len) * 8;
+    for (uint32_t i = first; i < next; i++) {
+      lim[i] = min((i + 1) * sub_bytes * 8, max(end_bits, i * sub_bytes * 8)) | (i == first ? 0x80000000u : 0u);
+      sseg[i] = (uint16_t)q;
+    }
   }
+  if (tid == 0) fr->total_bits = sc.nsub * sub_bytes * 8, fr->sub_bits = sub_bytes * 8, fr->nsub = sc.nsub;
 }
 
 // The lanes of a block decode neighbouring subsequences: their part of the stream is staged in LDS
@@ -527,7 +376,7 @@ __device__ __forceinline__ const uint32_t* stage_stream(uint32_t* s_stream, cons
                                                         uint32_t i_lo, uint32_t i_hi, int tid, int nthreads) {
   const uint32_t sub_words = fr.sub_bits >> 5;
   const uint32_t w0 = i_lo * sub_words;
-  const uint32_t w1 = min((i_hi + 1) * sub_words + 8, (fr.total_bits / 8 + 48) / 4);
+  const uint32_t w1 = min((i_hi + 1) * sub_words + 8, fr.total_bits / 32 + 8);
   if (w1 <= w0 || w1 - w0 > kStageWords) return nullptr;
   for (uint32_t j = tid; j < w1 - w0; j += nthreads) s_stream[j] = words[w0 + j];
   return s_stream - w0;
@@ -552,17 +401,20 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_seed(const HuffScan* 
   __syncthreads();
   const uint32_t i = lane / bpm;
   const int g = (int)(lane - i * bpm);
-  if (i >= fr.nsub || (i == 0 && g != 0)) return;
+  if (i >= fr.nsub) return;
+  const uint32_t lim = sb.lim[(size_t)frame * kSyncMaxSub + i];
+  const bool seg_start = (lim >> 31) != 0;  // first slot of a segment: the entry state is exact
+  if (seg_start && g != 0) return;
   SyncState st;
   st.p = i * fr.sub_bits, st.cz = (uint32_t)g;
   const SyncState entry = st;
-  const uint32_t limit = min((i + 1) * fr.sub_bits, fr.total_bits);
+  const uint32_t limit = lim & 0x7FFFFFFFu;
   const int nm = staged ? sync_span(staged, st, limit, T, bpm) : sync_span(words, st, limit, T, bpm);
   const size_t slot = ((size_t)frame * kSyncMaxSub + i) * kHypSlots + g;
   sb.ent[slot] = make_uint2(entry.p, entry.cz);
   sb.ext[slot] = make_uint2(st.p, st.cz);
   sb.nm[slot] = nm;
-  if (g == 0) cnt_out[(size_t)frame * kSyncMaxSub + i] = (uint8_t)(i == 0 ? 1 : min(bpm, kHypAppendMax));
+  if (g == 0) cnt_out[(size_t)frame * kSyncMaxSub + i] = (uint8_t)(seg_start ? 1 : min(bpm, kHypAppendMax));
 }
 
 // 16 lanes per subsequence i >= 1: lane k owns the exit state cached in slot k of subsequence i-1.
@@ -587,8 +439,10 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_extend(const HuffScan
   const int k = (int)(lane % kHypSlots);
   const bool in_range = i < fr.nsub;
   const size_t fbase = (size_t)frame * kSyncMaxSub;
+  const uint32_t lim = in_range ? sb.lim[fbase + i] : 0x80000000u;
+  const bool seg_start = (lim >> 31) != 0;  // exact entry state: nothing to extend
   const int n_cur = in_range ? cnt_in[fbase + i] : 0;
-  const int n_prev = (in_range && i > 0) ? cnt_in[fbase + i - 1] : 0;
+  const int n_prev = (in_range && !seg_start) ? cnt_in[fbase + i - 1] : 0;
   // lane k holds candidate k (exit state cached in slot k of subsequence i-1) and entry k of
   // subsequence i; the 16 lanes of the group compare through shuffles
   uint2 cand = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), mine = make_uint2(0xFFFFFFFEu, 0xFFFFFFFEu);
@@ -610,7 +464,7 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_extend(const HuffScan
   if (!fresh || slot >= kHypAppendMax) return;
   SyncState st;
   st.p = cand.x, st.cz = cand.y;
-  const uint32_t limit = min((i + 1) * fr.sub_bits, fr.total_bits);
+  const uint32_t limit = lim & 0x7FFFFFFFu;
   const int nm = staged ? sync_span(staged, st, limit, T, (int)sc.blocks_per_mcu)
                         : sync_span(words, st, limit, T, (int)sc.blocks_per_mcu);
   const size_t o = (fbase + i) * kHypSlots + slot;
@@ -648,7 +502,11 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_link(SyncBuffers sb, 
     lo |= __shfl_xor(lo, o, 64);
     hi |= __shfl_xor(hi, o, 64);
   }
-  if (k == 0 && i < fr.nsub) sb.map[fbase + i] = has_next ? ((unsigned long long)hi << 32) | lo : 0xFEDCBA9876543210ull;
+  if (k == 0 && i < fr.nsub) {
+    unsigned long long f = has_next ? ((unsigned long long)hi << 32) | lo : 0xFEDCBA9876543210ull;
+    if (has_next && (sb.lim[fbase + i + 1] >> 31)) f = 0;  // the next slot starts a segment: its slot 0 is exact
+    sb.map[fbase + i] = f;
+  }
 }
 
 // f: slot of subsequence i -> slot of subsequence i+1, 16 nibbles; (g o f)(k) = g(f(k))
@@ -665,6 +523,7 @@ constexpr unsigned long long kSlotAllMiss = 0xFFFFFFFFFFFFFFFFull;
 __device__ __forceinline__ unsigned long long build_slot_map(const SyncBuffers& sb, size_t fbase, uint32_t i,
                                                               const uint8_t* cnt) {
   // exit states of subsequence i looked up among the entry states of subsequence i+1
+  if (sb.lim[fbase + i + 1] >> 31) return 0;  // the next slot starts a segment: its slot 0 is exact
   unsigned long long f = kSlotAllMiss;
   const int n0 = cnt[fbase + i], n1 = cnt[fbase + i + 1];
   for (int k = 0; k < n0; k++) {
@@ -690,14 +549,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_resolve(const HuffScan* _
   __shared__ int s_miss;
   const int frame = blockIdx.x, tid = threadIdx.x;
   const SyncFrame fr = sb.frames[frame];
-  const HuffInterval iv = ivs[frame];
-  if (iv.nmcu == 0) return;
-  const int nsub = (int)fr.nsub;
-  if (nsub == 0) {
-    if (tid == 0) atomicOr(&status[frame], 1u);
-    return;
-  }
   const HuffScan& sc = scans[frame];
+  if (sc.nseg == 0) return;
+  const HuffInterval* seg = ivs + sc.seg_base;
+  const int nsub = (int)fr.nsub;
   load_sync_tables(T, sc, luts, nullptr, tid, kSyncThreads);
   const size_t fbase = (size_t)frame * kSyncMaxSub;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(sb.stream + (size_t)frame * sb.stream_stride);
@@ -748,7 +603,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_resolve(const HuffScan* _
       const uint2 x = sb.ext[(fbase + m - 1) * kHypSlots + tq];
       SyncState st;
       st.p = x.x, st.cz = x.y;
-      const int nm = sync_span(words, st, min((uint32_t)(m + 1) * fr.sub_bits, fr.total_bits), T, (int)sc.blocks_per_mcu);
+      const int nm = sync_span(words, st, sb.lim[fbase + m] & 0x7FFFFFFFu, T, (int)sc.blocks_per_mcu);
       const int n = cnt[fbase + m];
       const int dst = n < kHypSlots - 1 ? n : kHypSlots - 2;  // append, or recycle the last usable slot
       const size_t o = (fbase + m) * kHypSlots + dst;
@@ -778,15 +633,30 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_resolve(const HuffScan* _
     }
     sum += my_nm[q];
   }
+  // MCUs completed in front of every slot (scan over the frame), then relative to its segment
   int total;
   int first = block_exscan(sum, s_wave, &total);
+  __shared__ int s_ex[kSyncMaxSub + 1];
 #pragma unroll
   for (int q = 0; q < kPer; q++) {
     const int i = tid * kPer + q;
-    if (i < nsub) sb.mcu0[fbase + i] = first;
+    if (i < nsub) s_ex[i] = first;
     first += my_nm[q];
   }
-  if (tid == 0 && total < (int)iv.nmcu) atomicOr(&status[frame], 1u);  // the data ended before the last MCU
+  if (tid == 0) s_ex[nsub] = total;
+  __syncthreads();
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int i = tid * kPer + q;
+    if (i >= nsub) continue;
+    const HuffInterval& sg = seg[sb.seg[fbase + i]];
+    sb.mcu0[fbase + i] = (int)sg.mcu0 + s_ex[i] - s_ex[sg.first_sub];
+    // last slot of the segment: the segment must have produced exactly its MCUs
+    const bool last = i + 1 == nsub || (sb.lim[fbase + i + 1] >> 31);
+    if (last && s_ex[i + 1] - s_ex[sg.first_sub] < (int)sg.nmcu) bad = true;  // the data ended before the last MCU
+  }
+  if (bad) atomicOr(&status[frame], 1u);
 }
 
 __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan* __restrict__ scans,
@@ -814,28 +684,34 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
   SyncState st;
   st.p = e.x, st.cz = e.y;
   bool bad = false;
-  const uint32_t limit = min((i + 1) * fr.sub_bits, fr.total_bits);
+  const uint32_t limit = sb.lim[fbase + i] & 0x7FFFFFFFu;
+  const HuffInterval& sg = ivs[sc.seg_base + sb.seg[fbase + i]];
+  const int mcu_end = (int)(sg.mcu0 + sg.nmcu);  // (a segment never writes into the next one's MCUs)
   if (staged)
-    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i],
-               (int)ivs[frame].nmcu, &bad);
+    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i], mcu_end,
+               &bad);
   else
-    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i],
-               (int)ivs[frame].nmcu, &bad);
+    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i], mcu_end,
+               &bad);
   if (bad) atomicOr(&status[frame], 1u);
 }
 
-// DC differences -> DC values: per component a running sum over the blocks in scan order
-// (jdhuff.c last_dc_val).  One workgroup per frame, one MCU per thread and pass.
-__global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffInterval* __restrict__ ivs,
+// DC differences -> DC values: per component a running sum over the blocks in scan order, restarted
+// at every restart interval (jdhuff.c last_dc_val / process_restart).  One workgroup per frame,
+// one MCU per thread and pass.
+__global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __restrict__ scans,
                                                             const JpegFrameDesc* __restrict__ descs,
                                                             int16_t* __restrict__ coef, size_t coef_stride) {
   __shared__ int s_wave[kSyncThreads / 64];
+  __shared__ int s_pre[3][kSyncThreads];  // exclusive prefix of this pass (without the carry)
   const int frame = blockIdx.x, tid = threadIdx.x;
-  if (ivs[frame].nmcu == 0) return;
+  if (scans[frame].nseg == 0) return;
   const JpegFrameDesc& d = descs[frame];
   int16_t* fcoef = coef + (size_t)frame * coef_stride;
   const int total = d.mcux * d.mcuy;
-  int carry[3] = {0, 0, 0};
+  const int ri = d.restart_interval > 0 ? d.restart_interval : total;
+  int carry[3] = {0, 0, 0};      // sum over all MCUs in front of this pass
+  int seg_carry[3] = {0, 0, 0};  // ... in front of the restart interval that is open at the start of the pass
   for (int base = 0; base < total; base += kSyncThreads) {
     const int mcu = base + tid;
     const bool valid = mcu < total;
@@ -846,12 +722,20 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffInterval* 
         for (int by = 0; by < d.v[c]; by++)
           for (int bx = 0; bx < d.h[c]; bx++)
             sums[c] += fcoef[d.coef_off[c] + ((size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx) * 64];
+    int pre[3], tot[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      pre[c] = block_exscan(sums[c], s_wave, &tot[c]);
+      s_pre[c][tid] = pre[c];
+    }
+    __syncthreads();
+    // predictor = (sum in front of this MCU) - (sum in front of its restart interval)
+    const int seg_start = (mcu / ri) * ri;
     int pred[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      int tot;
-      pred[c] = carry[c] + block_exscan(sums[c], s_wave, &tot);
-      carry[c] += tot;
+      const int before_seg = seg_start >= base ? carry[c] + s_pre[c][seg_start - base] : seg_carry[c];
+      pred[c] = carry[c] + pre[c] - before_seg;
     }
     if (valid)
       for (int c = 0; c < d.ncomp; c++)
@@ -861,20 +745,18 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffInterval* 
             pred[c] += *p;
             *p = (int16_t)pred[c];
           }
+    // the interval open at the start of the next pass
+    const int nbase = base + kSyncThreads;
+    const int nstart = (nbase / ri) * ri;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (nstart >= base && nstart < nbase) seg_carry[c] = carry[c] + s_pre[c][nstart - base];
+      else if (nstart >= nbase) seg_carry[c] = carry[c] + tot[c];
+      carry[c] += tot[c];
+    }
+    __syncthreads();  // s_pre is reused by the next pass
   }
 }
-
-}  // namespace
-
-void launch_huffman_rst(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t n_iv,
-                        const HuffLut* d_luts, const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride,
-                        uint32_t* d_status, hipStream_t s) {
-  if (!n_iv) return;
-  hipLaunchKernelGGL(k_huffman_rst, dim3((n_iv + 63) / 64), dim3(64), 0, s, d_blob, d_scans, d_ivs, n_iv, d_luts, d_descs,
-                     d_coef, coef_stride, d_status);
-}
-
-namespace {
 
 __global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, size_t coef_stride, uint32_t vec_per_frame) {
   // 16-byte stores; coef_stride is a multiple of 8 int16
@@ -909,6 +791,8 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
   const size_t o_start = take(subs * sizeof(uint2));
   const size_t o_mcu0 = take(subs * sizeof(int));
   const size_t o_map = take(subs * sizeof(unsigned long long));
+  const size_t o_lim = take(subs * sizeof(uint32_t));
+  const size_t o_seg = take(subs * sizeof(uint16_t));
   if (layout) {
     uint8_t* base = layout->stream;
     layout->stream = base + o_stream;
@@ -921,21 +805,19 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
     layout->start = reinterpret_cast<uint2*>(base + o_start);
     layout->mcu0 = reinterpret_cast<int*>(base + o_mcu0);
     layout->map = reinterpret_cast<unsigned long long*>(base + o_map);
+    layout->lim = reinterpret_cast<uint32_t*>(base + o_lim);
+    layout->seg = reinterpret_cast<uint16_t*>(base + o_seg);
     layout->max_frames = max_frames;
   }
   return off;
 }
 
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
-                         uint32_t max_raw_bytes, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
+                         uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
                          uint32_t* d_status, hipStream_t s, const HuffStageHook* hook) {
   if (!frames) return;
-  // upper bound of the subsequence count of any frame (the kernels use the unstuffed length)
-  uint32_t sub_bytes = (max_raw_bytes + kSyncMaxSub - 1) / kSyncMaxSub;
-  sub_bytes = std::max((sub_bytes + 3u) & ~3u, (uint32_t)kSyncMinBytes);
-  const uint32_t nsub = sub_bytes == (uint32_t)kSyncMinBytes ? std::max(1u, (max_raw_bytes + sub_bytes - 1) / sub_bytes)
-                                                             : (uint32_t)kSyncMaxSub;
+  const uint32_t nsub = std::max(max_nsub, 1u);  // slots of the longest frame
   uint8_t* cnt_a = sb.cnt;
   uint8_t* cnt_b = sb.cnt + (size_t)sb.max_frames * kSyncMaxSub;
   const dim3 lanes(kSyncLaneThreads);
@@ -961,7 +843,7 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
     hipLaunchKernelGGL(k_huff_write, dim3((nsub + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
                        d_luts, d_descs, sb, d_coef, coef_stride, d_status);
   });
-  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_ivs, d_descs, d_coef, coef_stride); });
+  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, d_coef, coef_stride); });
 }
 
 }  // namespace ufd

@@ -53,6 +53,10 @@ struct HuffScan {
   uint32_t blob_off;        // offset of the frame's JPEG bytes inside the batch blob
   uint32_t blocks_per_mcu;  // <= 10
   uint32_t lut_base;        // first of the 4 HuffLut of this frame: dc slot 0/1, ac slot 0/1
+  // self-synchronising decoder: the frame's intervals ("segments": one without restart markers)
+  uint32_t seg_base, nseg;  // range in the batch's interval array (nseg = 0: frame skipped)
+  uint32_t sub_bytes;       // subsequence length for this frame (multiple of 4, >= 64)
+  uint32_t nsub;            // subsequence slots of the frame (sum over its segments)
   uint32_t pad;
   uint8_t blk_comp[12], blk_bx[12], blk_by[12], blk_dc[12], blk_ac[12];  // per block of the MCU
 };
@@ -62,6 +66,7 @@ struct HuffInterval {
   uint32_t frame;
   uint32_t begin, end;  // byte range inside the frame's JPEG (end = position of the terminating marker)
   uint32_t mcu0, nmcu;  // first MCU and MCU count
+  uint32_t first_sub;   // self-synchronising decoder: first subsequence slot of the segment
 };
 
 struct GpuScanPlan {

@@ -23,14 +23,9 @@ void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, 
 void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
                           const float* d_norm_lut, float* d_out, uint32_t W, uint32_t H, uint32_t count, hipStream_t s);
 
-// Entropy decoding on the device for restart-interval streams (huffman_kernels.hip): one lane per
-// interval writes the non-zero quantised coefficients into pre-zeroed slabs; status[frame] |= 1 on
-// a corrupt stream.
-void launch_huffman_rst(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t n_iv,
-                        const HuffLut* d_luts, const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride,
-                        uint32_t* d_status, hipStream_t s);
-// Streams without restart markers: self-synchronising subsequence decoding with speculation over
-// the block index (huffman_kernels.hip).  ivs[f] = the frame's single interval, nmcu = 0 skips the
+// Entropy decoding on the device: self-synchronising subsequence decoding with speculation over
+// the block index (huffman_kernels.hip).  scans[f].seg_base/nseg select the frame's segments in ivs
+// (one per restart interval; a stream without restart markers is one segment); nseg = 0 skips the
 // frame.  SyncBuffers is device scratch of one context, carved from one allocation.
 // Per table set: the four lookup tables plus their state-only form (bits consumed by code word and
 // magnitude | zigzag advance << 5; 0 = code word longer than the lookup).  Built on the host when a
@@ -55,7 +50,8 @@ inline void build_sync_lut_image(const HuffLut* luts /*[4]: dc0 dc1 ac0 ac1*/, S
     }
   }
 }
-constexpr int kSyncMaxSub = 4096;  // subsequences per frame (longer streams get longer subsequences)
+constexpr int kSyncMaxSub = 4096;  // subsequence slots per frame (longer streams get longer subsequences)
+constexpr int kSyncMaxSeg = 1024;  // segments (restart intervals) per frame
 struct SyncFrame {
   uint32_t total_bits, nsub, sub_bits, pad;
 };
@@ -69,6 +65,8 @@ struct SyncBuffers {
   uint8_t* cnt = nullptr;  // [2][frame][subsequence] cached pairs (double-buffered across rounds)
   uint2* start = nullptr;  // [frame][subsequence] true entry state
   int* mcu0 = nullptr;     // [frame][subsequence] first MCU
+  uint32_t* lim = nullptr; // [frame][subsequence] end of the slot's data in bits (min(slot end, segment end)) | first-of-segment << 31
+  uint16_t* seg = nullptr; // [frame][subsequence] segment of the slot
   unsigned long long* map = nullptr;  // [frame][subsequence] slot -> slot of the next subsequence, 16 nibbles
   uint32_t max_frames = 0;
 };
@@ -79,7 +77,7 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
 // Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
 void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, hipStream_t s);
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
-                         uint32_t max_raw_bytes, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
+                         uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
                          uint32_t* d_status, hipStream_t s, const HuffStageHook* hook = nullptr);
 

@@ -205,12 +205,10 @@ struct ufd_model {
   // device entropy decoding: table sets seen so far (append-only, shared by the contexts)
   static constexpr int kMaxLutSets = 16;
   std::vector<std::array<HuffLut, 4>> lut_sets;
-  HuffLut* d_luts = nullptr;
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   uint32_t iv_cap = 0;      // restart intervals per batch
-  bool gpu_entropy_enabled = true;   // device entropy kernels for streams without restart markers
-  bool gpu_entropy_restart = false;  // ... and (slow) for restart-interval streams
+  bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   bool branch_streams = false;
 
   Slot slots[UFD_MAX_SLOTS];
@@ -235,11 +233,10 @@ struct ufd_model {
 
 struct DevicePlan {
   bool ok = false;         // every decodable frame of the batch can take the device decoder
-  bool sync_path = false;  // no restart markers: self-synchronising decoder (else one lane per interval)
   bool any_ok = false;
   uint32_t n_iv = 0;       // intervals in h_ivs
   size_t used_blob = 0, used_coef = 0;
-  uint32_t max_raw = 0, max_bpm = 1;
+  uint32_t max_nsub = 0, max_bpm = 1;
 };
 
 
@@ -933,7 +930,7 @@ int status_from_jpeg(int st) {
   return st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : (st == kJpegUnsupported ? UFD_E_UNSUPPORTED : st));
 }
 
-// Index of this frame's Huffman table set in d_luts (uploading it first if it is new), or -1.
+// Index of this frame's Huffman table set in d_sync_luts (uploading it first if it is new), or -1.
 int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
   std::lock_guard<std::mutex> lk(m->shared_mu);
   for (size_t i = 0; i < m->lut_sets.size(); i++)
@@ -943,7 +940,6 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
   std::memcpy(set.data(), luts, sizeof(HuffLut) * 4);
   const size_t idx = m->lut_sets.size();
   // rare (once per camera stream): blocking copy into an unused slot of the shared table array
-  if (hipMemcpy(m->d_luts + idx * 4, set.data(), sizeof(HuffLut) * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
   {
     std::unique_ptr<SyncLutImage> img(new SyncLutImage);
     build_sync_lut_image(set.data(), img.get());
@@ -964,63 +960,48 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
     s.st[i] = st;
   });
-  bool device_path = true;
   uint32_t n_iv = 0;
-  bool sync_path = true;  // no frame carries restart markers: self-synchronising decoder
-  for (uint32_t i = 0; i < count && device_path; i++) {
-    if (s.st[i] == kJpegNotEligible) device_path = false;
-    if (s.st[i] == kJpegOk) {
-      n_iv += s.plans[i].n_intervals;
-      if (s.h_descs[i].restart_interval > 0) sync_path = false;
-    }
-  }
-  if (!sync_path) {
-    if (!m->gpu_entropy_restart) device_path = false;  // restart-interval streams: host workers unless asked for
-    // the restart-interval kernel needs every frame to carry restart markers
-    for (uint32_t i = 0; i < count && device_path; i++)
-      if (s.st[i] == kJpegOk && s.h_descs[i].restart_interval <= 0) device_path = false;
-    if (n_iv > m->iv_cap) device_path = false;
-  }
-  if (!device_path && std::getenv("UFD_DEBUG"))
-    std::fprintf(stderr, "[ufd] batch not eligible for device entropy decoding (n_iv %u)\n", n_iv);
-  if (!device_path) return p;
-  uint32_t k = 0;
-  HuffScan ref_scan{};
-  bool have_ref = false;
   for (uint32_t i = 0; i < count; i++) {
-    if (sync_path) {
-      HuffInterval none{};
-      s.h_ivs[i] = none;  // nmcu = 0: the frame's workgroup exits at once
-    }
+    if (s.st[i] == kJpegNotEligible) return p;
+    if (s.st[i] == kJpegOk) n_iv += s.plans[i].n_intervals;
+  }
+  if (n_iv > m->iv_cap) return p;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
     if (s.st[i] != kJpegOk) continue;
     const int set = lut_set_for(m, s.plans[i].luts);
     if (set < 0) return p;
     HuffScan sc = s.plans[i].scan;
     sc.blob_off = 0;
     sc.lut_base = (uint32_t)set * 4;
-    // the restart-interval kernel keeps ONE table set and MCU layout per wave in LDS: batches
-    // that mix them (different cameras in one batch) are decoded on the host instead; the
-    // self-synchronising kernels load them per frame
-    if (!sync_path && have_ref && std::memcmp(&sc, &ref_scan, sizeof(sc)) != 0) return p;
-    ref_scan = sc;
-    have_ref = true;
+    sc.seg_base = sc.nseg = sc.sub_bytes = sc.nsub = sc.pad = 0;
     sc.blob_off = (uint32_t)(i * m->blob_stride);
-    s.h_scans[i] = sc;
-    if (sync_path) {
-      HuffInterval iv = s.plans[i].iv[0];
-      iv.frame = i;
-      s.h_ivs[i] = iv;
-      p.max_raw = std::max(p.max_raw, iv.end - iv.begin);
-      p.max_bpm = std::max(p.max_bpm, sc.blocks_per_mcu);
-    } else {
-      for (uint32_t j = 0; j < s.plans[i].n_intervals; j++) {
+    const uint32_t nseg = s.plans[i].n_intervals;
+    {
+      // subsequence slots: every segment starts on a subsequence boundary and keeps 32 bytes of
+      // zero slack behind its data; longer streams get longer subsequences (<= kSyncMaxSub slots)
+      if (nseg < 1 || nseg > (uint32_t)kSyncMaxSeg) return p;
+      size_t padded = 0;
+      for (uint32_t j = 0; j < nseg; j++) padded += (size_t)(s.plans[i].iv[j].end - s.plans[i].iv[j].begin) + 32;
+      uint32_t sub = (uint32_t)((padded + (kSyncMaxSub - nseg) - 1) / (kSyncMaxSub - nseg));
+      sub = std::max((sub + 3u) & ~3u, 64u);
+      uint32_t first = 0;
+      for (uint32_t j = 0; j < nseg; j++) {
         HuffInterval iv = s.plans[i].iv[j];
         iv.frame = i;
-        s.h_ivs[k++] = iv;
+        iv.first_sub = first;
+        first += (iv.end - iv.begin + 32 + sub - 1) / sub;
+        s.h_ivs[k + j] = iv;
       }
+      if (first > (uint32_t)kSyncMaxSub || (size_t)first * sub + 64 > m->blob_stride) return p;
+      sc.seg_base = k, sc.nseg = nseg, sc.sub_bytes = sub, sc.nsub = first;
+      k += nseg;
+      p.max_nsub = std::max(p.max_nsub, first);
+      p.max_bpm = std::max(p.max_bpm, sc.blocks_per_mcu);
     }
+    s.h_scans[i] = sc;
   }
-  if (sync_path) k = count;
   tl_pool->parallel_for(count, [&](unsigned i) {
     if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
   });
@@ -1035,7 +1016,6 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     s.st[i] = status_from_jpeg(s.st[i]);
   }
   p.ok = true;
-  p.sync_path = sync_path;
   p.n_iv = k;
   return p;
 }
@@ -1049,18 +1029,15 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
     launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.stream);
   }
   HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
-  if (p.sync_path) {
+  {
     std::unique_ptr<ProfScope> scope;
     const double bytes = (double)p.used_blob * count;
     const HuffStageHook hook = [&](const char* kernel, bool begin) {
       if (begin) scope.reset(new ProfScope(m, kernel, bytes, 0));
       else scope.reset();
     };
-    launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_raw, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
+    launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_nsub, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
                         c.sync, c.d_status, c.stream, &hook);
-  } else {
-    ProfScope ps(m, "huffman_rst", (double)p.used_blob * count, 0);
-    launch_huffman_rst(d_blob, d_scans, d_ivs, p.n_iv, m->d_luts, d_descs, d_coef, m->coef_stride, c.d_status, c.stream);
   }
   return UFD_OK;
 }
@@ -1076,7 +1053,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
     const DevicePlan p = plan_device_entropy(m, s, jpegs, lens, count);
     if (p.ok) {
       s.gpu_entropy = true;
-      s.coef_zigzag = p.sync_path;
+      s.coef_zigzag = true;
       *any_ok_out = p.any_ok;
       if (!p.any_ok) return UFD_OK;
       const int buf = c.flip;
@@ -1156,7 +1133,7 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
   std::memcpy(s.h_descs, g.h_descs.data(), sizeof(JpegFrameDesc) * count);
   for (uint32_t i = 0; i < count; i++) s.st[i] = g.st[i];
   s.gpu_entropy = true;
-  s.coef_zigzag = g.plan.sync_path;
+  s.coef_zigzag = true;
   int buf = 0;
   if (g.plan.any_ok) {
     buf = c.flip;
@@ -1369,7 +1346,7 @@ void destroy(ufd_model* m) {
   auto dfree = [](void* p) {
     if (p) (void)hipFree(p);
   };
-  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_luts), dfree(m->d_sync_luts);
+  dfree(m->d_weights), dfree(m->d_priors), dfree(m->d_lut), dfree(m->d_sync_luts);
   for (Ctx& c : m->ctx) {
     dfree(c.d_arena), dfree(c.d_input), dfree(c.d_status);
     for (int i = 0; i < 2; i++) {
@@ -1546,8 +1523,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->blob_stride = (((size_t)m->max_w * m->max_h) + 64 + 4095) & ~(size_t)4095;
   m->iv_cap = (uint32_t)B * 160;
   m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_HOST_ENTROPY) == 0;
-  m->gpu_entropy_restart = m->gpu_entropy_enabled && (cfg->flags & UFD_FLAG_DEVICE_ENTROPY) != 0;
-  HIPB(hipMalloc(&m->d_luts, sizeof(HuffLut) * 4 * ufd_model::kMaxLutSets));
   HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];

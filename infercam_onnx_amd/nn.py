@@ -165,9 +165,9 @@ class UltrafaceModel(InferModel):
     `UltrafaceModel(variant, max_iou, min_confidence)` as in the reference; keyword arguments add
     placement (`device_id`, `max_batch`) and the weight source (`weights_path` = .onnx, or a packed
     f32 `weights` blob + optional `priors`; default = the reference's cache path, nn.rs:144-156).
-    Entropy stage: by default the GPU kernels decode streams without restart markers and the host
-    workers everything else; `device_entropy=True` also sends restart-interval streams to the GPU,
-    `host_entropy=True` keeps the whole Huffman stage on the host workers.
+    Entropy stage: by default the GPU kernels decode baseline single-scan streams (with or without
+    restart markers) and the host workers progressive / multi-scan files; `host_entropy=True` keeps
+    the whole Huffman stage on the host workers (`device_entropy` is accepted and ignored).
     """
 
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,

@@ -207,8 +207,8 @@ def model640_dev(weights):
 @pytest.mark.parametrize("size", [(640, 480), (641, 479), (1280, 720), (17, 9)])
 @pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2", "4:4:4"])
 def test_device_entropy_decode_bit_exact(model320_dev, oracle_lib, size, subsampling):
-    """Restart-interval streams take the device Huffman path: same pixels as the oracle and as
-    the host-entropy path for every interval length."""
+    """Restart-interval streams on the device entropy pipeline: same pixels as the oracle for
+    every interval length."""
     from infercam_onnx_amd import synth
 
     w, h = size
@@ -268,8 +268,8 @@ def test_device_sync_decoder_is_the_path_taken(weights):
 
 
 def test_default_handle_routes_entropy_by_stream_kind(weights, oracle_lib):
-    """No flags: streams without restart markers take the GPU entropy kernels, restart-interval
-    and progressive streams the host workers; all of them decode to the oracle's detections."""
+    """No flags: baseline single-scan streams, with or without restart markers, take the GPU
+    entropy kernels, progressive streams the host workers; all decode to the same detections."""
     from infercam_onnx_amd import synth
 
     m = make_model(640, weights, max_batch=4, profile=True)
@@ -285,8 +285,8 @@ def test_default_handle_routes_entropy_by_stream_kind(weights, oracle_lib):
             seen.append({p["name"] for p in m.profile_read() if p["launches"] > 0})
             results.append(res)
         assert "huff_write" in seen[0] and "h2d_coef" not in seen[0]
-        assert "h2d_coef" in seen[1] and "huff_write" not in seen[1] and "huffman_rst" not in seen[1]
-        assert "h2d_coef" in seen[2]
+        assert "huff_write" in seen[1] and "h2d_coef" not in seen[1] and "huffman_rst" not in seen[1]
+        assert "h2d_coef" in seen[2] and "huff_write" not in seen[2]
         assert results[0] == results[1]  # same pixels (baseline, same quantisation), same kernels
     finally:
         m.close()
@@ -334,13 +334,13 @@ def test_device_entropy_corrupt_interval_is_flagged(model640_dev, oracle_lib, we
     assert_dets_match(dets_array(res[0]), ref, scores=scores)
 
 
-def test_mixed_batch_falls_back_to_host_entropy(model640_dev, oracle_lib):
+def test_mixed_batch_restart_and_plain_streams(model640_dev, oracle_lib):
     model640 = model640_dev
     from infercam_onnx_amd import synth
 
     f = synth.synth_frame(72, 0, 640, 480)
     a = synth.encode_jpeg(f, restart_rows=1)
-    b = synth.encode_jpeg(f)  # no DRI: not eligible for the device decoder
+    b = synth.encode_jpeg(f)  # no DRI
     res, status = model640.infer_jpeg_batch([a, b, a])
     assert status == [0, 0, 0] and res[0] == res[1] == res[2]
 
@@ -424,3 +424,62 @@ def test_chained_blocks_kernel_is_bit_identical_to_the_unfused_pair(weights, ora
     finally:
         ref_model.close()
         fused_model.close()
+
+
+@pytest.fixture(scope="module")
+def model320_auto(weights):
+    m = make_model(320, weights, max_batch=4)  # no entropy flags: the product default
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("size", [(640, 480), (641, 479), (1280, 720), (17, 9), (8, 8), (33, 100)])
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2", "4:4:4"])
+def test_restart_interval_streams_through_the_segment_pipeline(model320_auto, oracle_lib, size, subsampling):
+    """Restart intervals are segments with exact entry states in the self-synchronising decoder
+    (DC predictors restart, padding bits before every marker): same pixels as the oracle for one
+    or several MCU rows per interval, long and short symbols, noise."""
+    from infercam_onnx_amd import synth
+
+    w, h = size
+    rgb = synth.synth_frame(15, w * 7 + h, w, h)
+    noise = np.random.default_rng(w + h).integers(0, 256, size=rgb.shape, dtype=np.uint8)
+    for img, kw in ((rgb, {"restart_rows": 1}), (rgb, {"restart_rows": 2}), (rgb, {"restart_rows": 1, "quality": 30}),
+                    (rgb, {"restart_rows": 3, "optimize": True}), (noise, {"restart_rows": 1, "quality": 95}),
+                    (np.zeros_like(rgb), {"restart_rows": 1})):
+        jpeg = synth.encode_jpeg(img, subsampling=subsampling, **kw)
+        assert b"\xff\xdd" in jpeg
+        got = model320_auto.debug_decode_jpeg(jpeg)
+        assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (size, subsampling, kw)
+
+
+def test_mixed_stream_kinds_in_one_batch_on_the_device(weights, oracle_lib):
+    from infercam_onnx_amd import synth
+
+    m = make_model(640, weights, max_batch=4, profile=True)
+    try:
+        f = synth.synth_frame(78, 0, 640, 480)
+        jpegs = [synth.encode_jpeg(f, restart_rows=1), synth.encode_jpeg(f), synth.encode_jpeg(f, restart_rows=4),
+                 synth.encode_jpeg(f, subsampling="4:2:2")]
+        res, st = m.infer_jpeg_batch(jpegs)
+        names = {p["name"] for p in m.profile_read() if p["launches"] > 0}
+        assert st == [0] * 4 and "huff_write" in names and "h2d_coef" not in names
+        assert res[0] == res[1] == res[2]
+        ref = [oracle_lib.jpeg_decode_rgb(j) for j in jpegs]
+        assert np.array_equal(ref[0], ref[1]) and np.array_equal(ref[0], ref[2])
+    finally:
+        m.close()
+
+
+def test_corrupt_restart_interval_is_flagged_by_the_segment_pipeline(model320_auto):
+    from infercam_onnx_amd import nn, synth
+
+    good = synth.encode_jpeg(synth.synth_frame(79, 0, 320, 240), restart_rows=1)
+    sos = good.index(b"\xff\xda")
+    bad = bytearray(good)
+    for i in range(sos + 100, sos + 400):  # garbage inside the first intervals (markers stay in place)
+        if bad[i] != 0xFF and bad[i - 1] != 0xFF and bad[i + 1] != 0xFF:
+            bad[i] = 0x00
+    res, status = model320_auto.infer_jpeg_batch([good, bytes(bad), good])
+    assert status[0] == 0 and status[2] == 0 and res[0] == res[2]
+    assert status[1] in (0, nn.UFD_E_DECODE)  # decoded (garbage pixels) or skipped, never a crash
