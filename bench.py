@@ -50,8 +50,8 @@ KERNEL_FUNCS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")

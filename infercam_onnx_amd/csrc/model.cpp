@@ -594,7 +594,6 @@ int upload_weights(ufd_model* m, const float* blob) {
 int alloc_slot(ufd_model* m, Slot& s) {
   if (s.h_descs) return UFD_OK;
   HIPC(m, hipHostMalloc(&s.h_descs, sizeof(JpegFrameDesc) * m->B, hipHostMallocDefault));
-  HIPC(m, hipHostMalloc(&s.h_coef, sizeof(int16_t) * m->coef_stride * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * m->B, hipHostMallocDefault));
@@ -1075,6 +1074,8 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
     }
   }
   // ---- host entropy decoding
+  if (!s.h_coef)  // pinned coefficient slabs: only handles / batches that decode on the host need them
+    HIPC(m, hipHostMalloc(&s.h_coef, sizeof(int16_t) * m->coef_stride * m->B, hipHostMallocDefault));
   s.gpu_entropy = false;
   s.coef_zigzag = false;
   tl_pool->parallel_for(count, [&](unsigned i) {
@@ -1562,6 +1563,16 @@ int create(const ufd_config* cfg, ufd_model** out) {
     w.ctx = &m->ctx[ci];
     w.pool.reset(new ThreadPool(std::max(1u, m->host_threads / (unsigned)m->num_ctx)));
     w.th = std::thread(worker_main, m, &w);
+  }
+  // pinned staging of every slot now: a first-use allocation (milliseconds) would land inside the
+  // caller's first batches
+  for (auto& sl : m->slots) {
+    const int rc = alloc_slot(m, sl);
+    if (rc) {
+      g_create_error = m->err;
+      destroy(m);
+      return rc;
+    }
   }
   *out = m;
   return UFD_OK;
