@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void k_upsample_norm(const JpegFrameDesc* __re
                                                        int H) {
   const int frame = blockIdx.z;
   const JpegFrameDesc& d = descs[frame];
+  if (d.width != W || d.height != H) return;  // failed / skipped frame: its descriptor is all zero
   const int y = blockIdx.y;
   const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (y >= H || x0 >= W) return;

@@ -483,3 +483,40 @@ def test_corrupt_restart_interval_is_flagged_by_the_segment_pipeline(model320_au
     res, status = model320_auto.infer_jpeg_batch([good, bytes(bad), good])
     assert status[0] == 0 and status[2] == 0 and res[0] == res[2]
     assert status[1] in (0, nn.UFD_E_DECODE)  # decoded (garbage pixels) or skipped, never a crash
+
+
+def test_corrupted_entropy_segments_never_break_the_handle(model640_dev, oracle_lib):
+    """Random damage inside the entropy-coded segment (byte flips, zero runs, 0xFF injections,
+    truncation) across stream kinds: every frame ends as decoded or UFD_E_DECODE / UNSUPPORTED,
+    nothing hangs or faults, and the same handle still decodes a clean batch bit-exactly."""
+    from infercam_onnx_amd import nn, synth
+
+    rng = np.random.default_rng(2024)
+    clean = [synth.encode_jpeg(synth.synth_frame(90, i, 640, 480), **kw)
+             for i, kw in enumerate(({}, {"restart_rows": 1}, {"subsampling": "4:2:2"}, {"restart_rows": 2, "quality": 40}))]
+    ref, st_ref = model640_dev.infer_jpeg_batch(clean)
+    assert st_ref == [0] * 4
+    allowed = (0, nn.UFD_E_DECODE, nn.UFD_E_UNSUPPORTED)
+    for rnd in range(12):
+        batch = []
+        for j in clean:
+            b = bytearray(j)
+            sos = j.index(b"\xff\xda") + 14
+            kind = rng.integers(0, 5)
+            pos = int(rng.integers(sos, len(b) - 2))
+            if kind == 0:
+                for p in rng.integers(sos, len(b) - 2, size=8):
+                    b[int(p)] ^= int(rng.integers(1, 256))
+            elif kind == 1:
+                b[pos:pos + 64] = bytes(64)
+            elif kind == 2:
+                b[pos:pos + 3] = b"\xff\xff\xff"
+            elif kind == 3:
+                b = b[:pos] + b[-2:]  # truncated, EOI kept
+            else:
+                b[pos:pos + 2] = b"\xff\xd3"  # a stray restart marker
+            batch.append(bytes(b))
+        res, st = model640_dev.infer_jpeg_batch(batch)
+        assert all(s in allowed for s in st), st
+    again, st_again = model640_dev.infer_jpeg_batch(clean)
+    assert st_again == [0] * 4 and again == ref
