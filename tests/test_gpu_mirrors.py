@@ -67,3 +67,17 @@ def test_inferer_loop(oracle_lib, weights):
         scores, _ = oracle_lib.forward(x, weights, pri)
         assert_dets_match(dets_array(dets), ref, scores=scores)
     model.close()
+
+
+@pytest.mark.gpu
+def test_whole_file_fuzz_never_faults():
+    """tools/fuzz_gpu.py: random corruptions over whole JPEG files (headers, markers, entropy data)
+    in mixed batches.  A GPU memory fault aborts the child process, so it runs as one."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "40"], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz ok" in r.stdout

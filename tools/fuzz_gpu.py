@@ -1,0 +1,63 @@
+"""Robustness fuzz on the GPU box: random corruptions over whole JPEG files (headers included)
+through ufd_infer_jpeg_batch in mixed batches.  Every frame must end as OK / UFD_E_DECODE /
+UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE, and a clean batch must still decode bit-exactly afterwards.
+Usage: python tools/fuzz_gpu.py [rounds]   (exits non-zero on any violation)"""
+import sys
+import numpy as np
+
+sys.path.insert(0, ".")
+from infercam_onnx_amd import nn, synth
+
+
+def corrupt(rng, j):
+    b = bytearray(j)
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        for p in rng.integers(2, min(len(b), 700), size=int(rng.integers(1, 4))):
+            b[int(p)] ^= int(rng.integers(1, 256))
+    elif kind == 1:
+        for p in rng.integers(2, len(b), size=int(rng.integers(1, 6))):
+            b[int(p)] ^= int(rng.integers(1, 256))
+    elif kind == 2:
+        b = b[:int(rng.integers(2, len(b)))]
+    elif kind == 3:
+        p = int(rng.integers(2, len(b) - 2))
+        b[p:p + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+    elif kind == 4:
+        p = int(rng.integers(2, len(b) - 40))
+        b[p:p] = b[p:p + int(rng.integers(1, 40))]
+    else:
+        p = int(rng.integers(2, min(len(b), 700)))
+        b[p:p + 2] = b"\x00\x00"
+    return bytes(b)
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(11)
+    w = synth.synthetic_weights()
+    m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=8,
+                          max_src=(640, 480), det_cap=4420)
+    base = [synth.encode_jpeg(synth.synth_frame(5, i, 96 + 8 * i, 64 + 8 * i), **kw) for i, kw in enumerate((
+        {}, {"restart_rows": 1}, {"subsampling": "4:2:2"}, {"progressive": True}, {"optimize": True, "quality": 30},
+        {"subsampling": "4:4:4", "restart_rows": 2}, {"quality": 100}, {"subsampling": "4:2:2", "restart_rows": 1}))]
+    ref, st = m.infer_jpeg_batch(base)
+    assert st == [0] * len(base), st
+    allowed = (0, nn.UFD_E_DECODE, nn.UFD_E_UNSUPPORTED, nn.UFD_E_TOO_LARGE)
+    seen = {}
+    for r in range(rounds):
+        batch = [corrupt(rng, j) if rng.random() < 0.8 else j for j in base]
+        res, st = m.infer_jpeg_batch(batch)
+        for s in st:
+            seen[s] = seen.get(s, 0) + 1
+        if not all(s in allowed for s in st):
+            print("unexpected status", st)
+            sys.exit(2)
+    again, st = m.infer_jpeg_batch(base)
+    if st != [0] * len(base) or again != ref:
+        print("clean batch differs after the fuzz rounds", st)
+        sys.exit(3)
+    print("fuzz ok:", rounds, "rounds, statuses", seen)
+
+
+main()
