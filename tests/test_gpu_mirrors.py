@@ -81,3 +81,44 @@ def test_whole_file_fuzz_never_faults():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_on_one_handle(weights):
+    """include/ufd.h "Threading": any thread may call a handle; calls serialise inside.  Four threads
+    mix synchronous batches, single frames and RGB calls on ONE handle and all get the results a
+    single-threaded run gives."""
+    import threading
+    from infercam_onnx_amd import nn, synth
+
+    m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights, priors=synth.gen_priors(320, 240),
+                          max_batch=4, max_src=(640, 480), det_cap=4420)
+    try:
+        frames = [synth.synth_frame(95, i, 320, 240) for i in range(4)]
+        jpegs = [synth.encode_jpeg(f, restart_rows=(i % 2)) for i, f in enumerate(frames)]
+        ref_batch, _ = m.infer_jpeg_batch(jpegs)
+        ref_single = [m.infer_jpeg(j) for j in jpegs]  # (batch 1 picks other kernels: fp32 rounding apart from batch 4)
+        ref_rgb = m.run(frames[0])
+        errors = []
+
+        def worker(k):
+            try:
+                for it in range(12):
+                    if (k + it) % 3 == 0:
+                        got, st = m.infer_jpeg_batch(jpegs)
+                        assert st == [0] * 4 and got == ref_batch
+                    elif (k + it) % 3 == 1:
+                        assert m.infer_jpeg(jpegs[k % 4]) == ref_single[k % 4]
+                    else:
+                        assert m.run(frames[0]) == ref_rgb
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    finally:
+        m.close()
