@@ -62,7 +62,8 @@ def parse_args():
     ap.add_argument("--entropy", choices=["host", "device"], default="device",
                     help="where the Huffman stage runs (device: self-synchronising decoder kernels; "
                          "host: worker threads, coefficient slabs over PCIe)")
-    ap.add_argument("--src", default="640x480", help="frame size of the synthetic stream (BASELINE config C5: 1280x720, --batch 16)")
+    ap.add_argument("--variant", type=int, choices=[640, 320], default=640, help="UltraFace variant (BASELINE C1/C2: 320)")
+    ap.add_argument("--src", default=None, help="frame size of the synthetic stream (BASELINE config C5: 1280x720, --batch 16)")
     ap.add_argument("--no-variants", action="store_true", help="skip the PCIe-inclusive comparison runs")
     ap.add_argument("--restart-rows", type=int, default=0,
                     help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
@@ -74,22 +75,22 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(jpegs, weights, priors, budget_s):
+def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
     """The CPU oracle (oracle/, a single-threaded plain-C port of the reference path) timed on
     this host on a bounded sample of the same frames."""
     import oracle
 
     oracle.build()
-    oracle.infer_jpeg(jpegs[0], 640, 480, weights, priors)  # warm
+    oracle.infer_jpeg(jpegs[0], W, H, weights, priors)  # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        oracle.infer_jpeg(jpegs[n % len(jpegs)], 640, 480, weights, priors, 0.5, 0.5)
+        oracle.infer_jpeg(jpegs[n % len(jpegs)], W, H, weights, priors, 0.5, 0.5)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 4 * len(jpegs):
             break
     return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the bench's 640x480 JPEG frames, full path decode->NMS, 1 thread, %.1f s" % (n, el)}
+            "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el)}
 
 
 def main():
@@ -111,17 +112,18 @@ def main():
 
     from infercam_onnx_amd import nn, parallel, synth
 
-    W, H, B = 640, 480, args.batch
+    W, H, B = (640, 480, args.batch) if args.variant == 640 else (320, 240, args.batch)
+    variant = nn.UltrafaceVariant.W640H480 if args.variant == 640 else nn.UltrafaceVariant.W320H240
     # ---- weights: generated on rank 0, broadcast over RCCL (the path's only collective)
     weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist,
                                          device=torch.device("cuda", local_rank))
     priors = synth.gen_priors(W, H)
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
-    SW, SH = (int(v) for v in args.src.lower().split("x"))
+    SW, SH = (int(v) for v in args.src.lower().split("x")) if args.src else (W, H)
     jpegs = synth.synth_jpeg_pool(rank, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
     device_entropy = args.entropy == "device" or args.input == "hbm"
-    model = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B,
+    model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B,
                               weights=weights, priors=priors, max_src=(SW, SH), host_threads=args.host_threads,
                               profile=True, det_cap=256, host_entropy=not device_entropy)
     nb = max(1, args.pool // B)
@@ -176,7 +178,7 @@ def main():
         run_steps(args.steps, bts=hb, staged=False)
         torch.cuda.synchronize()
         variants["host_bytes_device_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
-        m2 = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
+        m2 = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
                                priors=priors, max_src=(SW, SH), host_threads=args.host_threads, det_cap=256,
                                host_entropy=True)
         hb2 = [m2._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
@@ -223,11 +225,11 @@ def main():
                      "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
         gpu_ms = sum(v["ms"] for v in kern.values())
         out = {
-            "metric": "frames/sec end-to-end (decode->NMS), UltraFace-640 @ 640x480",
+            "metric": "frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, W, H),
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UltraFace-640, one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
+            "config": {"workload": "UltraFace-" + str(args.variant) + ", one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
                                    "frames, %s), batch=%d, seeded synthetic weights" % (
                                        SW, SH, args.pool, "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows
                                        else "no restart markers", B),
@@ -248,7 +250,7 @@ def main():
             with open(dump, "w") as f:
                 json.dump({"steps": prof_steps, "batch": B, "stats": stats}, f, indent=1)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H)
         print(json.dumps(out), flush=True)
     model.close()
     if dist is not None:
