@@ -42,7 +42,7 @@ KERNEL_FUNCS = {
     "huffman_rst": "k_huffman_rst",
     "huff_unstuff": "k_huff_unstuff", "huff_seed": "k_huff_seed", "huff_extend": "k_huff_extend", "huff_link": "k_huff_link",
     "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
-    "conv_dwpw_coop": "k_dwpw_coop",
+    "conv_dwpw_coop": "k_dwpw_coop", "stem_planes_mfma": "k_stem_planes_mfma",
     "sort_nms": "k_sort_nms",
 }
 

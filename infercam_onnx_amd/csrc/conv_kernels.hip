@@ -1085,6 +1085,121 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem conv (3 -> 16, 3x3, stride 2) reading the decoder's 4:2:0 sample planes directly: the
+// fancy h2v2 chroma upsampling, the fixed-point YCbCr -> RGB conversion and the (v/255 - mean)/std
+// table of k_upsample_norm_420 run per lane on the 3 x 8 input pixels it needs, so the normalised
+// f32 input tensor (3.7 MB per frame, written by one kernel and read by the next) never exists.
+// Same lane layout and MFMA sequence as k_conv3x3_rows_mfma<2, 1> (quad q = input channel R/G/B,
+// lane = group of 4 output pixels = 8 input columns; the left halo column from the previous lane),
+// same integer formulas as jpeg_kernels.hip, hence bit-identical to the two-kernel path.
+// Chroma column sums 3*near + far are computed for the lane's 4 chroma columns; the two
+// neighbour columns come from the adjacent lanes (clamped at the row ends as jdsample.c does).
+__global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
+  const ConvArgs& a = sa.a;
+  constexpr int HL = 1, NG = 16 - 2 * HL;
+  extern __shared__ float s_sh[];
+  float* s_w = s_sh;                 // packed weights [1][9][64]
+  float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j16 = lane & 15;
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = sa.lut[i];
+  __syncthreads();
+  const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
+  const long total = (long)a.B * gpf;
+  const long g = ((long)blockIdx.x * 4 + wave) * NG + j16 - HL;
+  const bool inrange = g >= 0 && g < total;
+  const bool live = inrange && j16 >= HL && j16 < 16 - HL;
+  const size_t frame = inrange ? g / gpf : 0;
+  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const JpegFrameDesc& d = sa.descs[frame];
+  const bool frame_ok = d.width == a.iw && d.height == a.ih;  // failed frames: zero input
+  const uint8_t* fp = sa.planes + frame * sa.plane_stride;
+  const int ypitch = d.wblk[0] * 8, cpitch = d.wblk[1] * 8;
+  const int dw = d.dw[1], dh = d.dh[1];
+  const int ix0 = ox * 2;       // first input column of the lane (multiple of 8)
+  const int c0 = ix0 >> 1;      // first chroma column (multiple of 4)
+  // per-channel colour coefficients: out = y + ((ku * (cb - 128) + kv * (cr - 128) + 32768) >> 16)
+  const int ku = q == 1 ? -22554 : (q == 2 ? 116130 : 0);
+  const int kv = q == 0 ? 91881 : (q == 1 ? -46802 : 0);
+  const float* lutq = s_lut + min(q, 2) * 256;
+
+  floatx4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int co = 4 * q + r;
+      acc[j][r] = co < a.cout ? a.bias[co] : 0.0f;
+    }
+
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int iy = oy * 2 + r - 1;
+    const bool ok = frame_ok && iy >= 0 && iy < a.ih && q < 3;
+    const int yc = min(max(iy, 0), a.ih - 1);
+    // luma: 8 bytes; chroma: the row pair of h2v2 fancy upsampling, 4 columns of each plane
+    const uint2 yy = frame_ok ? *reinterpret_cast<const uint2*>(fp + d.plane_off[0] + (size_t)yc * ypitch + ix0) : make_uint2(0, 0);
+    const int cy = yc >> 1, ny = max(0, min(dh - 1, (yc & 1) ? cy + 1 : cy - 1));
+    int s[2][6];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      uint32_t wa = 0, wb = 0;
+      if (frame_ok) {
+        wa = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[1 + c] + (size_t)cy * cpitch + c0);
+        wb = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[1 + c] + (size_t)ny * cpitch + c0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) s[c][1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
+      // neighbour columns c0-1 / c0+4 from the adjacent lanes (same input row when they exist)
+      const int from_prev = __shfl(s[c][4], lane - 1), from_next = __shfl(s[c][1], lane + 1);
+      s[c][0] = c0 > 0 ? from_prev : s[c][1];
+      s[c][5] = c0 + 4 <= dw - 1 ? from_next : s[c][4];
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = 1 + (j >> 1);
+      int cbv, crv;
+      if (j & 1) {
+        cbv = (s[0][i] * 3 + s[0][i + 1] + 7) >> 4;
+        crv = (s[1][i] * 3 + s[1][i + 1] + 7) >> 4;
+      } else {
+        cbv = (s[0][i] * 3 + s[0][i - 1] + 8) >> 4;
+        crv = (s[1][i] * 3 + s[1][i - 1] + 8) >> 4;
+      }
+      const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
+      const int px = min(255, max(0, yv + ((ku * (cbv - 128) + 32768 + kv * (crv - 128)) >> 16)));
+      v[j] = ok ? lutq[px] : 0.0f;
+    }
+    const float left_raw = __shfl(v[7], lane - 1);
+    const float left = (j16 > 0 && ix0 > 0) ? left_raw : 0.0f;  // column ix0 - 1 (zero padding at the row start)
+    float x[3][4];  // [kx][pixel]: output pixel j reads columns 2j-1, 2j, 2j+1
+    x[0][0] = left, x[0][1] = v[1], x[0][2] = v[3], x[0][3] = v[5];
+    x[1][0] = v[0], x[1][1] = v[2], x[1][2] = v[4], x[1][3] = v[6];
+    x[2][0] = v[1], x[2][1] = v[3], x[2][2] = v[5], x[2][3] = v[7];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const float w = s_w[(r * 3 + kx) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
+    }
+  }
+  if (!live) return;
+  const int pix = oy * a.ow + ox;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int co = 4 * q + r;
+    if (co < a.cout) {
+      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      if (a.relu) o = relu4(o);
+      *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = o;
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- host side
@@ -1138,6 +1253,18 @@ bool conv3x3_rows_supported(const ConvArgs& a) {
   if ((a.ow & 3) || (a.iw & 3) || a.pad != a.dil) return false;
   if (a.stride == 1) return (a.dil == 1 || a.dil == 2 || a.dil == 3 || a.dil == 5) && a.iw == a.ow && a.ih == a.oh;
   return a.stride == 2 && a.dil == 1 && a.iw == 2 * a.ow;
+}
+
+bool stem_planes_supported(const ConvArgs& a) {
+  return a.k == 3 && a.stride == 2 && a.dil == 1 && a.pad == 1 && a.cin == 3 && a.cout <= 16 && !a.depthwise && !a.res &&
+         a.iw == 2 * a.ow && a.ih == 2 * a.oh && (a.ow & 3) == 0 && (a.iw & 7) == 0;
+}
+
+void launch_stem_planes_mfma(const StemArgs& sa, hipStream_t s) {
+  const ConvArgs& a = sa.a;
+  const long groups = (long)a.B * (a.oh * a.ow / 4);
+  const size_t shmem = (9 * 64 + 768) * sizeof(float);
+  hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
 
 void launch_conv3x3_rows_mfma(const ConvArgs& a0, hipStream_t s) {

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
     }
     return a;
   };
-  for (int pass = 0; pass < 2; pass++) {
+  // (a single segment needs no boundary counts: its begin is the start of the range)
+  for (int pass = nseg > 1 ? 0 : 1; pass < 2; pass++) {
     uint32_t zbase = 0;  // stuffed zeros in front of the tile
     for (uint32_t tile = lo & ~15u; tile <= hi; tile += kSyncThreads * 16) {
       const uint32_t off = tile + (uint32_t)tid * 16;
@@ -331,9 +332,15 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
             if (bq >= off) s_zb[q] = myz + __popc(zmask & ((1u << (bq - off)) - 1));
             if (eq >= off && eq < off + 16) s_ze[q] = myz + __popc(zmask & ((1u << (eq - off)) - 1));
           }
+        } else if (q < nseg && s_beg[q] <= off && off + 16 <= s_end[q]) {
+          // the whole piece lies inside one segment: running output pointer
+          uint8_t* o = dst + seg[q].first_sub * sub_bytes + (off - s_beg[q]) - (myz - s_zb[q]);
+#pragma unroll
+          for (int j = 0; j < 16; j++)
+            if (!(zmask & (1u << j))) *o++ = (uint8_t)((w4[j >> 2] >> (8 * (j & 3))) & 0xFF);
         } else {
 #pragma unroll 1
-          for (int j = 0; j < 16; j++) {
+          for (int j = 0; j < 16; j++) {  // a piece with a segment boundary (or the edge of the range) in it
             const uint32_t pos = off + j;
             while (q < nseg && pos >= s_end[q]) q++;
             if (q >= nseg) break;
@@ -345,22 +352,33 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
       }
       zbase += (uint32_t)total;
     }
+    if (nseg == 1 && tid == 0) s_ze[0] = zbase;  // (s_zb[0] = 0)
     __syncthreads();
   }
-  // per segment: zero slack behind the data, slot tables
+  // per segment: zero slack behind the data; per slot (all threads): limit, flags, segment
   uint32_t* lim = sb.lim + (size_t)frame * kSyncMaxSub;
   uint16_t* sseg = sb.seg + (size_t)frame * kSyncMaxSub;
   for (int q = tid; q < nseg; q += kSyncThreads) {
     const uint32_t len = (s_end[q] - s_beg[q]) - (s_ze[q] - s_zb[q]);
     const uint32_t first = seg[q].first_sub;
-    const uint32_t next = q + 1 < nseg ? seg[q + 1].first_sub : sc.nsub;
     uint8_t* z = dst + (size_t)first * sub_bytes + len;
     for (int k = 0; k < 32; k++) z[k] = 0;  // the bit window reads a few words past the last symbol
-    const uint32_t end_bits = (first * sub_bytes + len) * 8;
-    for (uint32_t i = first; i < next; i++) {
-      lim[i] = min((i + 1) * sub_bytes * 8, max(end_bits, i * sub_bytes * 8)) | (i == first ? 0x80000000u : 0u);
-      sseg[i] = (uint16_t)q;
+    s_zb[q] = first;                         // (the counts are consumed: reuse the arrays)
+    s_ze[q] = (first * sub_bytes + len) * 8;  // end of the segment's data in bits
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < sc.nsub; i += kSyncThreads) {
+    int a = 0, b = nseg;  // last segment whose first slot is <= i
+    while (b - a > 1) {
+      const int mid = (a + b) >> 1;
+      if (s_zb[mid] <= i) a = mid; else b = mid;
     }
+    const uint32_t first = s_zb[a], end_bits = s_ze[a];
+    // bit 31: the entry state of the slot needs no search -- first slot of a segment (exact), or a
+    // slot behind the segment's data (nothing to decode: stuffing and the slack shrink the data)
+    const bool settled = i == first || i * sub_bytes * 8 >= end_bits;
+    lim[i] = min((i + 1) * sub_bytes * 8, max(end_bits, i * sub_bytes * 8)) | (settled ? 0x80000000u : 0u);
+    sseg[i] = (uint16_t)a;
   }
   if (tid == 0) fr->total_bits = sc.nsub * sub_bytes * 8, fr->sub_bits = sub_bytes * 8, fr->nsub = sc.nsub;
 }

@@ -147,6 +147,18 @@ void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);
 void launch_conv3x3_mfma(const ConvArgs* a, int n, hipStream_t s);
 // Row variant (16-byte row loads + cross-lane shuffles instead of per-tap gathers).
 bool conv3x3_rows_supported(const ConvArgs& a);
+// Stem conv straight from the decoder's 4:2:0 sample planes (every frame of the batch at the model
+// size): a = the stem's ConvArgs with the row packing of its weights (pack_conv3x3_rows_weights);
+// frames whose descriptor does not match (failed frames) read as zero input.
+struct StemArgs {
+  ConvArgs a;
+  const JpegFrameDesc* descs;
+  const uint8_t* planes;
+  size_t plane_stride;
+  const float* lut;  // 3 x 256 normalisation table
+};
+bool stem_planes_supported(const ConvArgs& a);
+void launch_stem_planes_mfma(const StemArgs& sa, hipStream_t s);
 void launch_conv3x3_rows_mfma(const ConvArgs& a, hipStream_t s);
 size_t conv3x3_rows_packed_floats(int cin);
 void pack_conv3x3_rows_weights(const float* w /*[cout][cin][3][3]*/, int cin, int cout, float* packed);

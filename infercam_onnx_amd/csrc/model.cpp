@@ -140,6 +140,7 @@ struct Ctx {
   HuffScan* d_scans_buf[2] = {nullptr, nullptr};
   HuffInterval* d_ivs_buf[2] = {nullptr, nullptr};
   uint8_t* d_sync = nullptr;  // scratch of the self-synchronising entropy decoder
+  const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 sample planes (fused stem)
   SyncBuffers sync;
   uint32_t* d_status = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
@@ -208,6 +209,7 @@ struct ufd_model {
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   uint32_t iv_cap = 0;      // restart intervals per batch
+  bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   bool branch_streams = false;
 
@@ -720,6 +722,20 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   if (L.kind == kKindFusedAway && !L.materialize) return;
   if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
   if (L.leader != i) return;  // issued with its group leader
+  if (i == 0 && tl_cur->stem_descs) {  // stem conv straight from the decoder's sample planes
+    int st_ = 1;
+    StemArgs sa;
+    sa.a = layer_args(m, 0, f0, count, &st_);
+    sa.a.w = L.d_w_rows;
+    sa.descs = tl_cur->stem_descs + f0;
+    sa.planes = tl_cur->d_planes + (size_t)f0 * m->plane_stride;
+    sa.plane_stride = m->plane_stride;
+    sa.lut = m->d_lut;
+    ProfScope ps(m, std::string("stem_planes_mfma:") + L.spec.name,
+                 (double)count * (1.5 * L.ih * L.iw + 4.0 * L.spec.cout * L.oh * L.ow) + L.weight_bytes, L.flops_per_frame * count, st);
+    launch_stem_planes_mfma(sa, st);
+    return;
+  }
   if (L.kind == kKindDwPw2) {
     int s1 = 1, s2 = 2;
     const Layer& F = m->layers[L.chain_first];
@@ -1151,6 +1167,7 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
 // network, head decode, NMS and the result copy, all on the context's stream.
 int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFrameDesc* d_descs_in, int16_t* d_coef_in, int buf) {
   int rc = UFD_OK;
+  bool fused_stem = false;
   uint32_t max_blocks = 0, mw = 0, mh = 0;
   bool all_model_size = true;
   for (uint32_t i = 0; i < count; i++) {
@@ -1178,14 +1195,21 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
         all_420 = d.ncomp == 3 && d.color == kColorYCbCr && d.h[0] == 2 && d.v[0] == 2 && d.h[1] == 1 && d.v[1] == 1 &&
                   d.h[2] == 1 && d.v[2] == 1 && d.dw[1] > 2;
       }
-      const double bytes = (double)count * (m->W * m->H * 1.5 + m->W * m->H * 12.0);
-      ProfScope ps(m, all_420 ? "upsample_norm_420" : "upsample_norm", bytes, 0);
-      if (all_420)
-        launch_upsample_norm_420(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
-      else
-        launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
-      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-      tl_cur->consumed_valid[buf] = true;
+      // 4:2:0 frames at the model size: the stem conv reads the sample planes itself (no f32 input
+      // tensor); UFD_NO_STEM_FUSE=1 at ufd_create keeps the two-kernel path
+      if (all_420 && m->stem_fusable && !m->branch_streams) {
+        tl_cur->stem_descs = d_descs;
+        fused_stem = true;
+      } else {
+        const double bytes = (double)count * (m->W * m->H * 1.5 + m->W * m->H * 12.0);
+        ProfScope ps(m, all_420 ? "upsample_norm_420" : "upsample_norm", bytes, 0);
+        if (all_420)
+          launch_upsample_norm_420(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
+        else
+          launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
+        HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+        tl_cur->consumed_valid[buf] = true;
+      }
     } else {
       {
         ProfScope ps(m, "upsample_rgb", 0, 0);
@@ -1228,6 +1252,11 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       }
     }
     enqueue_forward(m, count);
+    if (fused_stem) {  // the stem was the last reader of the descriptors / planes of this buffer
+      tl_cur->stem_descs = nullptr;
+      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+      tl_cur->consumed_valid[buf] = true;
+    }
     enqueue_heads(m, count);
     enqueue_nms(m, count);
   }
@@ -1485,6 +1514,14 @@ int create(const ufd_config* cfg, ufd_model** out) {
   }
   m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
   plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0 || m->branch_streams);
+  {
+    const Layer& L0 = m->layers[0];
+    ConvArgs probe{};
+    probe.k = L0.spec.k, probe.stride = L0.spec.stride, probe.dil = L0.spec.dil, probe.pad = L0.spec.pad;
+    probe.cin = L0.spec.cin, probe.cout = L0.spec.cout, probe.depthwise = L0.spec.groups > 1;
+    probe.ih = L0.ih, probe.iw = L0.iw, probe.oh = L0.oh, probe.ow = L0.ow;
+    m->stem_fusable = L0.kind == kKindConv3x3 && L0.leader == 0 && stem_planes_supported(probe) && !std::getenv("UFD_NO_STEM_FUSE");
+  }
   // shapes the kernels rely on (checked here once, not per launch)
   for (const Layer& L : m->layers) {
     if ((L.kind == kKindPointwise || L.kind == kKindDwPw || L.kind == kKindDwPw2) && (((L.oh * L.ow) & 3) || (L.spec.cin & 1))) {

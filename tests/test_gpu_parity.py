@@ -520,3 +520,33 @@ def test_corrupted_entropy_segments_never_break_the_handle(model640_dev, oracle_
         assert all(s in allowed for s in st), st
     again, st_again = model640_dev.infer_jpeg_batch(clean)
     assert st_again == [0] * 4 and again == ref
+
+
+def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracle_lib):
+    """4:2:0 frames at the model size: the stem conv reads the decoder's sample planes itself
+    (k_stem_planes_mfma: upsampling + colour + normalisation per lane).  Same integer formulas and
+    MFMA order as k_upsample_norm_420 + the row kernel: detections are bit-identical, for frames
+    whose first/last rows and columns exercise the padding, with a failed frame in the batch."""
+    import os
+    from infercam_onnx_amd import synth
+
+    jpegs = [synth.encode_jpeg(synth.synth_frame(92, i, 640, 480), **kw)
+             for i, kw in enumerate(({}, {"restart_rows": 1}, {"quality": 35}, {"quality": 98}))]
+    jpegs.insert(2, jpegs[0][: len(jpegs[0]) // 2])  # a frame that fails to decode
+    os.environ["UFD_NO_STEM_FUSE"] = "1"
+    try:
+        ref_model = make_model(640, weights, max_batch=5, profile=True)
+        ref, st_ref = ref_model.infer_jpeg_batch(jpegs)
+    finally:
+        del os.environ["UFD_NO_STEM_FUSE"]
+    fused_model = make_model(640, weights, max_batch=5, profile=True)
+    try:
+        got, st = fused_model.infer_jpeg_batch(jpegs)
+        assert st == st_ref and st[2] != 0 and got == ref
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names = {p["name"] for p in fused_model.profile_read() if p["launches"]}
+        assert any(n.startswith("stem_planes_mfma:") for n in names) and "upsample_norm_420" not in names, names
+        assert "upsample_norm_420" in names_ref and not any(n.startswith("stem_planes_mfma:") for n in names_ref)
+    finally:
+        ref_model.close()
+        fused_model.close()
