@@ -1143,33 +1143,30 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     // luma: 8 bytes; chroma: the row pair of h2v2 fancy upsampling, 4 columns of each plane
     const uint2 yy = frame_ok ? *reinterpret_cast<const uint2*>(fp + d.plane_off[0] + (size_t)yc * ypitch + ix0) : make_uint2(0, 0);
     const int cy = yc >> 1, ny = max(0, min(dh - 1, (yc & 1) ? cy + 1 : cy - 1));
-    int s[2][6];
+    // every lane upsamples ONE chroma plane for its 8 pixels (R: Cr, G and B: Cb); the G lanes
+    // fetch Cr from the R lane of the same pixels (16 lanes down)
+    const int plane = q == 0 || q == 3 ? 2 : 1;
+    uint32_t wa = 0, wb = 0;
+    if (frame_ok) {
+      wa = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[plane] + (size_t)cy * cpitch + c0);
+      wb = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[plane] + (size_t)ny * cpitch + c0);
+    }
+    int s[6];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      uint32_t wa = 0, wb = 0;
-      if (frame_ok) {
-        wa = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[1 + c] + (size_t)cy * cpitch + c0);
-        wb = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[1 + c] + (size_t)ny * cpitch + c0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) s[c][1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
+    for (int i = 0; i < 4; i++) s[1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
+    {
       // neighbour columns c0-1 / c0+4 from the adjacent lanes (same input row when they exist)
-      const int from_prev = __shfl(s[c][4], lane - 1), from_next = __shfl(s[c][1], lane + 1);
-      s[c][0] = c0 > 0 ? from_prev : s[c][1];
-      s[c][5] = c0 + 4 <= dw - 1 ? from_next : s[c][4];
+      const int from_prev = __shfl(s[4], lane - 1), from_next = __shfl(s[1], lane + 1);
+      s[0] = c0 > 0 ? from_prev : s[1];
+      s[5] = c0 + 4 <= dw - 1 ? from_next : s[4];
     }
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int i = 1 + (j >> 1);
-      int cbv, crv;
-      if (j & 1) {
-        cbv = (s[0][i] * 3 + s[0][i + 1] + 7) >> 4;
-        crv = (s[1][i] * 3 + s[1][i + 1] + 7) >> 4;
-      } else {
-        cbv = (s[0][i] * 3 + s[0][i - 1] + 8) >> 4;
-        crv = (s[1][i] * 3 + s[1][i - 1] + 8) >> 4;
-      }
+      const int mine = (j & 1) ? (s[i] * 3 + s[i + 1] + 7) >> 4 : (s[i] * 3 + s[i - 1] + 8) >> 4;
+      const int peer = __shfl(mine, lane - 16);  // the R lane's Cr for the G lane
+      const int cbv = mine, crv = q == 1 ? peer : mine;
       const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
       const int px = min(255, max(0, yv + ((ku * (cbv - 128) + 32768 + kv * (crv - 128)) >> 16)));
       v[j] = ok ? lutq[px] : 0.0f;
