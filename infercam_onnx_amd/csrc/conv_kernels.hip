@@ -178,15 +178,24 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
   const float* __restrict__ in = a.in;
   const uint32_t in_off = (uint32_t)((frame * a.in_ctotal + half) * hw + pix);
   const uint32_t in_step = 2u * (uint32_t)hw;
+  // two 1x1 convs over different tensors summed as one (RFB: ConvLinear(cat) + shortcut(x)):
+  // k-steps from ksplit on read the second tensor (wave-uniform choice)
+  const float* __restrict__ in2 = a.in2;
+  const uint32_t in2_off = in2 ? (uint32_t)((frame * a.in2_ctotal + half) * hw + pix) : 0u;
+  const int ksplit = in2 ? a.ksplit : 0x7FFFFFFF;
+  auto load_b = [&](int ks) -> float4 {
+    if (ks >= ksplit) return *reinterpret_cast<const float4*>(in2 + (in2_off + (uint32_t)(ks - ksplit) * in_step));
+    return *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)ks * in_step));
+  };
   float4 bq[D];
 #pragma unroll
-  for (int d = 0; d < D; d++) bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)min(kbeg + d, kend - 1) * in_step));
+  for (int d = 0; d < D; d++) bq[d] = load_b(min(kbeg + d, kend - 1));
   for (int ks = kbeg; ks < kend; ks += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const float4 b = bq[d];
       const int kn = min(ks + D + d, kend - 1);  // refill the slot (tail: harmless re-read)
-      bq[d] = *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)kn * in_step));
+      bq[d] = load_b(kn);
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) {
         const float w = s_w[(ct * ksteps + ks + d) * 64 + lane];

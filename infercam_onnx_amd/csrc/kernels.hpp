@@ -110,10 +110,12 @@ struct ConvArgs {
   float* out;         // [B][out_ctotal][oh][ow], written at channel offset out_coff
   const float* res;   // optional residual [B][cout][oh][ow]: out = relu(conv + res)
   const float* w2;    // fused dw->pw kernel: depthwise weights packed [cin][12] (taps, bias, pad)
+  const float* in2;   // pointwise kernel: second input tensor for k-steps >= ksplit (two 1x1 convs summed as one), or null
   const float* bias2; // unused by the fused kernel (bias is inside w2)
   int32_t B, cin, cout, ih, iw, oh, ow;
   int32_t k, stride, pad, dil, depthwise, relu;
   int32_t in_ctotal, out_ctotal, out_coff;
+  int32_t in2_ctotal, ksplit;  // with in2: its channel count, first k-step (2 channels each) read from it
   int32_t dbg;         // ablation switches (UFD_CONV_DBG), timing experiments only
   int32_t tiles, cts;  // MFMA kernels: pixel tiles (blocks) and 32-cout tiles, set by the launcher
 };

@@ -72,6 +72,9 @@ struct Layer {
   const float* d_w = nullptr;  // kernel-specific packing
   const float* d_w_rows = nullptr;    // dense 3x3 layers: packing of the row kernel
   const float* d_w_dwpack = nullptr;  // depthwise layers: [c][12] image for the fused dw->pw kernel
+  int sum_with = -1;                  // pointwise layer whose 1x1 conv is summed into this launch (RFB shortcut + ConvLinear)
+  const float* d_w_sum = nullptr;     // ... packed weights over both inputs' channels, and the summed bias
+  const float* d_b_sum = nullptr;
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
 };
@@ -453,6 +456,27 @@ void plan_tensors(ufd_model* m, bool keep_all) {
       P2.weight_bytes += P1.weight_bytes;
     }
   }
+  // out = relu(ConvLinear(cat) + shortcut(x)) as ONE 1x1 conv over the channels of both inputs
+  // (weights side by side, biases summed): ConvLinear's output, written once and read back as the
+  // residual, never exists.  fp32 rounding apart from the two-launch form (one fma chain, not two).
+  if (!keep_all && !std::getenv("UFD_NO_FUSE_RFB")) {
+    Layer& S = m->layers[kRfbShortcut];
+    Layer& Lin = m->layers[kRfbLinear];
+    if (S.kind == kKindPointwise && Lin.kind == kKindPointwise && S.res_tensor == tensor_of[kRfbLinear] && S.oh == Lin.oh &&
+        S.ow == Lin.ow && S.spec.cout == Lin.spec.cout && (Lin.spec.cin & 1) == 0 && (S.spec.cin & 1) == 0) {
+      bool only_reader = true;
+      for (int j = 0; j < kNumConv; j++)
+        if (j != kRfbShortcut && m->layers[j].spec.src == kRfbLinear) only_reader = false;
+      if (only_reader) {
+        S.sum_with = kRfbLinear;
+        S.res_tensor = -1;
+        Lin.chained = true;
+        S.bytes_per_frame = ((double)Lin.spec.cin + S.spec.cin + S.spec.cout) * S.oh * S.ow * 4;
+        S.flops_per_frame += Lin.flops_per_frame;
+        S.weight_bytes += Lin.weight_bytes;
+      }
+    }
+  }
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
   if (!(std::getenv("UFD_NO_MERGE"))) {
@@ -495,6 +519,8 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     if (src_t >= 0) last[src_t] = std::max(last[src_t], i);
     if (L.in_tensor >= 0 && L.kind != kKindDwPw && L.kind != kKindDwPw2) last[L.in_tensor] = std::max(last[L.in_tensor], i);
     if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], i);
+    if (L.sum_with >= 0 && m->layers[L.sum_with].in_tensor >= 0)
+      last[m->layers[L.sum_with].in_tensor] = std::max(last[m->layers[L.sum_with].in_tensor], i);
   }
   for (int h = 0; h < 4; h++) {
     last[tensor_of[kHeadCls[h]]] = kNumConv;
@@ -582,6 +608,36 @@ int upload_weights(ufd_model* m, const float* blob) {
     }
     p += s.cout;
   }
+  // summed 1x1 pairs: weights of both convs side by side per output channel, biases added
+  std::vector<size_t> sumw_off(kNumConv, (size_t)-1), sumb_off(kNumConv, (size_t)-1);
+  {
+    std::vector<const float*> wsrc(kNumConv), bsrc(kNumConv);
+    const float* q = blob;
+    for (int i = 0; i < kNumConv; i++) {
+      wsrc[i] = q;
+      q += conv_weight_floats(specs[i]);
+      bsrc[i] = q;
+      q += specs[i].cout;
+    }
+    for (int i = 0; i < kNumConv; i++) {
+      const int j = m->layers[i].sum_with;
+      if (j < 0) continue;
+      const int ca = specs[j].cin, cb = specs[i].cin, co = specs[i].cout;
+      std::vector<float> wcat((size_t)co * (ca + cb)), bsum(co);
+      for (int o = 0; o < co; o++) {
+        std::memcpy(&wcat[(size_t)o * (ca + cb)], wsrc[j] + (size_t)o * ca, sizeof(float) * ca);
+        std::memcpy(&wcat[(size_t)o * (ca + cb) + ca], wsrc[i] + (size_t)o * cb, sizeof(float) * cb);
+        bsum[o] = bsrc[j][o] + bsrc[i][o];
+      }
+      while (img.size() % 64) img.push_back(0.f);
+      sumw_off[i] = img.size();
+      img.resize(img.size() + pointwise_packed_floats(ca + cb, co));
+      pack_pointwise_weights(wcat.data(), ca + cb, co, img.data() + sumw_off[i]);
+      while (img.size() % 64) img.push_back(0.f);
+      sumb_off[i] = img.size();
+      img.insert(img.end(), bsum.begin(), bsum.end());
+    }
+  }
   HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
   HIPC(m, hipMemcpy(m->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   for (int i = 0; i < kNumConv; i++) {
@@ -589,6 +645,7 @@ int upload_weights(ufd_model* m, const float* blob) {
     m->layers[i].d_b = m->d_weights + b_off[i];
     if (dw_off[i] != (size_t)-1) m->layers[i].d_w_dwpack = m->d_weights + dw_off[i];
     if (rows_off[i] != (size_t)-1) m->layers[i].d_w_rows = m->d_weights + rows_off[i];
+    if (sumw_off[i] != (size_t)-1) m->layers[i].d_w_sum = m->d_weights + sumw_off[i], m->layers[i].d_b_sum = m->d_weights + sumb_off[i];
   }
   return UFD_OK;
 }
@@ -695,6 +752,17 @@ ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_st
   a.out_ctotal = m->tensors[L.out_tensor].c;
   a.out_coff = L.out_coff;
   *dw_stride = 1;
+  if (L.sum_with >= 0) {  // two summed 1x1 convs: first the other conv's input channels, then this layer's
+    const Layer& O = m->layers[L.sum_with];
+    a.in2 = a.in;
+    a.in2_ctotal = a.in_ctotal;
+    a.in = in_ptr(O.in_tensor, O.ih, O.iw);
+    a.in_ctotal = O.in_tensor < 0 ? 3 : m->tensors[O.in_tensor].c;
+    a.ksplit = O.spec.cin >> 1;
+    a.cin = O.spec.cin + L.spec.cin;
+    a.w = L.d_w_sum;
+    a.bias = L.d_b_sum;
+  }
   if (L.kind == kKindDwPw2) {  // second block of a chain: its input tensor does not exist
     const Layer& D = m->layers[L.fused_dw];
     a.in = nullptr;

@@ -550,3 +550,33 @@ def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracl
     finally:
         ref_model.close()
         fused_model.close()
+
+
+def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
+    """relu(ConvLinear(cat) + shortcut(x)) as one 1x1 conv over both inputs' channels: one fma chain
+    instead of two, so fp32 rounding apart (<= 5e-6 on scores / boxes) from the two-launch form,
+    and within the usual bar of the oracle."""
+    import os
+    from infercam_onnx_amd import synth
+
+    W, H = 640, 480
+    pri = synth.gen_priors(W, H)
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(93, i, W, H)) for i in range(3)])
+    os.environ["UFD_NO_FUSE_RFB"] = "1"
+    try:
+        ref_model = make_model(640, weights, max_batch=3, profile=True)
+    finally:
+        del os.environ["UFD_NO_FUSE_RFB"]
+    fused_model = make_model(640, weights, max_batch=3, profile=True)
+    try:
+        s0, b0 = ref_model.debug_forward(x)
+        s1, b1 = fused_model.debug_forward(x)
+        assert np.abs(s0 - s1).max() <= 5e-6 and np.abs(b0 - b1).max() <= 5e-6
+        rs, rb = oracle_lib.forward(x[0], weights, pri)
+        assert np.abs(s1[0] - rs).max() <= 1e-5 and np.abs(b1[0] - rb).max() <= 1e-5
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names = {p["name"] for p in fused_model.profile_read() if p["launches"]}
+        assert any("rfb.linear" in n for n in names_ref) and not any("rfb.linear" in n for n in names), names
+    finally:
+        ref_model.close()
+        fused_model.close()
