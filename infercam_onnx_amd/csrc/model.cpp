@@ -73,7 +73,9 @@ struct Layer {
   const float* d_w_rows = nullptr;    // dense 3x3 layers: packing of the row kernel
   const float* d_w_dwpack = nullptr;  // depthwise layers: [c][12] image for the fused dw->pw kernel
   int sum_with = -1;                  // pointwise layer whose 1x1 conv is summed into this launch (RFB shortcut + ConvLinear)
-  const float* d_w_sum = nullptr;     // ... packed weights over both inputs' channels, and the summed bias
+  int stack[3] = {-1, -1, -1};        // 1x1 convs of the same input run as ONE conv with their output channels stacked (itself first)
+  int in_coff = 0;                    // this layer reads channels [in_coff, in_coff + cin) of its input tensor
+  const float* d_w_sum = nullptr;     // ... packed weights over both inputs' channels / the stacked output channels, and their bias
   const float* d_b_sum = nullptr;
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
@@ -477,14 +479,51 @@ void plan_tensors(ufd_model* m, bool keep_all) {
       }
     }
   }
+  // The three RFB reduce convs (64 -> 8 each, same input) as ONE 64 -> 24 conv: one cout tile instead
+  // of three, the input read once; the consumers read channel slices of the stacked tensor.
+  if (!keep_all && !std::getenv("UFD_NO_STACK")) {
+    static const int kStack[3] = {13, 16, 19};
+    Layer& A = m->layers[kStack[0]];
+    int cout_sum = 0;
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+      const Layer& Bm = m->layers[kStack[k]];
+      ok = ok && Bm.kind == kKindPointwise && Bm.in_tensor == A.in_tensor && Bm.spec.cin == A.spec.cin && Bm.oh == A.oh &&
+           Bm.ow == A.ow && Bm.res_tensor < 0 && Bm.spec.relu == A.spec.relu && Bm.out_coff == 0 && !Bm.chained && Bm.sum_with < 0;
+      for (int h = 0; h < 4; h++) ok = ok && kHeadCls[h] != kStack[k] && kHeadReg[h] != kStack[k];
+      cout_sum += Bm.spec.cout;
+    }
+    if (ok && cout_sum <= 32) {
+      Tensor t;
+      t.c = cout_sum, t.h = A.oh, t.w = A.ow;
+      m->tensors.push_back(t);
+      const int stacked = (int)m->tensors.size() - 1;
+      int coff = 0;
+      for (int k = 0; k < 3; k++) {
+        Layer& Bm = m->layers[kStack[k]];
+        for (int j = 0; j < kNumConv; j++)
+          if (m->layers[j].in_tensor == Bm.out_tensor && m->layers[j].spec.src == kStack[k]) m->layers[j].in_tensor = stacked, m->layers[j].in_coff = coff;
+        coff += Bm.spec.cout;
+        A.stack[k] = kStack[k];
+        if (k > 0) {
+          Bm.chained = true;
+          A.bytes_per_frame += (double)Bm.spec.cout * Bm.oh * Bm.ow * 4;
+          A.flops_per_frame += Bm.flops_per_frame;
+          A.weight_bytes += Bm.weight_bytes;
+        }
+      }
+      A.out_tensor = stacked;
+    }
+  }
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
   if (!(std::getenv("UFD_NO_MERGE"))) {
     static const int kGroups[][3] = {{13, 16, 19}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
     for (const auto& g : kGroups) {
       const Layer& A = m->layers[g[0]];
-      bool ok = true;
+      bool ok = !A.chained && A.stack[0] < 0;
       for (int k = 1; k < 3 && g[k] >= 0; k++) {
+        ok = ok && !m->layers[g[k]].chained;
         const Layer& Bm = m->layers[g[k]];
         ok = ok && Bm.kind == A.kind && Bm.spec.cin == A.spec.cin && Bm.ih == A.ih && Bm.iw == A.iw && Bm.oh == A.oh &&
              Bm.ow == A.ow && Bm.spec.k == A.spec.k && Bm.spec.dil == A.spec.dil && Bm.spec.stride == A.spec.stride &&
@@ -620,6 +659,23 @@ int upload_weights(ufd_model* m, const float* blob) {
       q += specs[i].cout;
     }
     for (int i = 0; i < kNumConv; i++) {
+      if (m->layers[i].stack[0] != i) continue;
+      const int ci = specs[i].cin;
+      std::vector<float> wcat, bcat;
+      for (int k : m->layers[i].stack) {
+        if (k < 0) continue;
+        wcat.insert(wcat.end(), wsrc[k], wsrc[k] + (size_t)specs[k].cout * ci);
+        bcat.insert(bcat.end(), bsrc[k], bsrc[k] + specs[k].cout);
+      }
+      while (img.size() % 64) img.push_back(0.f);
+      sumw_off[i] = img.size();
+      img.resize(img.size() + pointwise_packed_floats(ci, (int)bcat.size()));
+      pack_pointwise_weights(wcat.data(), ci, (int)bcat.size(), img.data() + sumw_off[i]);
+      while (img.size() % 64) img.push_back(0.f);
+      sumb_off[i] = img.size();
+      img.insert(img.end(), bcat.begin(), bcat.end());
+    }
+    for (int i = 0; i < kNumConv; i++) {
       const int j = m->layers[i].sum_with;
       if (j < 0) continue;
       const int ca = specs[j].cin, cb = specs[i].cin, co = specs[i].cout;
@@ -752,6 +808,12 @@ ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_st
   a.out_ctotal = m->tensors[L.out_tensor].c;
   a.out_coff = L.out_coff;
   *dw_stride = 1;
+  if (L.in_coff) a.in += (size_t)L.in_coff * L.ih * L.iw;  // a channel slice of a stacked tensor
+  if (L.stack[0] == i) {  // this launch computes the stacked output channels of all members
+    a.cout = m->tensors[L.out_tensor].c;
+    a.w = L.d_w_sum;
+    a.bias = L.d_b_sum;
+  }
   if (L.sum_with >= 0) {  // two summed 1x1 convs: first the other conv's input channels, then this layer's
     const Layer& O = m->layers[L.sum_with];
     a.in2 = a.in;
