@@ -925,7 +925,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs3 p3) {
 // the difference is fp32 rounding, ~1e-7 relative).
 // a.w: packed [ceil(cin/4)][9][64] (lane l: W[l&15][4*kc + (l>>4)][tap], zero padded).
 template <int S, int DIL>
-__global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];  // merged launches: same shapes, blockIdx.y selects the conv
   constexpr int HL = (S == 1) ? (DIL + 3) / 4 : 1;  // halo lanes on each side of a quad
   constexpr int NG = 16 - 2 * HL;                   // output pixel groups per wave tile
   extern __shared__ float s_w[];                    // packed weights when they fit (a.dbg = 1)
@@ -1273,24 +1274,28 @@ void launch_stem_planes_mfma(const StemArgs& sa, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
 
-void launch_conv3x3_rows_mfma(const ConvArgs& a0, hipStream_t s) {
-  ConvArgs a = a0;
+void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
+  ConvArgs3 p{};
+  const ConvArgs& a = args[0];
   const long groups = (long)a.B * (a.oh * a.ow / 4);
   const size_t wbytes = conv3x3_rows_packed_floats(a.cin) * sizeof(float);
   const bool lds = wbytes <= 40 * 1024;
-  a.dbg = lds ? 1 : 0;  // weights staged in LDS
+  for (int i = 0; i < n; i++) {
+    p.a[i] = args[i];
+    p.a[i].dbg = lds ? 1 : 0;  // weights staged in LDS
+  }
   const size_t shmem = lds ? wbytes : 0;
-  auto grid = [&](int hl) { return dim3((unsigned)((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl)))); };
+  auto grid = [&](int hl) { return dim3((unsigned)((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl))), (unsigned)n); };
   if (a.stride == 2) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 1) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 1>), grid(1), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 1>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 2) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 2>), grid(1), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 2>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 3) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 3>), grid(1), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 3>), grid(1), dim3(256), shmem, s, p);
   } else {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 5>), grid(2), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 5>), grid(2), dim3(256), shmem, s, p);
   }
 }
 

@@ -161,7 +161,7 @@ struct StemArgs {
 };
 bool stem_planes_supported(const ConvArgs& a);
 void launch_stem_planes_mfma(const StemArgs& sa, hipStream_t s);
-void launch_conv3x3_rows_mfma(const ConvArgs& a, hipStream_t s);
+void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s);
 size_t conv3x3_rows_packed_floats(int cin);
 void pack_conv3x3_rows_weights(const float* w /*[cout][cin][3][3]*/, int cin, int cout, float* packed);
 size_t conv3x3_packed_floats(int cin);

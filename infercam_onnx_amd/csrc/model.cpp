@@ -518,7 +518,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
   if (!(std::getenv("UFD_NO_MERGE"))) {
-    static const int kGroups[][3] = {{13, 16, 19}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
+    static const int kGroups[][3] = {{13, 16, 19}, {14, 17, 20}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
     for (const auto& g : kGroups) {
       const Layer& A = m->layers[g[0]];
       bool ok = !A.chained && A.stack[0] < 0;
@@ -535,7 +535,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         if (A.kind == kKindDwPw)
           ok = ok && m->layers[Bm.fused_dw].spec.stride == m->layers[A.fused_dw].spec.stride &&
                m->layers[Bm.fused_dw].ih == m->layers[A.fused_dw].ih;
-        if (A.kind == kKindConv3x3) ok = ok && !(A.ow % 4 == 0);  // the row kernel is single-launch
+        if (A.kind == kKindConv3x3) ok = ok && Bm.spec.cout <= 16 && A.spec.cout <= 16;  // (row kernel or gather kernel: one cout tile)
       }
       if (!ok) continue;
       for (int k = 0; k < 3 && g[k] >= 0; k++) {
@@ -896,7 +896,8 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
     case kKindDwPw: kind = dwpw_uses_coop(args, n) ? "conv_dwpw_coop" : "conv_dwpw_mfma"; break;
     case kKindDwPw2: break;  // issued above
     case kKindConv3x3:
-      use_rows = n == 1 && conv3x3_rows_supported(a);
+      use_rows = true;
+      for (int j = 0; j < n; j++) use_rows = use_rows && conv3x3_rows_supported(args[j]);
       kind = use_rows ? "conv3x3_rows_mfma" : "conv3x3_mfma";
       break;
     case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
@@ -908,8 +909,10 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
     case kKindDwPw: launch_conv_dwpw_mfma(args, n, dw_stride, st); break;
     case kKindConv3x3:
       if (use_rows) {
-        a.w = L.d_w_rows;
-        launch_conv3x3_rows_mfma(a, st);
+        int k = 0;
+        for (int j : L.group)
+          if (j >= 0) args[k++].w = m->layers[j].d_w_rows;
+        launch_conv3x3_rows_mfma(args, n, st);
       } else {
         launch_conv3x3_mfma(args, n, st);
       }
