@@ -927,7 +927,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs3 p3) {
 template <int S, int DIL>
 __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
   const ConvArgs& a = p3.a[blockIdx.y];  // merged launches: same shapes, blockIdx.y selects the conv
-  constexpr int HL = (S == 1) ? (DIL + 3) / 4 : 1;  // halo lanes on each side of a quad
+  const int dil = DIL == 0 ? a.dil : DIL;
+  // DIL = 0: the dilation is a.dil (<= 8) of the selected conv -- merged launches of convs that differ
+  // in dilation only; two halo lanes and run-time tap offsets instead of compile-time ones
+  constexpr int HL = (S == 1) ? (DIL == 0 ? 2 : (DIL + 3) / 4) : 1;  // halo lanes on each side of a quad
   constexpr int NG = 16 - 2 * HL;                   // output pixel groups per wave tile
   extern __shared__ float s_w[];                    // packed weights when they fit (a.dbg = 1)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
   uint32_t rowoff[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    const int iy = oy * S + (r - 1) * DIL;
+    const int iy = oy * S + (r - 1) * dil;
     rowok[r] = iy >= 0 && iy < a.ih;
     rowoff[r] = (uint32_t)(frame * a.in_ctotal * (size_t)ihw) + (uint32_t)(min(max(iy, 0), a.ih - 1) * a.iw + ix0);
   }
@@ -974,8 +977,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
   bool lok[4], rok[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    lok[j] = S == 1 ? (ox + j - DIL >= 0) : (j > 0 || ix0 > 0);
-    rok[j] = S == 1 ? (ox + j + DIL < a.ow) : true;
+    lok[j] = S == 1 ? (ox + j - dil >= 0) : (j > 0 || ix0 > 0);
+    rok[j] = S == 1 ? (ox + j + dil < a.ow) : true;
   }
   const float* __restrict__ in = a.in;
   const float* wg = a.w + lane;
@@ -993,6 +996,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
   };
   // value of this lane's row segment at column offset c (relative to its first pixel), c in [-8, 11]
   auto col = [&](const float4& m, int c) -> float {
+    if (DIL == 0) {  // run-time offset: floor division by shift, unconditional shuffle (lane + 0 = itself)
+      const int o = c >> 2, k = c & 3;
+      const float v = k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w));
+      return __shfl(v, lane + o);
+    }
     const int o = (c >= 0) ? (c >> 2) : -((3 - c) >> 2);  // lane offset, floor(c / 4)
     const int k = c - 4 * o;
     const float v = k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w));
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
         for (int j = 0; j < 4; j++) {
           // shuffles first, unconditionally: a cross-lane read inside a divergent branch would
           // see inactive source lanes
-          const float vl = col(m, j - DIL), vc = col(m, j), vr = col(m, j + DIL);
+          const float vl = col(m, j - dil), vc = DIL == 0 ? (j == 0 ? m.x : (j == 1 ? m.y : (j == 2 ? m.z : m.w))) : col(m, j), vr = col(m, j + dil);
           x[0][j] = (ok && lok[j]) ? vl : 0.0f;
           x[1][j] = ok ? vc : 0.0f;
           x[2][j] = (ok && rok[j]) ? vr : 0.0f;
@@ -1286,6 +1294,12 @@ void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
   }
   const size_t shmem = lds ? wbytes : 0;
   auto grid = [&](int hl) { return dim3((unsigned)((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl))), (unsigned)n); };
+  bool mixed = false;
+  for (int i = 1; i < n; i++) mixed = mixed || args[i].dil != a.dil;
+  if (mixed) {  // (stride 1, dilations <= 8: conv3x3_rows_supported)
+    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 0>), grid(2), dim3(256), shmem, s, p);
+    return;
+  }
   if (a.stride == 2) {
     hipLaunchKernelGGL((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 1) {

@@ -518,7 +518,9 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
   if (!(std::getenv("UFD_NO_MERGE"))) {
-    static const int kGroups[][3] = {{13, 16, 19}, {14, 17, 20}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
+    // (leader first: the launch is issued at the leader's turn, so a leader that is not the lowest
+    // index -- the RFB's dilated convs wait for the b2 branch -- delays the others to its turn)
+    static const int kGroups[][3] = {{13, 16, 19}, {14, 17, 20}, {22, 15, 18}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
     for (const auto& g : kGroups) {
       const Layer& A = m->layers[g[0]];
       bool ok = !A.chained && A.stack[0] < 0;
@@ -526,12 +528,20 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         ok = ok && !m->layers[g[k]].chained;
         const Layer& Bm = m->layers[g[k]];
         ok = ok && Bm.kind == A.kind && Bm.spec.cin == A.spec.cin && Bm.ih == A.ih && Bm.iw == A.iw && Bm.oh == A.oh &&
-             Bm.ow == A.ow && Bm.spec.k == A.spec.k && Bm.spec.dil == A.spec.dil && Bm.spec.stride == A.spec.stride &&
+             Bm.ow == A.ow && Bm.spec.k == A.spec.k && Bm.spec.stride == A.spec.stride &&
              (Bm.spec.cout + 31) / 32 == (A.spec.cout + 31) / 32 && Bm.res_tensor < 0 && A.res_tensor < 0;
-        // one launch at the leader's turn: every member must read the same, already produced tensor
+        // dense 3x3 convs of stride 1 may differ in dilation (run-time dilation form of the row kernel)
+        const bool dil_free = A.kind == kKindConv3x3 && A.spec.stride == 1 && A.ow % 4 == 0 && Bm.spec.pad == Bm.spec.dil &&
+                              A.spec.pad == A.spec.dil && Bm.spec.dil <= 5 && A.spec.dil <= 5 && !keep_all;
+        ok = ok && (Bm.spec.dil == A.spec.dil || dil_free);
+        // one launch at the leader's turn: every member reads the same, already produced tensor, or
+        // a tensor whose producing launch comes before that turn
         const int src_a = A.kind == kKindDwPw ? m->layers[A.fused_dw].in_tensor : A.in_tensor;
         const int src_b = Bm.kind == kKindDwPw ? m->layers[Bm.fused_dw].in_tensor : Bm.in_tensor;
-        ok = ok && src_a == src_b;
+        const int prod_b = Bm.spec.src;
+        const bool produced_before = Bm.kind == kKindConv3x3 && prod_b >= 0 && prod_b < g[0] && m->layers[prod_b].leader < g[0] &&
+                                     g[k] < g[0];
+        ok = ok && (src_a == src_b || produced_before);
         if (A.kind == kKindDwPw)
           ok = ok && m->layers[Bm.fused_dw].spec.stride == m->layers[A.fused_dw].spec.stride &&
                m->layers[Bm.fused_dw].ih == m->layers[A.fused_dw].ih;
@@ -552,14 +562,15 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
     if (L.chained) continue;                                     // computed inside a later launch
     first[L.out_tensor] = std::min(first[L.out_tensor], L.leader);  // a merged layer writes at its leader's turn
-    last[L.out_tensor] = std::max(last[L.out_tensor], i);
+    last[L.out_tensor] = std::max(last[L.out_tensor], std::max(i, L.leader));
+    const int when = std::max(i, L.leader);  // a merged member is read at its leader's turn
     int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
     if (L.kind == kKindDwPw2) src_t = m->layers[m->layers[L.chain_first].fused_dw].in_tensor;
-    if (src_t >= 0) last[src_t] = std::max(last[src_t], i);
-    if (L.in_tensor >= 0 && L.kind != kKindDwPw && L.kind != kKindDwPw2) last[L.in_tensor] = std::max(last[L.in_tensor], i);
-    if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], i);
+    if (src_t >= 0) last[src_t] = std::max(last[src_t], when);
+    if (L.in_tensor >= 0 && L.kind != kKindDwPw && L.kind != kKindDwPw2) last[L.in_tensor] = std::max(last[L.in_tensor], when);
+    if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], when);
     if (L.sum_with >= 0 && m->layers[L.sum_with].in_tensor >= 0)
-      last[m->layers[L.sum_with].in_tensor] = std::max(last[m->layers[L.sum_with].in_tensor], i);
+      last[m->layers[L.sum_with].in_tensor] = std::max(last[m->layers[L.sum_with].in_tensor], when);
   }
   for (int h = 0; h < 4; h++) {
     last[tensor_of[kHeadCls[h]]] = kNumConv;
