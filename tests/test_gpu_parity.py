@@ -580,3 +580,23 @@ def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
     finally:
         ref_model.close()
         fused_model.close()
+
+
+def test_unusual_restart_layouts(model320_auto, oracle_lib):
+    """Restart intervals of a single MCU (1200 per frame: more than the device pipeline's segment
+    table, so the batch decodes on the host workers), of a few MCUs (segments shorter than one
+    subsequence slot) and grayscale streams with restart markers: same pixels as the oracle."""
+    import io
+    from PIL import Image
+    from infercam_onnx_amd import synth
+
+    rgb = synth.synth_frame(16, 5, 640, 480)
+    for mode, kw in (("RGB", {"restart_marker_blocks": 1}), ("RGB", {"restart_marker_blocks": 3}),
+                     ("RGB", {"restart_marker_blocks": 7, "subsampling": 0}), ("L", {"restart_marker_rows": 1}),
+                     ("L", {"restart_marker_blocks": 5})):
+        buf = io.BytesIO()
+        Image.fromarray(rgb).convert(mode).save(buf, format="JPEG", quality=88, **kw)
+        jpeg = buf.getvalue()
+        assert b"\xff\xdd" in jpeg
+        got = model320_auto.debug_decode_jpeg(jpeg)
+        assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (mode, kw)
