@@ -14,6 +14,7 @@ namespace {
 constexpr float kEps = 1.0e-7f;           // nn.rs:18
 constexpr int kSortLds = 4096;            // keys sorted inside LDS up to this many candidates
 constexpr int kSelLds = 1024;             // selected boxes kept in LDS; the rest spill to HBM
+constexpr int kBoxLds = 512;              // sorted candidate boxes gathered per round trip (power of two, <= block size)
 
 __device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
   conf = conf + 0.0f;  // -0.0 -> +0.0 (partial_cmp treats them as equal)
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   __shared__ unsigned long long s_keys[kSortLds];
   __shared__ float4 s_sel[kSelLds];
   __shared__ float4 s_cand[64];
+  __shared__ float4 s_box[kBoxLds];
   __shared__ unsigned long long s_row[64];
   __shared__ unsigned long long s_dead;
   __shared__ int s_nsel;
@@ -157,9 +159,15 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
 
   for (int b0 = 0; b0 < n; b0 += 64) {
     const int m = min(64, n - b0);
+    // candidate boxes in sorted order, 512 at a time: one gather round trip per 8 blocks instead
+    // of one per block (the dependent global gather dominated frames with many candidates)
+    if ((b0 & (kBoxLds - 1)) == 0) {
+      if (tid < kBoxLds && b0 + tid < n) s_box[tid] = fb[(int)(keys[b0 + tid] & 0xffffffffull) - 1];
+      __syncthreads();
+    }
     if (tid < 64) {
       float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid < m) c = fb[(int)(keys[b0 + tid] & 0xffffffffull) - 1];
+      if (tid < m) c = s_box[(b0 & (kBoxLds - 1)) + tid];
       s_cand[tid] = c;
       s_row[tid] = 0ull;
     }
@@ -184,11 +192,16 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
     __syncthreads();
     // phase 3
     if (wave == 0) {
+      // greedy pass over the block, kept in scalar registers: lane i holds row i and the loop reads
+      // it with v_readlane (a dependent LDS read per candidate cost ~100 cycles x 64 per block)
+      const unsigned long long myrow = s_row[lane];
+      const uint32_t row_lo = (uint32_t)myrow, row_hi = (uint32_t)(myrow >> 32);
       unsigned long long d = s_dead, keep = 0ull;
       for (int i = 0; i < m; i++) {
         if (!((d >> i) & 1ull)) {
           keep |= 1ull << i;
-          d |= s_row[i];
+          d |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)row_hi, i) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)row_lo, i);
         }
       }
       if ((keep >> lane) & 1ull) {
