@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
 // Tiles advance by 30 lane columns = 15 output groups; columns 0 and 31 only provide halos.
 // a[0]: first block (in, w2 = dw [C1][12], w = packed pw, bias, relu); a[1]: second block
 // (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0.
-template <int C1>
+template <int C1, int CT2>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
   const ConvArgs& a2 = p3.a[1];
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* s_dw1 = s_mem;             // [C1][12]
   float* s_w1 = s_dw1 + C1 * 12;    // [KS1][64]
   float* s_dw2 = s_w1 + KS1 * 64;   // [32][12]
-  float* s_w2 = s_dw2 + 32 * 12;    // [KS2][64]
+  float* s_w2 = s_dw2 + 32 * 12;    // [CT2][KS2][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Workgroup ids are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of
   // tiles, so that neighbouring tiles (which share input rows) meet in the same L2 close in time.
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     copy4(s_dw1, a1.w2, C1 * 3);
     copy4(s_w1, a1.w, KS1 * 16);
     copy4(s_dw2, a2.w2, 32 * 3);
-    copy4(s_w2, a2.w, KS2 * 16);
+    copy4(s_w2, a2.w, CT2 * KS2 * 16);
   }
   __syncthreads();
   const int half = lane >> 5, j32 = lane & 31;
@@ -744,13 +744,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // s = 4b + u needs channel 8b + 2u from the half-0 lanes and 8b + 2u + 1 from the half-1 lanes:
   //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
   //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
-  floatx16 acc2[2];
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const float bb = co < a2.cout ? a2.bias[co] : 0.0f;
-    acc2[0][r] = acc2[1][r] = bb;
-  }
+  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
+  float bop[KS2][2];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     float own[4][2], got[2][2];
@@ -765,28 +760,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       got[0][j] = __shfl_xor(s0, 32), got[1][j] = __shfl_xor(s1, 32);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const float w = s_w2[(4 * b + u) * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        float v;
-        if (u == 0) v = half ? got[0][j] : own[0][j];
-        else if (u == 1) v = half ? got[1][j] : own[2][j];
-        else if (u == 2) v = half ? own[1][j] : got[0][j];
-        else v = half ? own[3][j] : got[1][j];
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc2[j], 0, 0, 0);
-      }
+    for (int j = 0; j < 2; j++) {
+      bop[4 * b + 0][j] = half ? got[0][j] : own[0][j];
+      bop[4 * b + 1][j] = half ? got[1][j] : own[2][j];
+      bop[4 * b + 2][j] = half ? own[1][j] : got[0][j];
+      bop[4 * b + 3][j] = half ? own[3][j] : got[1][j];
     }
   }
-  if (live) {
-    const int pix = oy * a2.ow + ox + 2 * sub;
+  const int pix = oy * a2.ow + ox + 2 * sub;
+#pragma unroll
+  for (int ct = 0; ct < CT2; ct++) {
+    floatx16 acc2[2];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a2.cout) {
-        float2 v = make_float2(acc2[0][r], acc2[1][r]);
-        if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
-        *reinterpret_cast<float2*>(a2.out + (frame * a2.out_ctotal + a2.out_coff + co) * ohw + pix) = v;
+      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float bb = co < a2.cout ? a2.bias[co] : 0.0f;
+      acc2[0][r] = acc2[1][r] = bb;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS2; ks++) {
+      const float w = s_w2[(ct * KS2 + ks) * 64 + lane];
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][0], acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][1], acc2[1], 0, 0, 0);
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a2.cout) {
+          float2 v = make_float2(acc2[0][r], acc2[1][r]);
+          if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+          *reinterpret_cast<float2*>(a2.out + (frame * a2.out_ctotal + a2.out_coff + co) * ohw + pix) = v;
+        }
       }
     }
   }
@@ -1421,8 +1426,8 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
 }
 
 bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
-  return first.cin == 16 && first.cout == 32 && second.cin == 32 && second.cout <= 32 && first.iw % 8 == 0 &&
-         first.iw == first.ow && first.ih == first.oh && second.ow % 4 == 0 && first.ow == 2 * second.ow &&
+  return (first.cin == 16 || first.cin == 32) && first.cout == 32 && second.cin == 32 && second.cout <= 64 &&
+         first.iw % 8 == 0 && first.iw == first.ow && first.ih == first.oh && second.ow % 4 == 0 && first.ow == 2 * second.ow &&
          first.oh == 2 * second.oh && first.res == nullptr && second.res == nullptr;
 }
 
@@ -1434,8 +1439,13 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   const long wave_tiles = (half_groups + kDwGroups - 1) / kDwGroups;
   p.a[1].tiles = (int)((wave_tiles + 3) / 4);
   p.a[1].cts = 1;
-  const size_t lds = ((size_t)16 * 12 + 8 * 64 + 32 * 12 + 16 * 64) * sizeof(float);
-  hipLaunchKernelGGL((k_dwpw2_mfma<16>), dim3((unsigned)((p.a[1].tiles + 7) / 8 * 8)), dim3(256), lds, s, p);
+  const int ct2 = (second.cout + 31) / 32;
+  const size_t lds = ((size_t)first.cin * 12 + (first.cin / 2) * 64 + 32 * 12 + (size_t)ct2 * 16 * 64) * sizeof(float);
+  const dim3 grid((unsigned)((p.a[1].tiles + 7) / 8 * 8));
+  if (first.cin == 16 && ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<16, 1>), grid, dim3(256), lds, s, p);
+  else if (first.cin == 16) hipLaunchKernelGGL((k_dwpw2_mfma<16, 2>), grid, dim3(256), lds, s, p);
+  else if (ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<32, 1>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((k_dwpw2_mfma<32, 2>), grid, dim3(256), lds, s, p);
 }
 
 void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {
