@@ -418,7 +418,7 @@ def test_chained_blocks_kernel_is_bit_identical_to_the_unfused_pair(weights, ora
                 # form: fp32 rounding apart)
                 assert np.array_equal(s0, s1) and np.array_equal(b0, b1)
             else:
-                assert np.abs(s0 - s1).max() <= 1e-6 and np.abs(b0 - b1).max() <= 1e-6
+                assert np.abs(s0 - s1).max() <= 5e-6 and np.abs(b0 - b1).max() <= 5e-6
         names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
         names_fused = {p["name"] for p in fused_model.profile_read() if p["launches"]}
         assert any(n.startswith("conv_dwpw2_mfma:") for n in names_fused), names_fused
