@@ -12,9 +12,11 @@ namespace ufd {
 namespace {
 
 constexpr float kEps = 1.0e-7f;           // nn.rs:18
-constexpr int kSortLds = 4096;            // keys sorted inside LDS up to this many candidates
-constexpr int kSelLds = 1024;             // selected boxes kept in LDS; the rest spill to HBM
+constexpr int kSortLds = 2048;            // keys sorted inside LDS up to this many candidates (more: sorted in HBM)
+constexpr int kSelLds = 2048;             // selected boxes kept in LDS; the rest spill to HBM (a dependent global
+                                          // read per comparison: frames with > 1024 selected boxes took 600 us)
 constexpr int kBoxLds = 512;              // sorted candidate boxes gathered per round trip (power of two, <= block size)
+constexpr int kNmsBlock = 256;            // candidates per greedy block (4 x 64-bit suppression masks per row)
 
 __device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
   conf = conf + 0.0f;  // -0.0 -> +0.0 (partial_cmp treats them as equal)
@@ -89,10 +91,16 @@ __device__ __forceinline__ float bbox_area(float x0, float y0, float x1, float y
 }
 
 // descending bitonic sort of n2 (power of two) keys by one workgroup
-__device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthreads) {
+// Bitonic sort, descending.  Pair t of a stage with stride s is (lo, lo + s), lo = 2t - (t & (s-1)):
+// for s <= 64 the 64 pairs of a wave (t = 64w .. 64w+63, every pass of the t loop) stay inside one
+// 128-key chunk that no other wave touches, so those stages need no workgroup barrier -- only the
+// wave's own LDS/global accesses in order.  A 2048-key sort has 10 barrier stages instead of 66
+// (a barrier of 16 waves costs ~0.5-1 us: the sort was most of the kernel).
+__device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthreads, bool in_lds) {
   for (int size = 2; size <= n2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
+      if (stride >= 64 || !in_lds) __syncthreads();              // pairs cross the waves' chunks (64: the stage before did)
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // own stores before own loads
       for (int t = tid; t < (n2 >> 1); t += nthreads) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
@@ -112,6 +120,10 @@ __device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthr
 __device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const float4 sb, float max_iou) {
   const float ox0 = fmaxf(c.x, sb.x), oy0 = fmaxf(c.y, sb.y), ox1 = fminf(c.z, sb.z), oy1 = fminf(c.w, sb.w);
   const float overlap = bbox_area(ox0, oy0, ox1, oy1);
+  // Most pairs do not overlap: iou = 0 / (positive) = 0 exactly, so the IEEE division (the bulk of
+  // this function) is skipped when no lane of the wave has an overlap.  (0 > max_iou keeps the
+  // reference's answer for a negative threshold.)
+  if (__ballot(overlap != 0.0f) == 0ull) return 0.0f > max_iou;
   const float denom = __fadd_rn(__fsub_rn(__fadd_rn(area_c, bbox_area(sb.x, sb.y, sb.z, sb.w)), overlap), kEps);
   return __fdiv_rn(overlap, denom) > max_iou;
 }
@@ -130,10 +142,10 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
                                                   uint32_t* __restrict__ ndet, float4* __restrict__ spill) {
   __shared__ unsigned long long s_keys[kSortLds];
   __shared__ float4 s_sel[kSelLds];
-  __shared__ float4 s_cand[64];
+  __shared__ float4 s_cand[kNmsBlock];
   __shared__ float4 s_box[kBoxLds];
-  __shared__ unsigned long long s_row[64];
-  __shared__ unsigned long long s_dead;
+  __shared__ unsigned long long s_row[kNmsBlock][kNmsBlock / 64];  // row i: later candidates of the block that i suppresses
+  __shared__ unsigned long long s_dead[kNmsBlock / 64], s_keep[kNmsBlock / 64];
   __shared__ int s_nsel;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,72 +164,120 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   }
   if (tid == 0) s_nsel = 0;
   __syncthreads();
-  if (n > 1) bitonic_desc(keys, n2, tid, nthr);
+  if (n > 1) bitonic_desc(keys, n2, tid, nthr, keys == s_keys);
   const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
   float4* fspill = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
 
-  for (int b0 = 0; b0 < n; b0 += 64) {
-    const int m = min(64, n - b0);
-    // candidate boxes in sorted order, 512 at a time: one gather round trip per 8 blocks instead
-    // of one per block (the dependent global gather dominated frames with many candidates)
+  constexpr int Q = kNmsBlock / 64;  // 64-candidate groups per block
+  for (int b0 = 0; b0 < n; b0 += kNmsBlock) {
+    const int m = min(kNmsBlock, n - b0);
+    // candidate boxes in sorted order, kBoxLds at a time: one gather round trip per several blocks
     if ((b0 & (kBoxLds - 1)) == 0) {
       if (tid < kBoxLds && b0 + tid < n) s_box[tid] = fb[(int)(keys[b0 + tid] & 0xffffffffull) - 1];
       __syncthreads();
     }
-    if (tid < 64) {
-      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid < m) c = s_box[(b0 & (kBoxLds - 1)) + tid];
-      s_cand[tid] = c;
-      s_row[tid] = 0ull;
+    if (tid < kNmsBlock) {
+      s_cand[tid] = tid < m ? s_box[(b0 & (kBoxLds - 1)) + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < Q; q++) s_row[tid][q] = 0ull;
     }
-    if (tid == 0) s_dead = 0ull;
+    if (tid < Q) s_dead[tid] = 0ull;
     __syncthreads();
     const int nsel = s_nsel;
-    const float4 c = s_cand[lane];
-    const float area_c = bbox_area(c.x, c.y, c.z, c.w);
-    // phase 1: against previously selected boxes, wave w takes s = w, w+nwave, ...
-    unsigned long long dead = 0ull;
+    // the lane's candidates: lane, lane + 64, ...
+    float4 c[Q];
+    float area_c[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      c[q] = s_cand[q * 64 + lane];
+      area_c[q] = bbox_area(c[q].x, c[q].y, c[q].z, c[q].w);
+    }
+    // phase 1: against previously selected boxes, wave w takes s = w, w + nwave, ...
+    unsigned long long dead[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) dead[q] = 0ull;
     for (int sidx = wave; sidx < nsel; sidx += nwave) {
       const float4 sb = sidx < kSelLds ? s_sel[sidx] : fspill[sidx];
-      dead |= __ballot(lane < m && iou_exceeds(c, area_c, sb, max_iou));
+#pragma unroll
+      for (int q = 0; q < Q; q++) dead[q] |= __ballot(q * 64 + lane < m && iou_exceeds(c[q], area_c[q], sb, max_iou));
     }
-    if (lane == 0 && dead) atomicOr(&s_dead, dead);
-    // phase 2: inside the block, wave w takes rows i = w, w+nwave, ...; lane = column j
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+        if (dead[q]) atomicOr(&s_dead[q], dead[q]);
+    }
+    // phase 2: inside the block, wave w takes rows i = w, w + nwave, ...; lanes = the later columns
     for (int i = wave; i < m; i += nwave) {
       const float4 sb = s_cand[i];  // the earlier (higher-confidence) box plays "selected"
-      const unsigned long long row = __ballot(lane > i && lane < m && iou_exceeds(c, area_c, sb, max_iou));
-      if (lane == 0) s_row[i] = row;
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int j = q * 64 + lane;
+        const unsigned long long row = (q * 64 + 63 > i) ? __ballot(j > i && j < m && iou_exceeds(c[q], area_c[q], sb, max_iou)) : 0ull;
+        if (lane == 0) s_row[i][q] = row;
+      }
     }
     __syncthreads();
-    // phase 3
+    // phase 3: greedy pass over the block in scalar registers (lane l of wave 0 holds rows l, l + 64, ...)
     if (wave == 0) {
-      // greedy pass over the block, kept in scalar registers: lane i holds row i and the loop reads
-      // it with v_readlane (a dependent LDS read per candidate cost ~100 cycles x 64 per block)
-      const unsigned long long myrow = s_row[lane];
-      const uint32_t row_lo = (uint32_t)myrow, row_hi = (uint32_t)(myrow >> 32);
-      unsigned long long d = s_dead, keep = 0ull;
-      for (int i = 0; i < m; i++) {
-        if (!((d >> i) & 1ull)) {
-          keep |= 1ull << i;
-          d |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)row_hi, i) << 32) |
-               (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)row_lo, i);
+      uint32_t rlo[Q][Q], rhi[Q][Q];
+#pragma unroll
+      for (int g = 0; g < Q; g++)
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          const unsigned long long r = s_row[g * 64 + lane][q];
+          rlo[g][q] = (uint32_t)r, rhi[g][q] = (uint32_t)(r >> 32);
+        }
+      unsigned long long d[Q], keep[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) d[q] = s_dead[q], keep[q] = 0ull;
+#pragma unroll
+      for (int g = 0; g < Q; g++) {
+        const int cnt = min(64, m - g * 64);
+        // rows that suppress nothing (most of them) need no register reads
+        bool any = false;
+#pragma unroll
+        for (int q = g; q < Q; q++) any = any || (rlo[g][q] | rhi[g][q]) != 0u;
+        const unsigned long long nz = __ballot(any);
+        for (int i = 0; i < cnt; i++) {
+          if (!((d[g] >> i) & 1ull)) {
+            keep[g] |= 1ull << i;
+            if (!((nz >> i) & 1ull)) continue;
+#pragma unroll
+            for (int q = g; q < Q; q++)  // a row only has bits of later candidates
+              d[q] |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rhi[g][q], i) << 32) |
+                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rlo[g][q], i);
+          }
         }
       }
-      if ((keep >> lane) & 1ull) {
-        const int pos = nsel + __popcll(keep & ((1ull << lane) - 1ull));
+      if (lane < Q) s_keep[lane] = keep[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))];
+    }
+    __syncthreads();
+    // kept candidates -> selected list and output, in order
+    if (tid < kNmsBlock) {
+      const int g = tid >> 6;
+      const unsigned long long kg = s_keep[g];
+      if ((kg >> lane) & 1ull) {
+        int pos = nsel + __popcll(kg & ((1ull << lane) - 1ull));
+        for (int q = 0; q < g; q++) pos += __popcll(s_keep[q]);
+        const float4 cc = s_cand[tid];
         if (pos < kSelLds)
-          s_sel[pos] = c;
+          s_sel[pos] = cc;
         else
-          fspill[pos] = c;
+          fspill[pos] = cc;
         if ((uint32_t)pos < det_stride) {
           Det dd;
-          dd.x_tl = c.x, dd.y_tl = c.y, dd.x_br = c.z, dd.y_br = c.w, dd.conf = key_conf(keys[b0 + lane]);
+          dd.x_tl = cc.x, dd.y_tl = cc.y, dd.x_br = cc.z, dd.y_br = cc.w, dd.conf = key_conf(keys[b0 + tid]);
           fd[pos] = dd;
         }
       }
-      if (lane == 0) s_nsel = nsel + __popcll(keep);
-      __threadfence_block();  // spilled boxes are read back by the other waves
+    }
+    __threadfence_block();  // spilled boxes are read back by the other waves
+    __syncthreads();
+    if (tid == 0) {
+      int add = 0;
+      for (int q = 0; q < Q; q++) add += __popcll(s_keep[q]);
+      s_nsel = nsel + add;
     }
     __syncthreads();
   }
