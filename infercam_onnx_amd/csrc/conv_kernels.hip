@@ -31,12 +31,13 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // Neighbouring lane's value through the DPP crossbar (one VALU instruction; __shfl_up/down
 // compile to ds_bpermute_b32, an LDS-pipe instruction plus an address register).  Lane 0 of
-// lane_prev / lane 63 of lane_next get 0: those lanes are halo providers only.
+// lane_prev / lane 63 of lane_next get 0 (bound_ctrl: no "old" value to materialise first): those
+// lanes are halo providers only.
 __device__ __forceinline__ float lane_prev(float x) {  // value of lane - 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_next(float x) {  // value of lane + 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 // ReLU of a value that comes out of an MFMA: fmaxf() costs a canonicalising v_max first (the
 // compiler cannot know the accumulator is not a signalling NaN); for non-NaN floats the integer
