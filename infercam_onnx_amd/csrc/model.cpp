@@ -162,7 +162,7 @@ struct Ctx {
   float4* d_spill = nullptr;
   uint32_t last_forward_count = 0;
 };
-constexpr int kMaxCtx = 4;
+constexpr int kMaxCtx = 8;
 
 constexpr uint32_t kDetCopy = 256;  // detections per frame copied back with the batch
 
@@ -187,7 +187,7 @@ struct ufd_model {
   uint32_t max_w = 0, max_h = 0;
   Ctx ctx[kMaxCtx];
   Worker workers[kMaxCtx];
-  int num_ctx = 2;
+  int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s (tools/hwq_probe.sh); each has its own stream
   int next_ctx = 0;
   std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
   std::mutex err_mu;     // error string
@@ -1549,7 +1549,7 @@ void destroy(ufd_model* m) {
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
   for (Ctx& c : m->ctx) {
-    if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+    if (c.copy_stream && c.copy_stream != c.stream) (void)hipStreamDestroy(c.copy_stream);
     for (int k = 0; k < 2; k++) {
       if (c.aux[k]) (void)hipStreamDestroy(c.aux[k]);
       if (c.ev_join[k]) (void)hipEventDestroy(c.ev_join[k]);
@@ -1617,16 +1617,21 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
+  m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
   if (const char* e = std::getenv("UFD_CTX")) m->num_ctx = std::max(1, std::min(kMaxCtx, std::atoi(e)));  // tuning knob
+  const bool own_copy_stream = !(std::getenv("UFD_COPY_STREAM") && std::atoi(std::getenv("UFD_COPY_STREAM")) == 0);
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];
     HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-      HIPB(hipStreamCreateWithFlags(&c.aux[k], hipStreamNonBlocking));
-      HIPB(hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming));
+    if (own_copy_stream) HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    else c.copy_stream = c.stream;
+    if (m->branch_streams) {
+      for (int k = 0; k < 2; k++) {
+        HIPB(hipStreamCreateWithFlags(&c.aux[k], hipStreamNonBlocking));
+        HIPB(hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming));
+      }
+      HIPB(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
     }
-    HIPB(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
   }
 
   // ---- weights + priors
@@ -1656,7 +1661,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_WEIGHTS);
     }
   }
-  m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
   plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0 || m->branch_streams);
   {
     const Layer& L0 = m->layers[0];
