@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include <vector>
 
 namespace ufd {
 namespace {
@@ -234,6 +235,27 @@ struct DwWindow {  // raw 3 x 4*S input window of one channel for 4 output pixel
 // per-lane scalar gathers for the halo columns cost more than all arithmetic of this kernel.
 constexpr int kDwGroups = 30;
 
+// Depthwise weights in LDS: three copies of the packed [cin][12] table (9 taps ky-major, bias, 2 pad).
+// Copy 1 has tap row 0 zeroed, copy 2 tap row 2: a lane whose window hangs over the top / bottom
+// image border reads its taps from that copy instead of masking nine weights per k-step
+// (fma(0, x, t) == t for the finite x loaded from the clamped row address).
+__device__ __forceinline__ void fill_dw_variants(float* s_dw, const float* __restrict__ w2, int cin) {
+  const float4* src = reinterpret_cast<const float4*>(w2);
+  float4* dst = reinterpret_cast<float4*>(s_dw);
+  const int n4 = cin * 3;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = src[i];
+    const int q = i % 3;  // which 16 bytes of the record: taps 0-3 | taps 4-7 | tap 8, bias, pad
+    float4 top = v, bot = v;
+    if (q == 0) top.x = top.y = top.z = 0.f;
+    if (q == 1) bot.z = bot.w = 0.f;
+    if (q == 2) bot.x = 0.f;
+    dst[i] = v, dst[n4 + i] = top, dst[2 * n4 + i] = bot;
+  }
+}
+__device__ __forceinline__ int dw_variant(bool row0ok, bool row2ok) { return !row0ok ? 1 : (!row2ok ? 2 : 0); }
+
 template <int CT, int S, int D, int SK>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   const ConvArgs& a = p3.a[blockIdx.y];
@@ -244,14 +266,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   if (!remap_block(a, &tile, &ctile)) return;  // whole block, before the barrier
   const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
   float* s_dw = s_mem;
-  float* s_w = s_mem + a.cin * 12;
+  float* s_w = s_mem + 3 * a.cin * 12;
   float* s_red = s_w + CT * ksteps * 64;
   {  // straight 16-byte copies, all in flight at once (a.w2 is pre-packed [cin][12])
-    const float4* src = reinterpret_cast<const float4*>(a.w2);
-    float4* dst = reinterpret_cast<float4*>(s_dw);
-    const int n4 = a.cin * 3;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    fill_dw_variants(s_dw, a.w2, a.cin);
     const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
     float4* wdst = reinterpret_cast<float4*>(s_w);
     const int w4 = CT * ksteps * 16;
@@ -286,26 +304,26 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   // Loads are unconditional from clamped (always valid) addresses and zeroed by select; D k-steps
   // of windows are kept in flight in a register ring.
   const int iy0 = oy * S - 1, ix0 = ox * S;
-  bool rowok[3];
-  uint32_t rowoff[3];  // 32-bit element offsets from the wave-uniform base a.in (< 2^32 bytes, launcher-checked)
+  uint32_t rowoff[3];  // 32-bit BYTE offsets from the wave-uniform base a.in (< 2^32 bytes, launcher-checked)
   const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
-    rowoff[r] = lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0);
-  }
+  for (int r = 0; r < 3; r++) rowoff[r] = 4u * (lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0));
+  // rows outside the image are zero padding: the lane reads its taps from the LDS copy that has
+  // that tap row zeroed (the loads come from clamped, valid addresses)
+  const float* s_dw_lane = s_dw + (dw_variant(iy0 >= 0, iy0 + 2 < a.ih) * a.cin + half) * 12;
   const bool leftok = ix0 > 0;                        // else: image border, the tap is zero padding
   const bool rightok = (S == 1) && (ix0 + 4 < a.iw);  // stride 2 never needs column ix0+8
-  const float* __restrict__ in = a.in;
-  const uint32_t chan_step = 2u * (uint32_t)ihw;
+  const char* __restrict__ in = reinterpret_cast<const char*>(a.in);
+  const size_t chan_step = 8u * (size_t)ihw;  // bytes between the channels of consecutive k-steps
 
+  // (wave-uniform channel base + 32-bit lane offset: the scalar-base form of global_load, no
+  // per-load address arithmetic on the vector ALU)
   auto load_window = [&](int ks, DwWindow<S>& win) {
-    const uint32_t c = (uint32_t)ks * chan_step;
+    const char* base = in + (size_t)ks * chan_step;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const uint32_t o = rowoff[r] + c;
-      win.m0[r] = *reinterpret_cast<const float4*>(in + o);
-      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(in + (o + 4u));
+      win.m0[r] = *reinterpret_cast<const float4*>(base + rowoff[r]);
+      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(base + rowoff[r] + 16);
     }
   };
 
@@ -313,15 +331,13 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   // Rows outside the image are zero padding: their three weights are zeroed instead of the 4 or 8
   // loaded pixels (fma(0, x, t) == t for finite x; the loads come from clamped, valid addresses).
   auto dw_compute = [&](const DwWindow<S>& win, int ks, float (&t)[4]) {
-    // (unconditional 16-byte LDS reads first: a select on a load becomes a predicated load)
-    const float4* wq = reinterpret_cast<const float4*>(s_dw + (2 * ks + half) * 12);
+    const float4* wq = reinterpret_cast<const float4*>(s_dw_lane + 2 * ks * 12);
     const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
     const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
     float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const bool ok = rowok[r];
-      const float w0 = ok ? wd[3 * r] : 0.f, w1 = ok ? wd[3 * r + 1] : 0.f, w2 = ok ? wd[3 * r + 2] : 0.f;
+      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
       if (S == 1) {
         const float4 m = win.m0[r];
         const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
@@ -423,15 +439,9 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   }
   if (tgrp >= a.tiles) return;  // whole block, before any barrier
   const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
-  float* s_dw = s_mem;                                              // [cin][12]
-  float4* s_t = reinterpret_cast<float4*>(s_mem + a.cin * 12);      // [PT][3][CH][64]
-  {
-    const float4* src = reinterpret_cast<const float4*>(a.w2);
-    float4* dst = reinterpret_cast<float4*>(s_dw);
-    const int n4 = a.cin * 3;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-  }
+  float* s_dw = s_mem;                                              // [3][cin][12] (fill_dw_variants)
+  float4* s_t = reinterpret_cast<float4*>(s_mem + 3 * a.cin * 12);  // [PT][3][CH][64]
+  fill_dw_variants(s_dw, a.w2, a.cin);
   __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const long total = (long)a.B * gpf;
@@ -447,38 +457,35 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   floatx16 acc[1][4];
   init_acc<1>(a, acc, ct, half);
 
+  // (addressing and border handling as in k_dwpw_mfma: byte offsets from a wave-uniform channel
+  // base, tap rows over the image border zeroed in the lane's copy of the LDS table)
   const int iy0 = oy * S - 1, ix0 = ox * S;
-  bool rowok[3];
   uint32_t rowoff[3];
   const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    rowok[r] = (iy0 + r) >= 0 && (iy0 + r) < a.ih;
-    rowoff[r] = lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0);
-  }
+  for (int r = 0; r < 3; r++) rowoff[r] = 4u * (lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0));
+  const float* s_dw_lane = s_dw + (dw_variant(iy0 >= 0, iy0 + 2 < a.ih) * a.cin + half) * 12;
   const bool leftok = ix0 > 0;
   const bool rightok = (S == 1) && (ix0 + 4 < a.iw);
-  const float* __restrict__ in = a.in;
-  const uint32_t chan_step = 2u * (uint32_t)ihw;
+  const char* __restrict__ in = reinterpret_cast<const char*>(a.in);
+  const size_t chan_step = 8u * (size_t)ihw;
 
   auto load_window = [&](int ks, DwWindow<S>& win) {
-    const uint32_t c = (uint32_t)ks * chan_step;
+    const char* base = in + (size_t)ks * chan_step;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const uint32_t o = rowoff[r] + c;
-      win.m0[r] = *reinterpret_cast<const float4*>(in + o);
-      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(in + (o + 4u));
+      win.m0[r] = *reinterpret_cast<const float4*>(base + rowoff[r]);
+      if (S == 2) win.m1[r] = *reinterpret_cast<const float4*>(base + rowoff[r] + 16);
     }
   };
   auto dw_compute = [&](const DwWindow<S>& win, int ks) -> float4 {
-    const float4* wq = reinterpret_cast<const float4*>(s_dw + (2 * ks + half) * 12);
+    const float4* wq = reinterpret_cast<const float4*>(s_dw_lane + 2 * ks * 12);
     const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
     const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
     float t0 = wd[9], t1 = t0, t2 = t0, t3 = t0;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const bool ok = rowok[r];
-      const float w0 = ok ? wd[3 * r] : 0.f, w1 = ok ? wd[3 * r + 1] : 0.f, w2 = ok ? wd[3 * r + 2] : 0.f;
+      const float w0 = wd[3 * r], w1 = wd[3 * r + 1], w2 = wd[3 * r + 2];
       if (S == 1) {
         const float4 m = win.m0[r];
         const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
@@ -592,10 +599,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const ConvArgs& a2 = p3.a[1];
   constexpr int KS1 = C1 / 2, KS2 = 16;
   extern __shared__ float s_mem[];
-  float* s_dw1 = s_mem;             // [C1][12]
-  float* s_w1 = s_dw1 + C1 * 12;    // [KS1][64]
-  float* s_dw2 = s_w1 + KS1 * 64;   // [32][12]
-  float* s_w2 = s_dw2 + 32 * 12;    // [CT2][KS2][64]
+  float* s_dw1 = s_mem;                // [3][C1][12] (fill_dw_variants)
+  float* s_w1 = s_dw1 + 3 * C1 * 12;   // [KS1][64]
+  float* s_dw2 = s_w1 + KS1 * 64;      // [2][32][12]: the packed table, then a copy with all taps zero
+  float* s_w2 = s_dw2 + 2 * 32 * 12;   // [CT2][KS2][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Workgroup ids are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of
   // tiles, so that neighbouring tiles (which share input rows) meet in the same L2 close in time.
@@ -608,9 +615,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float4* d4 = reinterpret_cast<float4*>(dst);
       for (int i = threadIdx.x; i < n4; i += 256) d4[i] = s4[i];
     };
-    copy4(s_dw1, a1.w2, C1 * 3);
+    fill_dw_variants(s_dw1, a1.w2, C1);
     copy4(s_w1, a1.w, KS1 * 16);
     copy4(s_dw2, a2.w2, 32 * 3);
+    for (int i = threadIdx.x; i < 32 * 12; i += 256) s_dw2[32 * 12 + i] = 0.f;
     copy4(s_w2, a2.w, CT2 * KS2 * 16);
   }
   __syncthreads();
@@ -629,9 +637,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int x0 = 2 * ox + 4 * sub;            // first X1 / input column of the lane
   const bool leftok = x0 > 0;                 // column x0 - 1 exists (else zero padding)
   const bool rightok = x0 + 4 < W1;           // column x0 + 4 exists
-  const float* __restrict__ in = a1.in;
+  const char* __restrict__ in = reinterpret_cast<const char*>(a1.in);
   const uint32_t lane_base = (uint32_t)((frame * a1.in_ctotal + half) * ihw);
-  const uint32_t chan_step = 2u * (uint32_t)ihw;
+  const size_t chan_step = 8u * (size_t)ihw;  // bytes between the channels of consecutive k-steps
 
   // second block: depthwise sums of the lane's 16 channels x 2 output pixels
   float t2[16][2];
@@ -645,7 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int k = 0; k < 5; k++) {
     const int y0 = 2 * oy - 2 + k;
     ok5[k] = y0 >= 0 && y0 < H1;
-    rowoff5[k] = lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0);
+    rowoff5[k] = 4u * (lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0));  // bytes
   }
   // input windows: 3 rows x 4 columns of channel 2*ks + half; two k-steps are kept in flight
   // ACROSS the three X1 rows (the ring never drains: the first windows of the next row are loaded
@@ -654,41 +662,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (the row loop stays rolled -- unrolled, the three bodies keep 470 registers live -- so
   // rowoff5[row + k] is a select on the wave-uniform row, not a register-array index)
   auto pick = [](int row, auto v0, auto v1, auto v2) { return row == 0 ? v0 : (row == 1 ? v1 : v2); };
-  auto load_window = [&](int row, int ks, float4 (&m)[3]) {
-    const uint32_t c = (uint32_t)ks * chan_step;
+  // (wave-uniform channel base + the lane's 32-bit byte offset of the row)
+  auto load_window = [&](const uint32_t (&ro)[3], int ks, float4 (&m)[3]) {
+    const char* base = in + (size_t)ks * chan_step;
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-      m[k] = *reinterpret_cast<const float4*>(in + (pick(row, rowoff5[k], rowoff5[k + 1], rowoff5[k + 2]) + c));
+    for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(base + ro[k]);
+  };
+  auto row_offsets = [&](int row, uint32_t (&ro)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) ro[k] = pick(row, rowoff5[k], rowoff5[k + 1], rowoff5[k + 2]);
   };
   // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
-  // zero padding: their weights are zeroed instead of the pixels (fma(0, x, t) == t).
-  auto dw_compute = [&](int row, const float4 (&m3)[3], int ks, float (&t)[4]) {
-    // (unconditional 16-byte LDS reads first: a select on a load becomes a predicated load)
-    const float4* wq = reinterpret_cast<const float4*>(s_dw1 + (2 * ks + half) * 12);
+  // zero padding: `wl` points into the copy of the LDS table that has those taps zeroed.
+  auto dw_compute = [&](const float* wl, const float4 (&m3)[3], int ks, float (&t)[4]) {
+    const float4* wq = reinterpret_cast<const float4*>(wl + 2 * ks * 12);
     const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
     const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
     float t0 = wd[9], t1 = t0, t2_ = t0, t3 = t0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const bool ok = pick(row, ok5[k], ok5[k + 1], ok5[k + 2]);
-      const float w0 = ok ? wd[3 * k] : 0.f, w1 = ok ? wd[3 * k + 1] : 0.f, w2 = ok ? wd[3 * k + 2] : 0.f;
+      const float w0 = wd[3 * k], w1 = wd[3 * k + 1], w2 = wd[3 * k + 2];
       const float4 m = m3[k];
       const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
       const float l = leftok ? from_prev : 0.f, rr = rightok ? from_next : 0.f;
-      t0 = fmaf(w0, l, t0), t0 = fmaf(w1, m.x, t0), t0 = fmaf(w2, m.y, t0);
-      t1 = fmaf(w0, m.x, t1), t1 = fmaf(w1, m.y, t1), t1 = fmaf(w2, m.z, t1);
-      t2_ = fmaf(w0, m.y, t2_), t2_ = fmaf(w1, m.z, t2_), t2_ = fmaf(w2, m.w, t2_);
-      t3 = fmaf(w0, m.z, t3), t3 = fmaf(w1, m.w, t3), t3 = fmaf(w2, rr, t3);
+      t0 = fmaf(w0, l, t0), t1 = fmaf(w0, m.x, t1), t2_ = fmaf(w0, m.y, t2_), t3 = fmaf(w0, m.z, t3);
+      t0 = fmaf(w1, m.x, t0), t1 = fmaf(w1, m.y, t1), t2_ = fmaf(w1, m.z, t2_), t3 = fmaf(w1, m.w, t3);
+      t0 = fmaf(w2, m.y, t0), t1 = fmaf(w2, m.z, t1), t2_ = fmaf(w2, m.w, t2_), t3 = fmaf(w2, rr, t3);
     }
     t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
   };
-  load_window(0, 0, win[0]);
-  load_window(0, 1, win[1]);
+  {
+    uint32_t ro[3];
+    row_offsets(0, ro);
+    load_window(ro, 0, win[0]);
+    load_window(ro, 1, win[1]);
+  }
 
 #pragma unroll 1
   for (int row = 0; row < 3; row++) {
     const int y1 = 2 * oy - 1 + row;  // X1 row
     const bool row1ok = y1 >= 0 && y1 < H1;
+    uint32_t ro[3], ro_next[3];  // this X1 row's input rows, the next one's (the last row: its own)
+    row_offsets(row, ro);
+    row_offsets(row < 2 ? row + 1 : row, ro_next);
+    // (an X1 row outside the image has two padding input rows; it is computed from whatever the
+    // clamped addresses hold and dropped below by the zero taps of the second depthwise conv)
+    const float* wl = s_dw1 + (dw_variant(pick(row, ok5[0], ok5[1], ok5[2]), pick(row, ok5[2], ok5[3], ok5[4])) * C1 + half) * 12;
     floatx16 acc[4];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -698,7 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // software pipeline: the MFMAs of k-step ks run beside the depthwise arithmetic of ks + 1
     float tcur[4];
-    dw_compute(row, win[0], 0, tcur);
+    dw_compute(wl, win[0], 0, tcur);
 #pragma unroll 1
     for (int ks0 = 0; ks0 < KS1; ks0 += 2) {
 #pragma unroll
@@ -707,30 +726,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // slot d held step ks (already consumed into tcur): refill it with step ks + 2 -- of the
         // next X1 row once this one runs out (the last row re-reads its own last window)
         if (ks + 2 < KS1)
-          load_window(row, ks + 2, win[d]);
+          load_window(ro, ks + 2, win[d]);
         else
-          load_window(row < 2 ? row + 1 : row, row < 2 ? ks + 2 - KS1 : KS1 - 1, win[d]);
+          load_window(ro_next, row < 2 ? ks + 2 - KS1 : KS1 - 1, win[d]);
         const float w = s_w1[ks * 64 + lane];
         float tnext[4];
-        dw_compute(row, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
+        dw_compute(wl, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
+        // (no sched_group_barrier here: fp32 MFMAs and the wave's own vector instructions do not
+        // overlap on gfx950 -- tools/ubench/mfma_f32_cost.hip -- and the compiler's own order
+        // measured 3 % faster than "one MFMA, fourteen VALU")
 #pragma unroll
         for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, tcur[p], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // then a slice of the VALU work
-        }
 #pragma unroll
         for (int p = 0; p < 4; p++) tcur[p] = tnext[p];
       }
     }
-    // X1 row of the lane's 16 channels -> second depthwise sums (row `row` of the 3x3 taps)
+    // X1 row of the lane's 16 channels -> second depthwise sums (row `row` of the 3x3 taps);
+    // an X1 row outside the image is zero padding: taps from the all-zero copy (fma(0, x, t) == t)
+    const float* wl2 = s_dw2 + (row1ok ? 0 : 32 * 12) + 4 * half * 12 + 3 * row;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float* wd2 = s_dw2 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 3 * row;
-      // an X1 row outside the image is zero padding: zero weights (fma(0, x, t) == t)
-      const float u0 = wd2[0], u1 = wd2[1], u2 = wd2[2];
-      const float w0 = row1ok ? u0 : 0.f, w1 = row1ok ? u1 : 0.f, w2 = row1ok ? u2 : 0.f;
+      const float* wd2 = wl2 + ((r & 3) + 8 * (r >> 2)) * 12;
+      const float w0 = wd2[0], w1 = wd2[1], w2 = wd2[2];
       float x[4];
 #pragma unroll
       for (int p = 0; p < 4; p++) x[p] = a1.relu ? relu_acc(acc[p][r]) : acc[p][r];
@@ -1336,6 +1353,15 @@ static bool want_splitk(long wave_tiles, int cts, int ksteps) {
   // chain length (15x20 maps, 64->4/8 heads at 30x40, the 256-channel layers); costs otherwise
   return wave_tiles * cts < 6L * ksteps;
 }
+constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of a gfx950 CU
+// Kernels that ask for more than the default 64 KB of dynamic LDS: raised once per kernel and host thread.
+static void allow_large_lds(const void* kernel) {
+  thread_local std::vector<const void*> done;
+  for (const void* k : done)
+    if (k == kernel) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes);
+  done.push_back(kernel);
+}
 constexpr size_t kSplitKBytes = 64 * 64 * sizeof(float);  // CT = 1: one partial tile at a time
 
 // n (<= 3) convolutions with identical shapes except cout / weights / outputs
@@ -1377,7 +1403,7 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
   const long groups = (long)r.B * (r.oh * r.ow / 4);
   const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
   const int ksteps = r.cin >> 1;
-  const size_t lds = ((size_t)r.cin * 12 + (size_t)ksteps * 64) * sizeof(float);
+  const size_t lds = ((size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float);
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
   const bool sk = want_splitk(wave_tiles, max_cts * n, ksteps);
@@ -1394,35 +1420,32 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     p.a[0].cts = max_cts;
     p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups
     const unsigned blocks = (unsigned)((p.a[0].tiles + 7) / 8) * 8 * (max_cts / ctw);
-    const size_t clds = (size_t)r.cin * 12 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
-    if (stride == 1) {
-      if (ctw == 4) hipLaunchKernelGGL((k_dwpw_coop<1, 4>), dim3(blocks, 1), dim3(256), clds, s, p);
-      else hipLaunchKernelGGL((k_dwpw_coop<1, 2>), dim3(blocks, 1), dim3(256), clds, s, p);
-    } else {
-      if (ctw == 4) hipLaunchKernelGGL((k_dwpw_coop<2, 4>), dim3(blocks, 1), dim3(256), clds, s, p);
-      else hipLaunchKernelGGL((k_dwpw_coop<2, 2>), dim3(blocks, 1), dim3(256), clds, s, p);
-    }
+    const size_t clds = (size_t)r.cin * 36 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
+    void (*kernel)(ConvArgs3) = stride == 1 ? (ctw == 4 ? k_dwpw_coop<1, 4> : k_dwpw_coop<1, 2>)
+                                             : (ctw == 4 ? k_dwpw_coop<2, 4> : k_dwpw_coop<2, 2>);
+    if (clds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, dim3(blocks, 1), dim3(256), clds, s, p);
     return;
   }
   const dim3 g(grid, n);
+  // (the three copies of the depthwise table of a 256-channel layer need more than the default
+  // 64 KB of dynamic LDS: raised once per instantiation)
+  auto launch = [&](void (*kernel)(ConvArgs3), size_t bytes) {
+    if (bytes > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, g, dim3(256), bytes, s, p);
+  };
   if (sk) {
-    if (stride == 1)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 4>), g, dim3(256), lds + kSplitKBytes, s, p);
-    else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 4>), g, dim3(256), lds + kSplitKBytes, s, p);
+    if (stride == 1) launch(k_dwpw_mfma<1, 1, 2, 4>, lds + kSplitKBytes);
+    else launch(k_dwpw_mfma<1, 2, 2, 4>, lds + kSplitKBytes);
     return;
   }
   const bool deep = ksteps % 4 == 0;
   if (stride == 1) {
-    if (deep)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 2, 1>), g, dim3(256), lds, s, p);
-    else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 1, 1, 1>), g, dim3(256), lds, s, p);
+    if (deep) launch(k_dwpw_mfma<1, 1, 2, 1>, lds);
+    else launch(k_dwpw_mfma<1, 1, 1, 1>, lds);
   } else {
-    if (deep)
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 2, 1>), g, dim3(256), lds, s, p);
-    else
-      hipLaunchKernelGGL((k_dwpw_mfma<1, 2, 1, 1>), g, dim3(256), lds, s, p);
+    if (deep) launch(k_dwpw_mfma<1, 2, 2, 1>, lds);
+    else launch(k_dwpw_mfma<1, 2, 1, 1>, lds);
   }
 }
 
@@ -1441,7 +1464,7 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   p.a[1].tiles = (int)((wave_tiles + 3) / 4);
   p.a[1].cts = 1;
   const int ct2 = (second.cout + 31) / 32;
-  const size_t lds = ((size_t)first.cin * 12 + (first.cin / 2) * 64 + 32 * 12 + (size_t)ct2 * 16 * 64) * sizeof(float);
+  const size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64) * sizeof(float);
   const dim3 grid((unsigned)((p.a[1].tiles + 7) / 8 * 8));
   if (first.cin == 16 && ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<16, 1>), grid, dim3(256), lds, s, p);
   else if (first.cin == 16) hipLaunchKernelGGL((k_dwpw2_mfma<16, 2>), grid, dim3(256), lds, s, p);
