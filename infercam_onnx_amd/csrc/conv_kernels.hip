@@ -239,20 +239,20 @@ constexpr int kDwGroups = 30;
 // Copy 1 has tap row 0 zeroed, copy 2 tap row 2: a lane whose window hangs over the top / bottom
 // image border reads its taps from that copy instead of masking nine weights per k-step
 // (fma(0, x, t) == t for the finite x loaded from the clamped row address).
+__device__ __forceinline__ void put_dw_variants(float4* dst, int n4, int i, float4 v) {  // 16 bytes i of the table
+  const int q = i % 3;  // which 16 bytes of the record: taps 0-3 | taps 4-7 | tap 8, bias, pad
+  float4 top = v, bot = v;
+  if (q == 0) top.x = top.y = top.z = 0.f;
+  if (q == 1) bot.z = bot.w = 0.f;
+  if (q == 2) bot.x = 0.f;
+  dst[i] = v, dst[n4 + i] = top, dst[2 * n4 + i] = bot;
+}
 __device__ __forceinline__ void fill_dw_variants(float* s_dw, const float* __restrict__ w2, int cin) {
   const float4* src = reinterpret_cast<const float4*>(w2);
   float4* dst = reinterpret_cast<float4*>(s_dw);
   const int n4 = cin * 3;
 #pragma unroll 4
-  for (int i = threadIdx.x; i < n4; i += 256) {
-    const float4 v = src[i];
-    const int q = i % 3;  // which 16 bytes of the record: taps 0-3 | taps 4-7 | tap 8, bias, pad
-    float4 top = v, bot = v;
-    if (q == 0) top.x = top.y = top.z = 0.f;
-    if (q == 1) bot.z = bot.w = 0.f;
-    if (q == 2) bot.x = 0.f;
-    dst[i] = v, dst[n4 + i] = top, dst[2 * n4 + i] = bot;
-  }
+  for (int i = threadIdx.x; i < n4; i += 256) put_dw_variants(dst, n4, i, src[i]);
 }
 __device__ __forceinline__ int dw_variant(bool row0ok, bool row2ok) { return !row0ok ? 1 : (!row2ok ? 2 : 0); }
 
@@ -268,15 +268,6 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   float* s_dw = s_mem;
   float* s_w = s_mem + 3 * a.cin * 12;
   float* s_red = s_w + CT * ksteps * 64;
-  {  // straight 16-byte copies, all in flight at once (a.w2 is pre-packed [cin][12])
-    fill_dw_variants(s_dw, a.w2, a.cin);
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
-    float4* wdst = reinterpret_cast<float4*>(s_w);
-    const int w4 = CT * ksteps * 16;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < w4; i += 256) wdst[i] = wsrc[i];
-  }
-  __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int j32 = lane & 31;
   const long total = (long)a.B * gpf;
@@ -368,6 +359,22 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   DwWindow<S> ring[D];
 #pragma unroll
   for (int d = 0; d < D; d++) load_window(min(kbeg + d, kend - 1), ring[d]);
+  // the first windows are in flight while the weights go to LDS
+  {  // straight 16-byte copies in ONE loop, so that loads of both tables are in flight together
+    // (a.w2 is pre-packed [cin][12], a.w [cout tile][k-step][64])
+    const float4* dsrc = reinterpret_cast<const float4*>(a.w2);
+    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
+    float4* ddst = reinterpret_cast<float4*>(s_dw);
+    float4* wdst = reinterpret_cast<float4*>(s_w);
+    const int n4 = a.cin * 3, w4 = CT * ksteps * 16;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4 + w4; i += 256) {
+      const float4 v = i < n4 ? dsrc[i] : wsrc[i - n4];
+      if (i < n4) put_dw_variants(ddst, n4, i, v);
+      else wdst[i - n4] = v;
+    }
+  }
+  __syncthreads();
   float tcur[4];
   dw_compute(ring[0], kbeg, tcur);
   for (int ks0 = kbeg; ks0 < kend; ks0 += D) {
@@ -441,8 +448,6 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
   float* s_dw = s_mem;                                              // [3][cin][12] (fill_dw_variants)
   float4* s_t = reinterpret_cast<float4*>(s_mem + 3 * a.cin * 12);  // [PT][3][CH][64]
-  fill_dw_variants(s_dw, a.w2, a.cin);
-  __syncthreads();
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const long total = (long)a.B * gpf;
   const long g = ((long)tgrp * PT + pt) * kDwGroups + j32 - 1;
@@ -549,6 +554,8 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   load_windows(0, winA);
   load_windows(1, winB);
   load_weights(0, wA);
+  fill_dw_variants(s_dw, a.w2, a.cin);  // (the first windows are in flight while the table goes to LDS)
+  __syncthreads();
   publish(0, winA);
   load_windows(2, winA);
   publish(1, winB);
