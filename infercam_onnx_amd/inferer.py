@@ -6,6 +6,7 @@ thresholds 0.5/0.5 (inferer.rs:23); here one GPU worker drains the queue in batc
 asynchronous C ABI.  Draw + JPEG re-encode (inferer.rs:38-40) are outside this path:
 the sender receives the detections.
 """
+import collections
 import queue
 
 from .nn import UltrafaceModel, UltrafaceVariant
@@ -18,9 +19,11 @@ class Inferer:
     (lib.rs:32); `sender` is a callable receiving `(detections or None, status)`; a `None` slot
     stops the loop (the reference loops forever)."""
 
-    def __init__(self, infer_rx, model=None, max_batch=32, **model_kw):
+    def __init__(self, infer_rx, model=None, max_batch=32, depth=6, **model_kw):
         self.infer_rx = infer_rx
         self.max_batch = max_batch
+        # batches in flight: the handle runs three device contexts, two batches each keep them fed
+        self.depth = max(1, min(depth, 8))
         # reference default: UltrafaceModel::new(W320H240, 0.5, 0.5) (inferer.rs:23)
         self.model = model or UltrafaceModel(UltrafaceVariant.W320H240, 0.5, 0.5, max_batch=max_batch, **model_kw)
 
@@ -38,19 +41,24 @@ class Inferer:
         return slots
 
     def run(self):
-        pending = None
+        pending = collections.deque()
         stop = False
         while not stop:
+            # nothing waiting to be overlapped with: hand the oldest results over before blocking
+            # on the channel (a lone frame must not wait for the next one to arrive)
+            if pending and self.infer_rx.empty():
+                self._deliver(*pending.popleft())
+                continue
             slots = self._drain()
             if slots[-1] is None:
                 stop = True
                 slots = slots[:-1]
-            ticket = self.model.submit_jpeg_batch([s[2] for s in slots]) if slots else None
-            if pending is not None:
-                self._deliver(*pending)
-            pending = (ticket, slots) if slots else None
-        if pending is not None:
-            self._deliver(*pending)
+            if slots:
+                pending.append((self.model.submit_jpeg_batch([s[2] for s in slots]), slots))
+            while len(pending) >= self.depth:
+                self._deliver(*pending.popleft())
+        while pending:
+            self._deliver(*pending.popleft())
 
     def _deliver(self, ticket, slots):
         results, status = self.model.wait(ticket)

@@ -138,3 +138,51 @@ def test_synthetic_inputs_are_deterministic():
     assert not np.array_equal(synth.synth_frame(1, 2, 64, 48), synth.synth_frame(1, 3, 64, 48))
     j = synth.encode_jpeg(synth.synth_frame(synth.DEFAULT_FRAME_SEED, 0, 640, 480))
     assert 15000 < len(j) < 90000  # camera-like size, not incompressible noise
+
+
+def test_inferer_loop_pipelining_and_ordering():
+    """Host logic of the Inferer mirror (inferer.rs:29-50) with a stand-in model: results reach the
+    slots in order, at most `depth` batches are in flight, and a lone frame is delivered without
+    waiting for the next one to arrive."""
+    import queue
+    import threading
+
+    from infercam_onnx_amd.inferer import Inferer
+
+    class FakeModel:
+        def __init__(self):
+            self.in_flight = 0
+            self.max_in_flight = 0
+            self.batches = []
+
+        def submit_jpeg_batch(self, jpegs):
+            self.in_flight += 1
+            self.max_in_flight = max(self.max_in_flight, self.in_flight)
+            self.batches.append(list(jpegs))
+            return len(self.batches) - 1
+
+        def wait(self, ticket):
+            self.in_flight -= 1
+            jpegs = self.batches[ticket]
+            return [[("det", j)] for j in jpegs], [0] * len(jpegs)
+
+    # a burst: 50 frames queued up front, batches of 4, depth 3
+    rx, got, model = queue.Queue(), [], FakeModel()
+    for i in range(50):
+        rx.put((1280, 720, b"frame%d" % i, lambda r, i=i: got.append((i, r))))
+    rx.put(None)
+    Inferer(rx, model=model, max_batch=4, depth=3).run()
+    assert [i for i, _ in got] == list(range(50))
+    assert all(r == ([("det", b"frame%d" % i)], 0) for i, r in got)
+    assert 2 <= model.max_in_flight <= 3 and model.in_flight == 0
+    assert all(len(b) <= 4 for b in model.batches)
+
+    # a lone frame: its result arrives while the loop is still waiting for the next slot
+    rx, model, delivered = queue.Queue(), FakeModel(), threading.Event()
+    rx.put((1280, 720, b"only", lambda r: delivered.set()))
+    t = threading.Thread(target=Inferer(rx, model=model, max_batch=4).run, daemon=True)
+    t.start()
+    assert delivered.wait(5.0)
+    rx.put(None)
+    t.join(5.0)
+    assert not t.is_alive()
