@@ -111,8 +111,10 @@ int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h
 
 /* Asynchronous form (the 10-slot StaticImage ring of lib.rs:32-37 becomes `slots` in-flight
  * batches): ufd_submit_jpeg_batch copies/entropy-decodes on host workers and enqueues the GPU
- * work on the handle's stream, returning a ticket; ufd_wait blocks until that batch is done
- * and fills the outputs given at submit.  Input and output buffers must stay valid until then. */
+ * work on one of the handle's streams, returning a ticket; ufd_wait blocks until that batch is done
+ * and fills the outputs given at submit.  Input and output buffers must stay valid until then.
+ * The handle runs three device contexts in rotation: keep a multiple of three batches in flight
+ * (six is what bench.py uses) for full throughput; one at a time is the lowest-latency form. */
 #define UFD_MAX_SLOTS 8
 int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
                           ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket);

@@ -1,12 +1,19 @@
-# Throughput against the number of HSA hardware queues the HIP runtime may use (GPU_MAX_HW_QUEUES)
-# and the number of contexts (UFD_CTX).  Usage on the GPU box: bash tools/hwq_probe.sh
+# Throughput against the number of HSA hardware queues the HIP runtime may use (GPU_MAX_HW_QUEUES),
+# the number of contexts (UFD_CTX) and the other pipeline-level tuning knobs.  Usage on the GPU box:
+# bash tools/hwq_probe.sh [set]   (set: queues | chunk)
 set -u
 B="python bench.py --no-variants --no-cpu-baseline --steps 300 --warmup 30"
 run() { echo "== $1"; shift; env "$@" $B 2>&1 | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         j=json.loads(l); print(j['value'], j['ms_per_step'])"; }
-B0="$B"
-for d in 3 6 8; do B="$B0 --depth $d"; run "ctx3 depth$d" A=1; done
-for d in 4 8; do B="$B0 --depth $d"; run "ctx4 depth$d" UFD_CTX=4; done
-B="$B0 --depth 6"; run "ctx3 depth6 again" A=1
+case "${1:-queues}" in
+queues)
+  for c in 1 2 3 4; do run "ctx$c" UFD_CTX=$c; done
+  for q in 2 3 5 8; do run "hwq$q ctx3" GPU_MAX_HW_QUEUES=$q UFD_CTX=3; done
+  ;;
+chunk)
+  run base A=1
+  for ch in 4 8 16; do for l in 5 9; do run "chunk$ch layers<$l" UFD_CHUNK=$ch UFD_CHUNK_LAYERS=$l; done; done
+  ;;
+esac
