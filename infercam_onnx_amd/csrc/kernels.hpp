@@ -186,8 +186,12 @@ void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_c
 struct Det {
   float x_tl, y_tl, x_br, y_br, conf;
 };
+// Frames with more than 256 (and at most 2048) candidates are finished by two more launches: their
+// suppression matrix over the whole GPU, then one wave per frame (d_mat: nms_matrix_bytes(B) of
+// scratch; nullptr keeps everything inside the first kernel).
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
-                     uint32_t B, hipStream_t s);
+                     unsigned long long* d_mat, uint32_t B, hipStream_t s);
+size_t nms_matrix_bytes(uint32_t B);
 
 }  // namespace ufd

@@ -160,6 +160,7 @@ struct Ctx {
   Det* d_dets = nullptr;
   uint32_t* d_ndet = nullptr;
   float4* d_spill = nullptr;
+  unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
   uint32_t last_forward_count = 0;
 };
 constexpr int kMaxCtx = 8;
@@ -217,6 +218,7 @@ struct ufd_model {
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   bool branch_streams = false;
+  bool nms_matrix = true;  // UFD_NO_NMS_MATRIX: every frame's NMS inside k_sort_nms (comparison knob)
 
   Slot slots[UFD_MAX_SLOTS];
   uint32_t next_ticket = 1;
@@ -1017,7 +1019,7 @@ void enqueue_heads(ufd_model* m, uint32_t count) {
 void enqueue_nms(ufd_model* m, uint32_t count) {
   ProfScope ps(m, "sort_nms", 0, 0);
   launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, tl_cur->d_dets, m->K, tl_cur->d_ndet,
-                  tl_cur->d_spill, count, tl_cur->stream);
+                  tl_cur->d_spill, m->nms_matrix ? tl_cur->d_nms_mat : nullptr, count, tl_cur->stream);
 }
 
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
@@ -1532,6 +1534,7 @@ void destroy(ufd_model* m) {
     dfree(c.d_planes), dfree(c.d_rgb), dfree(c.d_sync);
     dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_dets), dfree(c.d_ndet);
     dfree(c.d_spill);
+    dfree(c.d_nms_mat);
   }
   for (auto& kv : m->taps)
     for (TapsDev* t : {&kv.second.first, &kv.second.second}) dfree(t->left), dfree(t->cnt), dfree(t->w);
@@ -1617,6 +1620,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
+  m->nms_matrix = !std::getenv("UFD_NO_NMS_MATRIX");
   m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
   if (const char* e = std::getenv("UFD_CTX")) m->num_ctx = std::max(1, std::min(kMaxCtx, std::atoi(e)));  // tuning knob
   const bool own_copy_stream = !(std::getenv("UFD_COPY_STREAM") && std::atoi(std::getenv("UFD_COPY_STREAM")) == 0);
@@ -1739,6 +1743,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_dets, B * m->K * sizeof(Det)));
     HIPB(hipMalloc(&c.d_ndet, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
+    HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B)));
     HIPB(hipMemset(c.d_dets, 0, B * m->K * sizeof(Det)));
   }
   HIPB(hipDeviceSynchronize());

@@ -7,6 +7,7 @@
 // Processing order = confidence descending, ties by HIGHER prior index first: encoded as one
 // 64-bit key (orderable confidence bits << 32 | prior index + 1) sorted descending.
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace ufd {
 namespace {
@@ -17,6 +18,14 @@ constexpr int kSelLds = 2048;             // selected boxes kept in LDS; the res
                                           // read per comparison: frames with > 1024 selected boxes took 600 us)
 constexpr int kBoxLds = 512;              // sorted candidate boxes gathered per round trip (power of two, <= block size)
 constexpr int kNmsBlock = 256;            // candidates per greedy block (4 x 64-bit suppression masks per row)
+// Frames with more candidates than one greedy block (and at most kMatMax) leave k_sort_nms after the
+// sort: their pairwise suppression matrix is computed by the whole GPU (k_nms_matrix) and resolved
+// by one wave per frame (k_nms_scan).  Inside k_sort_nms the quadratic work of such a frame runs on
+// ONE compute unit and set the latency of the whole batch (1359 candidates: 380 us).
+constexpr int kMatMin = 256;              // frames with more candidates than this take the matrix path
+constexpr int kMatMax = 2048;             // = kSortLds: the sorted keys of such a frame are in LDS
+constexpr int kMatWords = kMatMax / 64;   // 64-bit words per matrix row
+constexpr uint32_t kHeavyFlag = 0x80000000u;  // ndet[frame] = kHeavyFlag | n between the kernels
 
 __device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
   conf = conf + 0.0f;  // -0.0 -> +0.0 (partial_cmp treats them as equal)
@@ -139,7 +148,7 @@ __device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const 
 __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
                                                   const uint32_t* __restrict__ counts, const float* __restrict__ boxes,
                                                   int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
-                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill) {
+                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min) {
   __shared__ unsigned long long s_keys[kSortLds];
   __shared__ float4 s_sel[kSelLds];
   __shared__ float4 s_cand[kNmsBlock];
@@ -168,6 +177,17 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
   float4* fspill = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
+  if (n > mat_min && n <= kMatMax) {
+    // sorted keys and boxes for k_nms_matrix / k_nms_scan (the spill area is free: it only holds
+    // selected boxes of the in-kernel path)
+    for (int i = tid; i < n; i += nthr) {
+      const unsigned long long key = keys[i];
+      fkeys[i] = key;
+      fspill[i] = fb[(int)(key & 0xffffffffull) - 1];
+    }
+    if (tid == 0) ndet[frame] = kHeavyFlag | (uint32_t)n;
+    return;
+  }
 
   constexpr int Q = kNmsBlock / 64;  // 64-candidate groups per block
   for (int b0 = 0; b0 < n; b0 += kNmsBlock) {
@@ -239,15 +259,22 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
 #pragma unroll
         for (int q = g; q < Q; q++) any = any || (rlo[g][q] | rhi[g][q]) != 0u;
         const unsigned long long nz = __ballot(any);
-        for (int i = 0; i < cnt; i++) {
-          if (!((d[g] >> i) & 1ull)) {
-            keep[g] |= 1ull << i;
-            if (!((nz >> i) & 1ull)) continue;
-#pragma unroll
-            for (int q = g; q < Q; q++)  // a row only has bits of later candidates
-              d[q] |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rhi[g][q], i) << 32) |
-                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rlo[g][q], i);
+        // everything alive in front of the next survivor with a non-empty row is kept in one step
+        unsigned long long alive = cnt <= 0 ? 0ull : (~d[g] & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull)));  // (m may end before group g)
+        while (alive) {
+          const unsigned long long hot = alive & nz;
+          if (!hot) {
+            keep[g] |= alive;
+            break;
           }
+          const int i = __builtin_ctzll(hot);
+          const unsigned long long upto = (2ull << i) - 1ull;  // bits 0..i
+          keep[g] |= alive & upto;
+#pragma unroll
+          for (int q = g; q < Q; q++)  // a row only has bits of later candidates
+            d[q] |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rhi[g][q], i) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rlo[g][q], i);
+          alive &= ~(upto | d[g]);
         }
       }
       if (lane < Q) s_keep[lane] = keep[lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3))];
@@ -284,6 +311,124 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   if (tid == 0) ndet[frame] = (uint32_t)s_nsel;
 }
 
+// Suppression matrix of a heavy frame: bit j of row i (i < j, sorted order) = "i, once selected,
+// suppresses j".  Block (rb, cg) = 64 rows x 4 column words, one word per wave, lane = row; every
+// test is iou_exceeds(candidate j, selected i), the in-kernel path's call.
+constexpr int kMatColGroups = kMatWords / 4;
+__global__ __launch_bounds__(256) void k_nms_matrix(const uint32_t* __restrict__ ndet, const float4* __restrict__ spill, int K,
+                                                    float max_iou, unsigned long long* __restrict__ mat) {
+  __shared__ float4 s_col[4][64];
+  __shared__ float s_area[4][64];
+  const int frame = blockIdx.z, rb = blockIdx.x, cg = blockIdx.y;
+  const uint32_t flag = ndet[frame];
+  if (!(flag & kHeavyFlag)) return;
+  const int n = (int)(flag & ~kHeavyFlag);
+  if (rb * 64 >= n || cg * 4 + 3 < rb || cg * 256 >= n) return;  // past the end / below the diagonal
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4* fsp = spill + (size_t)frame * K;
+  const int cb = cg * 4 + wave;  // this wave's column word
+  {
+    const int j = min(cb * 64 + lane, n - 1);
+    const float4 b = fsp[j];
+    s_col[wave][lane] = b;
+    s_area[wave][lane] = bbox_area(b.x, b.y, b.z, b.w);
+  }
+  const int i = rb * 64 + lane;
+  const float4 bi = fsp[min(i, n - 1)];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave reads only its own s_col / s_area row
+  if (cb < rb || cb * 64 >= n) return;
+  unsigned long long word = 0ull;
+  const int jn = min(64, n - cb * 64);
+  for (int b = 0; b < jn; b++) {
+    const int j = cb * 64 + b;
+    const bool hit = iou_exceeds(s_col[wave][b], s_area[wave][b], bi, max_iou);  // (wave-uniform j: the ballot inside sees all rows)
+    word |= (hit && j > i) ? (1ull << b) : 0ull;
+  }
+  if (i < n) mat[((size_t)frame * kMatMax + i) * kMatWords + cb] = word;
+}
+
+// Greedy pass over the matrix, exactly the reference's order (nn.rs:198-224): candidate i is
+// selected iff no selected earlier candidate has its bit set.  One wave per frame walks the 64-row
+// blocks; the removed-mask is spread over the lanes (lanes l and l + 32 both hold word l), a block's
+// rows arrive two per load instruction (lane = row parity x word) and are prefetched one block
+// ahead in registers; no LDS, no barrier.
+__global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __restrict__ gkeys, size_t key_stride,
+                                                 const float4* __restrict__ spill, int K, const unsigned long long* __restrict__ mat,
+                                                 Det* __restrict__ dets, uint32_t det_stride, uint32_t* __restrict__ ndet) {
+  static_assert(kMatWords == 32, "lane = (row parity, word) layout");
+  const int frame = blockIdx.x;
+  const uint32_t flag = ndet[frame];
+  if (!(flag & kHeavyFlag)) return;
+  const int n = (int)(flag & ~kHeavyFlag);
+  const int lane = threadIdx.x, half = lane >> 5, word = lane & 31;
+  const int nrb = (n + 63) >> 6;
+  const unsigned long long* fmat = mat + (size_t)frame * kMatMax * kMatWords;
+  const unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
+  const float4* fsp = spill + (size_t)frame * K;
+  Det* fd = dets + (size_t)frame * det_stride;
+  unsigned long long rows[32], rows_next[32], diag, diag_next;
+  // rows 2q + half of block rb, word `word`; the diagonal word of row `lane` (rows past n and words
+  // below the diagonal were never written: loaded from clamped rows and masked where they are used)
+  auto load_block = [&](int rb, unsigned long long (&r)[32], unsigned long long& d) {
+    const int rbc = min(rb, nrb - 1);
+#pragma unroll
+    for (int q = 0; q < 32; q++) r[q] = fmat[(size_t)min(rbc * 64 + 2 * q + half, n - 1) * kMatWords + word];
+    d = fmat[(size_t)min(rbc * 64 + lane, n - 1) * kMatWords + rbc];
+  };
+  load_block(0, rows, diag);
+  unsigned long long removed = 0ull;
+  int nsel = 0;
+  for (int rb = 0; rb < nrb; rb++) {
+    load_block(rb + 1, rows_next, diag_next);
+    const int cnt = min(64, n - rb * 64);
+    const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    const uint32_t rm_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)removed, rb);
+    const uint32_t rm_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(removed >> 32), rb);
+    unsigned long long alive = ~(((unsigned long long)rm_hi << 32) | rm_lo) & valid;
+    const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+    // Only a candidate whose row has bits inside the block can change `alive`: everything alive
+    // in front of the next such candidate is kept in one step (most rows are empty: boxes rarely
+    // overlap), so the serial chain has one iteration per overlapping survivor, not per candidate.
+    const unsigned long long nz = __ballot(diag != 0ull);
+    unsigned long long kept = 0ull;
+    while (alive) {
+      const unsigned long long hot = alive & nz;
+      if (!hot) {
+        kept |= alive;
+        break;
+      }
+      const int b = __builtin_ctzll(hot);
+      const unsigned long long upto = (2ull << b) - 1ull;  // bits 0..b
+      kept |= alive & upto;
+      const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dlo, b);
+      alive &= ~(row | upto);
+    }
+    // the kept rows' later words join the mask
+    const unsigned long long kh = kept >> half;  // bit 2q = row 2q + half
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int q = 0; q < 32; q++) acc |= ((kh >> (2 * q)) & 1ull) ? rows[q] : 0ull;
+    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)acc, 32), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), 32);
+    acc |= ((unsigned long long)ohi << 32) | olo;
+    if (word > rb && word < nrb) removed |= acc;
+    if ((kept >> lane) & 1ull) {
+      const int pos = nsel + __popcll(kept & ((1ull << lane) - 1ull));
+      if ((uint32_t)pos < det_stride) {
+        const float4 cc = fsp[rb * 64 + lane];
+        Det dd;
+        dd.x_tl = cc.x, dd.y_tl = cc.y, dd.x_br = cc.z, dd.y_br = cc.w, dd.conf = key_conf(fkeys[rb * 64 + lane]);
+        fd[pos] = dd;
+      }
+    }
+    nsel += __popcll(kept);
+#pragma unroll
+    for (int q = 0; q < 32; q++) rows[q] = rows_next[q];
+    diag = diag_next;
+  }
+  if (lane == 0) ndet[frame] = (uint32_t)nsel;
+}
+
 }  // namespace
 
 void launch_head_decode(const HeadArgs& h, const float* d_priors, uint32_t B, float min_conf, float* d_scores,
@@ -302,9 +447,17 @@ void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_c
 
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
-                     uint32_t B, hipStream_t s) {
+                     unsigned long long* d_mat, uint32_t B, hipStream_t s) {
+  static const int knob = std::getenv("UFD_NMS_MAT_MIN") ? std::atoi(std::getenv("UFD_NMS_MAT_MIN")) : kMatMin;  // tuning knob
+  const bool use_matrix = d_mat != nullptr && K > (uint32_t)knob;
   hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
-                     d_dets, det_stride, d_ndet, d_sel_spill);
+                     d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : kMatMax);
+  if (!use_matrix) return;
+  // (both return at once for frames the first kernel finished itself)
+  hipLaunchKernelGGL(k_nms_matrix, dim3(kMatWords, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
+  hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(64), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
+                     d_ndet);
 }
+size_t nms_matrix_bytes(uint32_t B) { return (size_t)B * kMatMax * kMatWords * sizeof(unsigned long long); }
 
 }  // namespace ufd

@@ -143,6 +143,37 @@ def test_postproc_exact_on_same_inputs(model320, oracle_lib):
         assert np.array_equal(got, ref), "trial %d differs" % trial
 
 
+@pytest.mark.parametrize("size", [0.02, 0.12, 0.5])
+def test_postproc_many_candidates_matrix_path(model320, oracle_lib, size):
+    """Frames with 257..2048 candidates leave k_sort_nms after the sort (k_nms_matrix + k_nms_scan);
+    lighter and heavier frames of the same batch stay inside it.  Bit-exact selection and order
+    for sparse, dense and mostly-overlapping boxes, confidence ties and zero-area boxes."""
+    rng = np.random.default_rng(int(size * 1000))
+    K = model320.num_priors
+    counts = [257, 2048, 64, 2049, 300, 1000, 1984, 0, 511, 1360, 256, 2047]
+    for b0 in range(0, len(counts), 4):
+        sc, bx = [], []
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            conf = rng.random(K).astype(np.float32) * 0.5
+            hot = rng.permutation(K)[:n]
+            conf[hot] = 0.5 + (1 + rng.random(n).astype(np.float32)) * 0.249
+            if f % 2 == 1:
+                conf[hot] = np.round(conf[hot] * 64) / 64  # many exact ties
+            c = rng.random((K, 2)).astype(np.float32)
+            s = (rng.random((K, 2)).astype(np.float32) * size + 0.01)
+            boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+            boxes[::53, 2] = boxes[::53, 0] - 0.01  # degenerate boxes: zero area
+            sc.append(np.stack([1 - conf, conf], 1).astype(np.float32))
+            bx.append(boxes)
+        got = model320.debug_postproc(np.stack(sc), np.stack(bx))
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            ref = oracle_lib.postproc(sc[f], bx[f], 0.5, 0.5)
+            g = dets_array(got[f])
+            assert int((sc[f][:, 1] > 0.5).sum()) == n
+            assert g.shape == ref.shape, "%d candidates: %d vs %d selected" % (n, len(g), len(ref))
+            assert np.array_equal(g, ref), "%d candidates differ" % n
+
+
 # ---------------------------------------------------------------- end to end
 @pytest.mark.parametrize("variant,src", [(320, (320, 240)), (640, (640, 480)), (640, (1280, 720)), (320, (1280, 720)),
                                          (640, (640, 427))])
