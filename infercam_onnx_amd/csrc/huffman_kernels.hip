@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
 // The lanes of a block decode neighbouring subsequences: their part of the stream is staged in LDS
 // with coalesced loads first.  (Per-lane global loads of one word at a time made every refill of the
 // bit window a ~1-2 us round trip: 16 of them in a row dominated the pass.)
-constexpr uint32_t kStageWords = 8192 + 16;
+constexpr uint32_t kStageWords = 2048 + 16;  // 8 KB: a block of k_huff_seed spans 43 subsequences (2.7 KB at 64 bytes each); longer spans read the stream from global memory.  With the 18.6 KB of tables five blocks fit a CU -- at 32 KB of staging three did, k_huff_extend ran in two rounds and the blocks kept the convolutions of the other contexts off the CU's LDS (43.2 k -> 44.7 k frames/s)
 
 // Stages the words of subsequences [i_lo, i_hi] plus the look-ahead tail; returns the pointer p with
 // p[w] = word w of the stream (nullptr: the range does not fit, read global memory instead).

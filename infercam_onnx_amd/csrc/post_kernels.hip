@@ -14,9 +14,10 @@ namespace {
 
 constexpr float kEps = 1.0e-7f;           // nn.rs:18
 constexpr int kSortLds = 2048;            // keys sorted inside LDS up to this many candidates (more: sorted in HBM)
-constexpr int kSelLds = 2048;             // selected boxes kept in LDS; the rest spill to HBM (a dependent global
-                                          // read per comparison: frames with > 1024 selected boxes took 600 us)
-constexpr int kBoxLds = 512;              // sorted candidate boxes gathered per round trip (power of two, <= block size)
+constexpr int kSelLds = 512;              // selected boxes kept in LDS; the rest spill to HBM (only frames with more than
+                                          // kMatMax candidates get there: the others have at most kNmsBlock or leave for
+                                          // the matrix path).  LDS is what keeps other kernels off the frame's CU: 40 KB, not 68
+constexpr int kBoxLds = 256;              // sorted candidate boxes gathered per round trip (power of two, <= block size)
 constexpr int kNmsBlock = 256;            // candidates per greedy block (4 x 64-bit suppression masks per row)
 // Frames with more candidates than one greedy block (and at most kMatMax) leave k_sort_nms after the
 // sort: their pairwise suppression matrix is computed by the whole GPU (k_nms_matrix) and resolved
