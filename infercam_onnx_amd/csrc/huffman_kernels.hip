@@ -49,16 +49,20 @@ struct SyncState {
   uint32_t cz;  // block inside the MCU | zigzag position << 8
 };
 
-struct SyncTables {
-  // (the first two members mirror SyncLutImage: copied from the prebuilt per-table-set image)
-  HuffLut lut[4];
-  uint16_t step[4][1024];  // state-only form of lut[].fast: bits consumed (code + magnitude) | zigzag advance << 5
+template <bool kWrite>
+struct SyncTablesT {
+  // (head and table: copied from the prebuilt per-table-set image, load_sync_tables)
+  HuffSlow slow[4];
+  uint16_t tab[4][1024];   // state-only passes: bits consumed (code + magnitude) | zigzag advance << 5 (SyncLutImage::step);
+                           // write pass: (code length << 8) | symbol (SyncLutImage::fast); 0 = code longer than 10 bits
   uint32_t blk[12];        // per block of the MCU: comp | bx << 8 | by << 12 | dc << 16 | ac << 20
   uint32_t dc_bits, ac_bits;  // bit c = table slot (0/1) of block c of the MCU
   // coefficient offset of block c of MCU (mx, my): blk_base[c] + mx * blk_dx[c] + my * blk_dy[c]
   uint32_t blk_base[12], blk_dx[12], blk_dy[12];
   int mcux;
 };
+using SyncTables = SyncTablesT<false>;
+using WriteTables = SyncTablesT<true>;
 
 // Bit window over the unstuffed stream: n valid bits at the top of acc, one aligned word in flight.
 struct BitWindow {
@@ -94,7 +98,7 @@ struct BitWindow {
 // search over the lengths is not a serial loop of dependent LDS reads: maxcode[l] (exclusive bound
 // of the code space used by lengths <= l, left-justified) grows with l, hence
 // length = 11 + #{l in 11..16 : code >= maxcode[l]}, with all bounds and offsets read at once.
-__device__ __forceinline__ int slow_symbol(const HuffLut& t, uint32_t top) {
+__device__ __forceinline__ int slow_symbol(const HuffSlow& t, uint32_t top) {
   const int code = (int)(top >> 16);
   int mc[6], dl[6];
 #pragma unroll
@@ -122,9 +126,9 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
   while (pos < limit) {
     bw.refill();
     const uint32_t top = bw.top();
-    uint32_t e = T.step[cur_t][top >> 22];
+    uint32_t e = T.tab[cur_t][top >> 22];
     if (__builtin_expect(e == 0, 0)) {
-      const int ls = slow_symbol(T.lut[cur_t], top);
+      const int ls = slow_symbol(T.slow[cur_t], top);
       // no code word (only reachable out of step or on corrupt data): consume one bit as EOB
       e = ls ? (uint32_t)sync_step(ls >> 8, ls & 0xFF, cur_t < 2) : (uint32_t)sync_step(1, 0, cur_t < 2);
     }
@@ -149,7 +153,7 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
 // Same walk from the true entry state, storing the coefficients: AC in ZIGZAG order (the IDCT
 // kernel undoes it), DC as differences (k_dc_prefix sums them).  Zero coefficients are not stored
 // (the slab is pre-zeroed).
-__device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, uint32_t limit, const SyncTables& T, int bpm,
+__device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, uint32_t limit, const WriteTables& T, int bpm,
                                            int16_t* fcoef, int mcu, int total_mcus, bool* bad) {
   uint32_t pos = st.p;
   int c = (int)(st.cz & 0xFF), z = (int)(st.cz >> 8);
@@ -163,9 +167,9 @@ __device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, 
   while (pos < limit) {
     bw.refill();
     const uint32_t top = bw.top();
-    int e = T.lut[cur_t].fast[top >> 22];
+    int e = T.tab[cur_t][top >> 22];
     if (__builtin_expect(e == 0, 0)) {
-      e = slow_symbol(T.lut[cur_t], top);
+      e = slow_symbol(T.slow[cur_t], top);
       if (!e) e = 1 << 8, *bad = true;
     }
     const int len = e >> 8, sz = e & 15, run = (e >> 4) & 15;
@@ -228,27 +232,34 @@ constexpr int kSyncLaneThreads = 256;  // seed / extend / write: one lane per (s
 constexpr int kHypSlots = 16;          // cached (entry -> exit) pairs per subsequence; nibble 15 = "not cached"
 constexpr int kHypAppendMax = 14;      // the speculation rounds fill slots 0..13, k_huff_resolve may use 14
 
-static_assert(sizeof(SyncLutImage) % 16 == 0 && offsetof(SyncTables, blk) == sizeof(SyncLutImage), "image layout");
+static_assert(sizeof(HuffSlow) % 16 == 0 && offsetof(SyncLutImage, step) == 4 * sizeof(HuffSlow) &&
+                  offsetof(SyncLutImage, fast) == offsetof(SyncLutImage, step) + sizeof(SyncLutImage::step) &&
+                  offsetof(SyncTables, tab) == offsetof(SyncLutImage, step) && offsetof(SyncTables, blk) == offsetof(SyncLutImage, fast),
+              "image layout");
 
-// Fills the block's tables: the table-set image with wide loads that are all in flight at once
-// (a load -> store loop pays one memory round trip per iteration), the per-frame layout from the
-// scan and frame descriptors.
-__device__ __forceinline__ void load_sync_tables(SyncTables& T, const HuffScan& sc, const SyncLutImage* __restrict__ images,
+// Fills the block's tables: the head of the table-set image and its step (or symbol) tables with
+// wide loads that are all in flight at once (a load -> store loop pays one memory round trip per
+// iteration), the per-frame layout from the scan and frame descriptors.
+template <bool kWrite>
+__device__ __forceinline__ void load_sync_tables(SyncTablesT<kWrite>& T, const HuffScan& sc, const SyncLutImage* __restrict__ images,
                                                  const JpegFrameDesc* d, int tid, int nthreads) {
-  constexpr int kVec = (int)(sizeof(SyncLutImage) / 16);
+  constexpr int kHead = (int)(offsetof(SyncLutImage, step) / 16), kVec = (int)(offsetof(SyncLutImage, fast) / 16);
+  constexpr int kSkip = kWrite ? (int)(sizeof(SyncLutImage::step) / 16) : 0;  // the write pass takes `fast` in place of `step`
   const uint4* src = reinterpret_cast<const uint4*>(images + sc.lut_base / 4);
   uint4* dst = reinterpret_cast<uint4*>(&T);
   if (nthreads == kSyncLaneThreads) {
     constexpr int kPer = (kVec + kSyncLaneThreads - 1) / kSyncLaneThreads;
     uint4 r[kPer];
 #pragma unroll
-    for (int q = 0; q < kPer; q++)
-      if (tid + q * kSyncLaneThreads < kVec) r[q] = src[tid + q * kSyncLaneThreads];
+    for (int q = 0; q < kPer; q++) {
+      const int i = tid + q * kSyncLaneThreads;
+      if (i < kVec) r[q] = src[i < kHead ? i : i + kSkip];
+    }
 #pragma unroll
     for (int q = 0; q < kPer; q++)
       if (tid + q * kSyncLaneThreads < kVec) dst[tid + q * kSyncLaneThreads] = r[q];
   } else {
-    for (int i = tid; i < kVec; i += nthreads) dst[i] = src[i];
+    for (int i = tid; i < kVec; i += nthreads) dst[i] = src[i < kHead ? i : i + kSkip];
   }
   if (tid < 12) {
     T.blk[tid] = sc.blk_comp[tid] | (sc.blk_bx[tid] << 8) | (sc.blk_by[tid] << 12) | (sc.blk_dc[tid] << 16) |
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
                                                                  const JpegFrameDesc* __restrict__ descs, SyncBuffers sb,
                                                                  int16_t* __restrict__ coef, size_t coef_stride,
                                                                  uint32_t* __restrict__ status) {
-  __shared__ SyncTables T;
+  __shared__ WriteTables T;
   __shared__ uint32_t s_stream[kStageWords];
   const int frame = blockIdx.y, tid = threadIdx.x;
   const SyncFrame fr = sb.frames[frame];

@@ -30,9 +30,20 @@ void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes,
 // Per table set: the four lookup tables plus their state-only form (bits consumed by code word and
 // magnitude | zigzag advance << 5; 0 = code word longer than the lookup).  Built on the host when a
 // new table set is first seen (build_sync_lut_image), copied to LDS by every decoding block.
+// Table set of a frame as the entropy kernels copy it to LDS: the long-code search data of the four
+// tables, then their state-only step tables (seed / extend / resolve) and their symbol tables (write)
+// -- a kernel takes the head and ONE of the two, 9.6 KB instead of 17.6 (LDS is what keeps the
+// convolutions of the other contexts off a CU while these latency-bound kernels sit on it).
+struct HuffSlow {
+  int32_t maxcode[18];  // as HuffLut
+  int32_t delta[17];
+  uint8_t sym[256];
+  int32_t pad;
+};
 struct SyncLutImage {
-  HuffLut lut[4];
+  HuffSlow slow[4];
   uint16_t step[4][1024];
+  uint16_t fast[4][1024];
 };
 // State-only step of a symbol.  A DC symbol advances the zigzag index 0 -> 1, an AC coefficient by
 // run + 1, ZRL by 16 and EOB to 64, so the decoder state update is "z += dz" for all of them.
@@ -43,9 +54,13 @@ __host__ __device__ inline uint16_t sync_step(int len, int sym, bool is_dc) {
 }
 inline void build_sync_lut_image(const HuffLut* luts /*[4]: dc0 dc1 ac0 ac1*/, SyncLutImage* out) {
   for (int t = 0; t < 4; t++) {
-    out->lut[t] = luts[t];
+    for (int i = 0; i < 18; i++) out->slow[t].maxcode[i] = luts[t].maxcode[i];
+    for (int i = 0; i < 17; i++) out->slow[t].delta[i] = luts[t].delta[i];
+    for (int i = 0; i < 256; i++) out->slow[t].sym[i] = luts[t].sym[i];
+    out->slow[t].pad = 0;
     for (int i = 0; i < 1024; i++) {
       const int e = luts[t].fast[i];
+      out->fast[t][i] = (uint16_t)e;
       out->step[t][i] = e ? sync_step(e >> 8, e & 0xFF, t < 2) : (uint16_t)0;
     }
   }
