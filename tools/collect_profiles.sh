@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 timeout 600 python3 bench.py --steps 80 --warmup 8 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-variants > $out/bench_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-variants --profile-every 1 > $out/bench_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --depth 1 --no-cpu-baseline --no-variants --pool 64 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --depth 1 --no-cpu-baseline --no-variants --pool 64 > /dev/null 2>&1
 find $out -name "*.csv" < /dev/null | head -20
