@@ -207,7 +207,9 @@ def main():
         d = kern[dom]
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv3x3_mfma", "conv3x3_rows_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+        # (the roof the kernel sits closer to; on gfx950 fp32 MFMA and fp32 vector work share one datapath)
+        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "stem_planes_mfma", "conv3x3_mfma",
+                   "conv3x3_rows_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
             roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
         else:
@@ -221,6 +223,8 @@ def main():
             pass
         per_launch = d["bytes"] / max(d["launches"], 1)
         roof.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(per_launch),
+                     "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
+                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                      "kernel": KERNEL_FUNCS.get(dom, dom),
                      "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
         gpu_ms = sum(v["ms"] for v in kern.values())
