@@ -6,11 +6,18 @@ One "step" = one pass of the hot path over one batch of 32 synthetic 640x480 cam
 streams shard one-per-GPU ("weak" scaling) and the only collective is the start-up RCCL
 broadcast of the weight blob.  Prints ONE JSON line on rank 0.
 
+The timed region is the reference's own boundary (inferer.rs:35-37): JPEG bytes in host memory
+-> detections in host memory, PCIe included (`--input host`, the default).  `--input hbm` times
+the same path with the JPEG bytes staged in HBM before the clock starts; at N=1 the default run
+reports that figure too (`config.hbm_resident_fps`).
+
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -39,12 +46,26 @@ KERNEL_FUNCS = {
     "upsample_rgb": "k_upsample_rgb",
     "resize_norm": "k_resize_norm",
     "head_decode": "k_head_decode",
-    "huffman_rst": "k_huffman_rst",
     "huff_unstuff": "k_huff_unstuff", "huff_seed": "k_huff_seed", "huff_extend": "k_huff_extend", "huff_link": "k_huff_link",
     "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
     "conv_dwpw_coop": "k_dwpw_coop", "stem_planes_mfma": "k_stem_planes_mfma",
     "sort_nms": "k_sort_nms",
 }
+MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "stem_planes_mfma", "conv3x3_mfma",
+                "conv3x3_rows_mfma")
+
+
+def stage_of(label):
+    """Stage of SURVEY 8(d)'s breakdown a profiled kernel label belongs to."""
+    if label.startswith("h2d_"):
+        return "h2d"
+    if label.startswith("huff_") or label in ("dc_prefix", "zero_coef"):
+        return "entropy"
+    if label in ("idct", "upsample_norm", "upsample_norm_420", "upsample_rgb", "resize_norm"):
+        return "idct_preproc"
+    if label in ("head_decode", "sort_nms"):
+        return "post"
+    return "cnn"  # (the fused stem -- upsampling + colour + normalise + conv 0 -- counts as CNN)
 
 
 def parse_args():
@@ -55,29 +76,32 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
-    ap.add_argument("--input", choices=["hbm", "host"], default="hbm",
-                    help="hbm: the JPEG bytes of every batch are staged in HBM before the clock starts "
-                         "(ufd_stage_jpeg_batch / ufd_submit_staged; implies --entropy device); "
-                         "host: the timed region starts from host buffers (PCIe-inclusive)")
+    ap.add_argument("--input", choices=["host", "hbm"], default="host",
+                    help="host: the timed region starts from JPEG bytes in host memory (the reference's boundary, PCIe "
+                         "included); hbm: the JPEG bytes of every batch are staged in HBM before the clock starts "
+                         "(ufd_stage_jpeg_batch / ufd_submit_staged)")
     ap.add_argument("--entropy", choices=["host", "device"], default="device",
                     help="where the Huffman stage runs (device: self-synchronising decoder kernels; "
                          "host: worker threads, coefficient slabs over PCIe)")
     ap.add_argument("--variant", type=int, choices=[640, 320], default=640, help="UltraFace variant (BASELINE C1/C2: 320)")
     ap.add_argument("--src", default=None, help="frame size of the synthetic stream (BASELINE config C5: 1280x720, --batch 16)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the PCIe-inclusive comparison runs")
-    ap.add_argument("--restart-rows", type=int, default=0,
-                    help="JPEG restart interval in MCU rows (0 = none: entropy decoding on host workers; "
-                         ">0: restart-interval stream, entropy decoding on the GPU)")
-    ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-extras", "--no-variants", dest="no_extras", action="store_true",
+                    help="skip the side measurements (other boundary, stage breakdown, batch-1 latency, verification)")
+    ap.add_argument("--restart-rows", type=int, default=0, help="JPEG restart interval in MCU rows (0 = none)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host workers of the handle (0: hardware threads / ranks, <= 32)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=4, help="record kernel events for every n-th timed step")
+    ap.add_argument("--profile-every", type=int, default=8, help="record kernel events for every n-th timed step (0: never)")
     return ap.parse_args()
 
 
 def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
-    """The CPU oracle (oracle/, a single-threaded plain-C port of the reference path) timed on
-    this host on a bounded sample of the same frames."""
+    """The CPU oracle (oracle/, a plain-C port of the reference path; the reference's own tract-onnx
+    path cannot be built here) timed on this host on a bounded sample of the bench's frames:
+    (a) one thread -- the reference's operating point is a single Inferer task (infer_server.rs:48-50);
+    (b) one worker per hardware thread, frames being independent."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import oracle
 
     oracle.build()
@@ -89,8 +113,27 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 4 * len(jpegs):
             break
-    return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el)}
+    one = n / el
+    cores = os.cpu_count() or 1
+    # all cores: each worker runs whole frames (ctypes releases the GIL inside the C call)
+    per_worker = max(2, int(one * budget_s * 0.8))
+    jobs = [jpegs[i % len(jpegs)] for i in range(per_worker * cores)]
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jobs))
+    el_all = time.perf_counter() - t1
+    return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el),
+            "all_cores": {"value": round(len(jobs) / el_all, 2), "unit": "frames/s", "cores": cores,
+                          "sample": "%d frames, one worker thread per hardware thread, %.1f s" % (len(jobs), el_all)}}
+
+
+def kernel_source_sha():
+    """Hash of the kernel sources: a PMC traffic figure is only reported for the code it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "infercam_onnx_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -98,6 +141,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run --nproc-per-node N"
+                         % (args.gpus, world))
     import torch
 
     dist = None
@@ -106,38 +152,47 @@ def main():
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, "RCCL formed %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     from infercam_onnx_amd import nn, parallel, synth
 
     W, H, B = (640, 480, args.batch) if args.variant == 640 else (320, 240, args.batch)
     variant = nn.UltrafaceVariant.W640H480 if args.variant == 640 else nn.UltrafaceVariant.W320H240
     # ---- weights: generated on rank 0, broadcast over RCCL (the path's only collective)
-    weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist,
-                                         device=torch.device("cuda", local_rank))
+    weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist, device=dev)
     priors = synth.gen_priors(W, H)
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
     SW, SH = (int(v) for v in args.src.lower().split("x")) if args.src else (W, H)
     jpegs = synth.synth_jpeg_pool(rank, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
-    device_entropy = args.entropy == "device" or args.input == "hbm"
-    model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B,
-                              weights=weights, priors=priors, max_src=(SW, SH), host_threads=args.host_threads,
-                              profile=True, det_cap=256, host_entropy=not device_entropy)
+    device_entropy = args.entropy == "device"
+    if args.input == "hbm" and not device_entropy:
+        raise SystemExit("--input hbm needs the device entropy decoder")
+    # host workers: this rank's share of the box (8 ranks must not oversubscribe it)
+    host_threads = args.host_threads or max(2, min(32, (os.cpu_count() or 8) // world))
+    model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights, priors=priors,
+                              max_src=(SW, SH), host_threads=host_threads, profile=True, det_cap=256,
+                              host_entropy=not device_entropy)
     nb = max(1, args.pool // B)
-    if args.input == "hbm":
-        # inputs resident in HBM before the clock starts: bytes + parsed headers of every batch
-        batches = [model.stage_jpeg_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
-    else:
-        batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
-    depth = min(args.depth, nb) if args.input == "hbm" else args.depth  # a staged batch is in flight once at a time
+    host_batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+    staged_batches = None
 
-    def run_steps(k, mdl=None, bts=None, staged=None):
+    def get_batches(staged):
+        nonlocal staged_batches
+        if not staged:
+            return host_batches
+        if staged_batches is None:  # bytes + parsed headers of every batch resident in HBM
+            staged_batches = [model.stage_jpeg_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
+        return staged_batches
+
+    def run_steps(k, staged, depth=None, mdl=None, bts=None):
         mdl = mdl or model
-        bts = bts or batches
-        staged = (args.input == "hbm") if staged is None else staged
+        bts = bts or get_batches(staged)
+        depth = min(depth or args.depth, len(bts))  # a batch object (its output arrays) is in flight once at a time
         inflight = []
         dets = 0
         for s in range(k):
@@ -156,78 +211,152 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
+    primary_staged = args.input == "hbm"
+    get_batches(primary_staged)
+    run_steps(args.warmup, primary_staged)
     model.profile_reset()
-    model.profile_sampling(args.profile_every)
+    model.profile_sampling(args.profile_every if args.profile_every > 0 else 1 << 30)
     barrier()
     t0 = time.perf_counter()
-    ndet = run_steps(args.steps)
+    ndet = run_steps(args.steps, primary_staged)
+    torch.cuda.synchronize()
+    el_local = time.perf_counter() - t0
     barrier()
     el = time.perf_counter() - t0
-    el = parallel.max_over_ranks(el, dist, device=torch.device("cuda", local_rank))
+    el = parallel.max_over_ranks(el, dist, device=dev)
     stats = model.profile_read()
+    prof_steps = max(1, (args.steps + args.profile_every - 1) // args.profile_every) if args.profile_every > 0 else 0
 
-    # ---- the same workload over the reference's own boundary (host buffers in, PCIe inside the
-    # timed region): reported beside `value`, never as `value`
-    variants = {}
-    if world == 1 and args.input == "hbm" and not args.no_variants:
-        hb = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
-        run_steps(args.warmup, bts=hb, staged=False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(args.steps, bts=hb, staged=False)
-        torch.cuda.synchronize()
-        variants["host_bytes_device_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
-        m2 = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights,
-                               priors=priors, max_src=(SW, SH), host_threads=args.host_threads, det_cap=256,
-                               host_entropy=True)
-        hb2 = [m2._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
-        run_steps(args.warmup, mdl=m2, bts=hb2, staged=False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(args.steps, mdl=m2, bts=hb2, staged=False)
-        torch.cuda.synchronize()
-        variants["host_bytes_host_entropy_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
-        m2.close()
+    # ---- per-rank record: which device each rank ran on and what it did alone
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = torch.tensor([rank, local_rank, B * args.steps / el_local, getattr(props, "pci_bus_id", -1),
+                         getattr(props, "pci_device_id", -1)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    ranks = [{"rank": int(t[0]), "local_rank": int(t[1]), "fps": round(float(t[2]), 1),
+              "pci": "%02x:%02x" % (int(t[3]), int(t[4]))} for t in (x.cpu() for x in allr)]
+    if dist is not None:
+        assert len({r["pci"] for r in ranks}) == world or ranks[0]["pci"] == "-1:-1", "two ranks share a GPU: %s" % ranks
+
+    def aggregate(st):
+        agg = {}
+        for s in st:
+            key = s["name"].split(":")[0]
+            a = agg.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            a["ms"] += s["total_ms"]
+            a["launches"] += s["launches"]
+            a["bytes"] += s["bytes"]
+            a["flops"] += s["flops"]
+        return agg
+
+    def stage_ms(st, steps):
+        out = {}
+        for k, v in aggregate(st).items():
+            out[stage_of(k)] = out.get(stage_of(k), 0.0) + v["ms"] / steps
+        return out
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # ---- the same workload over the other boundary
+        if device_entropy:
+            other = not primary_staged
+            run_steps(args.warmup, other)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps, other)
+            torch.cuda.synchronize()
+            extras["hbm_resident_fps" if other else "host_boundary_fps"] = round(B * args.steps / (time.perf_counter() - t1), 1)
+        # ---- stage breakdown: device time per batch, every kernel timed (HIP events on the library's
+        # streams), with the pipeline loaded (depth batches in flight over the contexts) and alone (one batch in flight)
+        sb = {}
+        for name, depth, k in (("loaded", args.depth, 24), ("alone", 1, 12)):
+            model.profile_sampling(1)
+            run_steps(3, primary_staged, depth=depth)
+            model.profile_reset()
+            run_steps(k, primary_staged, depth=depth)
+            for stg, ms in stage_ms(model.profile_read(), k).items():
+                sb.setdefault(stg, {})[name + "_ms"] = round(ms, 4)
+        extras["stages"] = sb
+        model.profile_sampling(1 << 30)
+        # ---- per-frame latency at batch 1, one frame in flight, host bytes -> host detections
+        lat = []
+        for i in range(60):
+            j = jpegs[i % len(jpegs)]
+            t1 = time.perf_counter()
+            model.infer_jpeg(j)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = sorted(lat[10:])
+        extras["latency_ms_batch1"] = {"median": round(lat[len(lat) // 2], 3), "p90": round(lat[int(len(lat) * 0.9)], 3),
+                                       "what": "ufd_infer_jpeg, one %dx%d frame at a time, host bytes -> host detections" % (SW, SH)}
+
+    verified = None
+    if rank == 0 and not args.no_extras:
+        # ---- after the clock: detections of the batches just timed vs the CPU oracle
+        from concurrent.futures import ThreadPoolExecutor
+
+        import oracle
+
+        oracle.build()
+        nver = min(2, nb)
+        bts = get_batches(primary_staged)[:nver]
+        tickets = [(model.submit_staged(b) if primary_staged else model.submit_jpeg_batch(b)) for b in bts]
+        got = []
+        for t, b in zip(tickets, bts):
+            model.wait(t, collect=False)
+            arr = np.frombuffer(b.out, np.float32).reshape(b.count, model.det_cap, 5)
+            got += [(arr[i, :min(b.cnt[i], model.det_cap)].copy(), int(b.cnt[i])) for i in range(b.count)]
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+            refs = list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jpegs[:nver * B]))
+        max_err, bad = 0.0, 0
+        for (g, n), r in zip(got, refs):
+            if n != len(r):
+                bad += 1
+                continue
+            r = r[:len(g)]
+            if len(g):
+                max_err = max(max_err, float(np.abs(g - r).max()))
+        verified = {"frames": len(got), "max_abs_err": max_err, "count_mismatch_frames": bad,
+                    "against": "CPU oracle (oracle/) on the same JPEG bytes, every detection of every frame; tolerance 1e-3 (north_star)"}
+        if max_err > 1e-3 or bad > max(1, len(got) // 50):
+            raise SystemExit("bench.py: detections differ from the CPU oracle: %s" % verified)
 
     if rank == 0:
         frames = world * B * args.steps
-        prof_steps = (args.steps + args.profile_every - 1) // args.profile_every  # steps that carried events
-        # ---- roofline of the dominant kernel (device time from HIP events on the library's stream)
-        agg = {}
-        for st in stats:
-            key = st["name"].split(":")[0]
-            a = agg.setdefault(key, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
-            a["ms"] += st["total_ms"]
-            a["launches"] += st["launches"]
-            a["bytes"] += st["bytes"]
-            a["flops"] += st["flops"]
+        # ---- roofline of the dominant kernel (device time from HIP events on the library's streams,
+        # sampled over the timed region)
+        agg = aggregate(stats)
         kern = {k: v for k, v in agg.items() if not k.startswith("h2d_")}
-        dom = max(kern, key=lambda k: kern[k]["ms"])
-        d = kern[dom]
-        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        # (the roof the kernel sits closer to; on gfx950 fp32 MFMA and fp32 vector work share one datapath)
-        if dom in ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "stem_planes_mfma", "conv3x3_mfma",
-                   "conv3x3_rows_mfma") and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
-            roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
-        else:
-            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        traffic = None
-        try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))["kernels"]
-            traffic = round(pmc[KERNEL_FUNCS.get(dom, dom)]["hbm_bytes_per_launch"])
-        except Exception:
-            pass
-        per_launch = d["bytes"] / max(d["launches"], 1)
-        roof.update({"traffic": traffic, "algorithmic_bytes_per_launch": round(per_launch),
-                     "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
-                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
-                     "kernel": KERNEL_FUNCS.get(dom, dom),
-                     "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
-        gpu_ms = sum(v["ms"] for v in kern.values())
+        roof = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["ms"])
+            d = kern[dom]
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            # (the roof the kernel sits closer to; on gfx950 fp32 MFMA and fp32 vector work share one datapath)
+            if dom in MFMA_KERNELS and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+                roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
+            else:
+                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            traffic, traffic_src = None, "not measured for this build of the kernels (tools/collect_profiles.sh refreshes it)"
+            try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+                if pmc.get("kernel_source_sha") == kernel_source_sha():
+                    traffic = round(pmc["kernels"][KERNEL_FUNCS.get(dom, dom)]["hbm_bytes_per_launch"])
+                    traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) at commit %s, same kernel sources" % pmc.get("commit", "?")
+            except Exception:
+                pass
+            per_launch = d["bytes"] / max(d["launches"], 1)
+            roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(per_launch),
+                         "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
+                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                         "kernel": KERNEL_FUNCS.get(dom, dom),
+                         "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
+        flops_frame = 798315520 if args.variant == 640 else 200837120  # 2 x MACs of the 52 convs
         out = {
             "metric": "frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, W, H),
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -240,22 +369,35 @@ def main():
                        "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
                        "entropy_decode": "GPU kernels" if device_entropy else "host worker threads",
                        "timed_region": ("JPEG bytes resident in HBM (headers parsed at staging) -> detections in host memory"
-                                        if args.input == "hbm" else
+                                        if primary_staged else
                                         "host JPEG bytes -> host detections (%s + PCIe included)" % (
-                                            "JPEG bytes H2D" if device_entropy else "host Huffman, coefficient slabs H2D")),
-                       "async_depth": depth, "pcie_inclusive": variants or None},
+                                            "header scan, JPEG bytes H2D" if device_entropy else "host Huffman, coefficient slabs H2D")),
+                       "async_depth": min(args.depth, nb), "host_threads_per_rank": host_threads, "ranks": ranks},
             "roofline": roof,
-            "gpu_ms_per_step": round(gpu_ms / prof_steps, 3),
-            "kernels_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+            "whole_net_mfma_frac": round(frames / el * flops_frame / 1e12 / MFMA_F32_PEAK_TFLOPS / world, 4),
             "detections_per_frame": round(ndet / (B * args.steps), 2),
         }
+        out["config"].update({k: v for k, v in extras.items() if k.endswith("_fps")})
+        if "stages" in extras:
+            out["stages"] = extras["stages"]
+        if "latency_ms_batch1" in extras:
+            out["latency_ms_batch1"] = extras["latency_ms_batch1"]
+        if verified is not None:
+            out["verified"] = verified
+        if prof_steps:
+            gpu_ms = sum(v["ms"] for v in kern.values())
+            out["gpu_ms_per_step"] = round(gpu_ms / prof_steps, 3)
+            out["kernels_ms_per_step"] = {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         dump = os.environ.get("UFD_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:
                 json.dump({"steps": prof_steps, "batch": B, "stats": stats}, f, indent=1)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H)
         print(json.dumps(out), flush=True)
+    if staged_batches:
+        for b in staged_batches:
+            model.free_staged(b)
     model.close()
     if dist is not None:
         dist.barrier()

@@ -78,6 +78,11 @@ typedef struct ufd_config {
  * handle's host worker threads. */
 #define UFD_FLAG_DEVICE_ENTROPY 4u /* accepted for compatibility: the GPU entropy kernels are the default */
 #define UFD_FLAG_HOST_ENTROPY 8u   /* never use the GPU entropy kernels */
+/* Parity-test instruments (no effect on results beyond what each says): */
+#define UFD_FLAG_TAP_LAYERS 16u    /* the issued (fused) plan, plus a copy of every tensor it writes for ufd_debug_layer_output */
+#define UFD_FLAG_NO_CHAIN 32u      /* m1->m2 / m3->m4 as two launches each instead of the chained kernel */
+#define UFD_FLAG_NO_RFB_SUM 64u    /* ConvLinear and shortcut of the RFB block as two convs instead of one summed conv */
+#define UFD_FLAG_NO_STEM_FUSE 128u /* upsample/colour/normalise kernel + stem conv instead of the stem reading the sample planes */
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
@@ -144,7 +149,9 @@ int ufd_debug_preproc_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t
 /* A6 only: `count` pre-normalised inputs [count][3][H][W] -> scores [count][K][2], boxes [count][K][4]. */
 int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, float* scores, float* boxes);
 /* Output of conv `layer` (0..51, post activation; 24 = RFB block output) for frame `frame` of the
- * last forward; needs UFD_FLAG_KEEP_LAYERS.  *floats = cout*oh*ow. */
+ * last forward.  UFD_FLAG_KEEP_LAYERS: the unfused plan, every layer available.  UFD_FLAG_TAP_LAYERS:
+ * the plan the product issues; layers whose output is fused into the next launch (depthwise
+ * convs, m1.pw, m3.pw, rfb.linear) return UFD_E_STATE.  *floats = cout*oh*ow. */
 int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats,
                            size_t* floats);
 /* A7-A10 only: threshold + sort + NMS on caller-provided raw outputs of `count` frames. */

@@ -1353,9 +1353,7 @@ bool dwpw_supported(const ConvArgs& a, int stride) {
 // launchers use CT = 1: activations of wider layers are re-read per cout tile from L2.
 // Split-K when a launch would have fewer wave tiles than ~2 per SIMD.
 static bool want_splitk(long wave_tiles, int cts, int ksteps) {
-  static const int knob = std::getenv("UFD_SPLITK") ? std::atoi(std::getenv("UFD_SPLITK")) : -1;  // tuning knob
   if (ksteps % 16 != 0) return false;
-  if (knob >= 0) return knob != 0 && wave_tiles * cts < (long)knob;
   // measured on MI355X at batch 32: pays when the launch has fewer than ~6 waves per k-step of
   // chain length (15x20 maps, 64->4/8 heads at 30x40, the 256-channel layers); costs otherwise
   return wave_tiles * cts < 6L * ksteps;
@@ -1398,10 +1396,9 @@ void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
 }
 
 bool dwpw_uses_coop(const ConvArgs* args, int n) {
-  // (4 cout tiles per block; the 2-tile form measured slower than k_dwpw_mfma -- UFD_COOP=2 selects it, 0 disables)
-  static const int coop_knob = std::getenv("UFD_COOP") ? std::atoi(std::getenv("UFD_COOP")) : 1;
+  // (4 cout tiles per block; the 2-tile form measured slower than k_dwpw_mfma)
   const int cts = (args[0].cout + 31) / 32, ksteps = args[0].cin >> 1;
-  return coop_knob && n == 1 && ksteps % 8 == 0 && (coop_knob == 2 ? cts % 2 == 0 : cts % 4 == 0);
+  return n == 1 && ksteps % 8 == 0 && cts % 4 == 0;
 }
 
 void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t s) {

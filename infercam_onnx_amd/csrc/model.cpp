@@ -79,6 +79,7 @@ struct Layer {
   const float* d_b_sum = nullptr;
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
+  int tap_tensor = -1, tap_coff = 0;  // where this layer's output lives in the issued plan (-1: it never exists)
 };
 
 struct ProfEntry {
@@ -93,6 +94,7 @@ struct Slot {
   JpegFrameDesc* h_descs = nullptr;
   int16_t* h_coef = nullptr;
   Det* h_dets = nullptr;
+  Det* d_dets = nullptr;  // [B][K] detections of this slot's batch: stays valid until the slot is released (tail reads at ufd_wait)
   uint32_t* h_ndet = nullptr;
   uint32_t* h_gpu_status = nullptr;  // per frame: device entropy decoder flagged a corrupt stream
   uint8_t* h_blob = nullptr;        // pinned staging of the batch's JPEG bytes
@@ -134,8 +136,6 @@ struct Worker {
 struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
-  hipStream_t aux[2] = {nullptr, nullptr};  // side streams for independent branches (RFB branches, cls / reg heads)
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float* d_arena = nullptr;
   float* d_input = nullptr;
   JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
@@ -157,7 +157,6 @@ struct Ctx {
   float* d_boxes = nullptr;
   unsigned long long* d_keys = nullptr;
   uint32_t* d_counts = nullptr;
-  Det* d_dets = nullptr;
   uint32_t* d_ndet = nullptr;
   float4* d_spill = nullptr;
   unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
@@ -188,7 +187,7 @@ struct ufd_model {
   uint32_t max_w = 0, max_h = 0;
   Ctx ctx[kMaxCtx];
   Worker workers[kMaxCtx];
-  int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s (tools/hwq_probe.sh); each has its own stream
+  int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s; each has its own stream pair
   int next_ctx = 0;
   std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
   std::mutex err_mu;     // error string
@@ -217,8 +216,7 @@ struct ufd_model {
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
-  bool branch_streams = false;
-  bool nms_matrix = true;  // UFD_NO_NMS_MATRIX: every frame's NMS inside k_sort_nms (comparison knob)
+  std::vector<float*> tap_buf;        // UFD_FLAG_TAP_LAYERS: per tensor, a copy taken right after its producing launch
 
   Slot slots[UFD_MAX_SLOTS];
   uint32_t next_ticket = 1;
@@ -363,6 +361,7 @@ void gen_priors(int W, int H, std::vector<float>& out) {
 // Liveness-based arena: every conv output gets [B][c][h][w]; buffers are recycled after their
 // last reader unless UFD_FLAG_KEEP_LAYERS asks to keep all of them for ufd_debug_layer_output.
 void plan_tensors(ufd_model* m, bool keep_all) {
+  const uint32_t flags = m->cfg.flags;
   const ConvSpec* specs = conv_specs();
   m->layers.resize(kNumConv);
   m->tensors.clear();
@@ -433,7 +432,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   }
   // chain two dw->pw blocks into one launch where the tensor between them is the big one
   // (m1 -> m2: 32 channels at half the input resolution) and nothing else reads it
-  if (!keep_all && !std::getenv("UFD_NO_FUSE2")) {
+  if (!keep_all && !(flags & UFD_FLAG_NO_CHAIN)) {
     for (int i = 0; i < kNumConv; i++) {
       Layer& P2 = m->layers[i];
       if (P2.kind != kKindDwPw) continue;
@@ -463,7 +462,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   // out = relu(ConvLinear(cat) + shortcut(x)) as ONE 1x1 conv over the channels of both inputs
   // (weights side by side, biases summed): ConvLinear's output, written once and read back as the
   // residual, never exists.  fp32 rounding apart from the two-launch form (one fma chain, not two).
-  if (!keep_all && !std::getenv("UFD_NO_FUSE_RFB")) {
+  if (!keep_all && !(flags & UFD_FLAG_NO_RFB_SUM)) {
     Layer& S = m->layers[kRfbShortcut];
     Layer& Lin = m->layers[kRfbLinear];
     if (S.kind == kKindPointwise && Lin.kind == kKindPointwise && S.res_tensor == tensor_of[kRfbLinear] && S.oh == Lin.oh &&
@@ -483,7 +482,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   }
   // The three RFB reduce convs (64 -> 8 each, same input) as ONE 64 -> 24 conv: one cout tile instead
   // of three, the input read once; the consumers read channel slices of the stacked tensor.
-  if (!keep_all && !std::getenv("UFD_NO_STACK")) {
+  if (!keep_all) {
     static const int kStack[3] = {13, 16, 19};
     Layer& A = m->layers[kStack[0]];
     int cout_sum = 0;
@@ -505,6 +504,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         Layer& Bm = m->layers[kStack[k]];
         for (int j = 0; j < kNumConv; j++)
           if (m->layers[j].in_tensor == Bm.out_tensor && m->layers[j].spec.src == kStack[k]) m->layers[j].in_tensor = stacked, m->layers[j].in_coff = coff;
+        Bm.tap_tensor = stacked, Bm.tap_coff = coff;
         coff += Bm.spec.cout;
         A.stack[k] = kStack[k];
         if (k > 0) {
@@ -519,7 +519,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   }
   // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
   for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
-  if (!(std::getenv("UFD_NO_MERGE"))) {
+  {
     // (leader first: the launch is issued at the leader's turn, so a leader that is not the lowest
     // index -- the RFB's dilated convs wait for the b2 branch -- delays the others to its turn)
     static const int kGroups[][3] = {{13, 16, 19}, {14, 17, 20}, {22, 15, 18}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
@@ -555,6 +555,13 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         m->layers[g[0]].group[k] = g[k];
       }
     }
+  }
+  // where each layer's output can be read back in this plan (ufd_debug_layer_output)
+  for (int i = 0; i < kNumConv; i++) {
+    Layer& L = m->layers[i];
+    if (L.tap_tensor >= 0) continue;  // slice of the stacked reduce tensor
+    if ((L.kind == kKindFusedAway && !L.materialize) || L.chained) continue;
+    L.tap_tensor = L.out_tensor, L.tap_coff = L.out_coff;
   }
   // liveness: first writer, last reader (head outputs live until the decode kernel)
   const int nt = (int)m->tensors.size();
@@ -723,6 +730,8 @@ int alloc_slot(ufd_model* m, Slot& s) {
   if (s.h_descs) return UFD_OK;
   HIPC(m, hipHostMalloc(&s.h_descs, sizeof(JpegFrameDesc) * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
+  HIPC(m, hipMalloc(&s.d_dets, sizeof(Det) * m->K * m->B));
+  HIPC(m, hipMemset(s.d_dets, 0, sizeof(Det) * m->K * m->B));
   HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_blob, m->blob_stride * m->B, hipHostMallocDefault));
@@ -859,8 +868,32 @@ ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_st
 // Issues conv layer i -- together with the layers merged into its launch (Layer::group: cls + reg
 // head pairs and the three RFB reduce convs share shapes and run as one launch, blockIdx.y
 // selecting the member).  Non-leading members are skipped when their turn comes.
-void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st = nullptr) {
-  if (!st) st = tl_cur->stream;
+void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st);
+
+void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st);
+
+void enqueue_layer(ufd_model* m, int i, uint32_t count) {
+  hipStream_t st = tl_cur->stream;
+  enqueue_layer_launch(m, i, 0, count, st);
+  if (!m->tap_buf.empty() && tl_cur == &m->ctx[0]) tap_outputs(m, i, count, st);
+}
+
+// UFD_FLAG_TAP_LAYERS: copies every tensor the launch issued at layer i's turn has just written
+// (whole batch) to its tap buffer, before the arena recycles it.
+void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st) {
+  const Layer& L = m->layers[i];
+  if ((L.kind == kKindFusedAway && !L.materialize) || L.chained || L.leader != i) return;
+  int seen[3] = {-1, -1, -1}, n = 0;
+  for (int j : L.group) {
+    if (j < 0) continue;
+    const int t = m->layers[j].out_tensor;
+    if (t == seen[0] || t == seen[1]) continue;
+    seen[n++] = t;
+    (void)hipMemcpyAsync(m->tap_buf[t], tensor_ptr(m, t), sizeof(float) * m->tensors[t].per_frame() * count, hipMemcpyDeviceToDevice, st);
+  }
+}
+
+void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st) {
   const Layer& L = m->layers[i];
   if (L.kind == kKindFusedAway && !L.materialize) return;
   if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
@@ -934,67 +967,10 @@ void enqueue_layer(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t
   }
 }
 
-// [count][3][H][W] in d_input -> every conv output the heads need.
-// The 240x320 / 120x160 stages move 10-20 MB per frame each, so a 32-frame batch streams through
-// HBM between layers; run in chunks of `early_chunk` frames those layers keep producer->consumer
-// tensors inside the 256 MiB Infinity Cache.  Deeper layers are small and want the whole batch
-// in one launch.
+// [count][3][H][W] in d_input (or the sample planes, fused stem) -> every conv output the heads need.
 void enqueue_forward(ufd_model* m, uint32_t count) {
-  Ctx& c = *tl_cur;
-  if (!m->branch_streams) {
-    // optional: the first layers in chunks of frames, so that their large producer->consumer
-    // tensors stay inside the 256 MiB Infinity Cache (UFD_CHUNK / UFD_CHUNK_LAYERS tuning knobs)
-    static const int chunk_knob = std::getenv("UFD_CHUNK") ? std::atoi(std::getenv("UFD_CHUNK")) : 0;
-    static const int until_knob = std::getenv("UFD_CHUNK_LAYERS") ? std::atoi(std::getenv("UFD_CHUNK_LAYERS")) : 5;
-    const uint32_t chunk = chunk_knob > 0 ? (uint32_t)chunk_knob : count;
-    const int early_end = chunk < count ? std::min(until_knob, kNumConv) : 0;
-    for (uint32_t f0 = 0; early_end && f0 < count; f0 += chunk)
-      for (int i = 0; i < early_end; i++) enqueue_layer(m, i, f0, std::min(chunk, count - f0));
-    for (int i = early_end; i < kNumConv; i++) enqueue_layer(m, i, 0, count);
-    c.last_forward_count = count;
-    return;
-  }
-  // Branch-parallel issue: the RFB branches and the cls / reg heads are independent of the
-  // backbone's continuation; they go to two side streams so that their small, latency-bound
-  // kernels run beside the main chain (the arena keeps every tensor alive in this mode).
-  auto fork = [&]() {
-    (void)hipEventRecord(c.ev_fork, c.stream);
-    (void)hipStreamWaitEvent(c.aux[0], c.ev_fork, 0);
-    (void)hipStreamWaitEvent(c.aux[1], c.ev_fork, 0);
-  };
-  auto join = [&]() {
-    for (int k = 0; k < 2; k++) {
-      (void)hipEventRecord(c.ev_join[k], c.aux[k]);
-      (void)hipStreamWaitEvent(c.stream, c.ev_join[k], 0);
-    }
-  };
-  auto run = [&](std::initializer_list<int> layers, hipStream_t st) {
-    for (int i : layers) enqueue_layer(m, i, 0, count, st);
-  };
-  for (int i = 0; i <= 12; i++) enqueue_layer(m, i, 0, count);
-  fork();
-  run({13, 14, 15}, c.aux[0]);
-  run({16, 17, 18}, c.aux[1]);
-  run({19, 20, 21, 22}, c.stream);
-  join();
-  run({23, 24}, c.stream);
-  fork();
-  run({25, 26}, c.aux[0]);
-  run({27, 28}, c.aux[1]);
-  run({29, 30, 31, 32, 33, 34}, c.stream);
-  fork();  // (aux streams keep their own order: heads 1 follow heads 0)
-  run({35, 36}, c.aux[0]);
-  run({37, 38}, c.aux[1]);
-  run({39, 40, 41, 42}, c.stream);
-  fork();
-  run({43, 44}, c.aux[0]);
-  run({45, 46}, c.aux[1]);
-  run({47, 48, 49}, c.stream);
-  fork();
-  run({50}, c.aux[0]);
-  run({51}, c.stream);
-  join();
-  c.last_forward_count = count;
+  for (int i = 0; i < kNumConv; i++) enqueue_layer(m, i, count);
+  tl_cur->last_forward_count = count;
 }
 
 void enqueue_heads(ufd_model* m, uint32_t count) {
@@ -1016,17 +992,17 @@ void enqueue_heads(ufd_model* m, uint32_t count) {
                      tl_cur->d_counts, tl_cur->stream);
 }
 
-void enqueue_nms(ufd_model* m, uint32_t count) {
+void enqueue_nms(ufd_model* m, Slot& s, uint32_t count) {
   ProfScope ps(m, "sort_nms", 0, 0);
-  launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, tl_cur->d_dets, m->K, tl_cur->d_ndet,
-                  tl_cur->d_spill, m->nms_matrix ? tl_cur->d_nms_mat : nullptr, count, tl_cur->stream);
+  launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, s.d_dets, m->K, tl_cur->d_ndet,
+                  tl_cur->d_spill, tl_cur->d_nms_mat, count, tl_cur->stream);
 }
 
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
   if (s.gpu_entropy)
     HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
-  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, tl_cur->d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
+  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, s.d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
                            hipMemcpyDeviceToHost, tl_cur->stream));
   HIPC(m, hipEventRecord(s.done, tl_cur->stream));
   s.ctx = tl_cur;
@@ -1061,8 +1037,9 @@ int finish_slot(ufd_model* m, Slot& s) {
       ufd_det* dst = s.out + (size_t)i * s.cap;
       const uint32_t fast = std::min(ncopy, kDetCopy);
       std::memcpy(dst, s.h_dets + (size_t)i * kDetCopy, sizeof(Det) * fast);
-      if (ncopy > fast) {  // rare: more than kDetCopy detections requested for one frame
-        HIPC(m, hipMemcpy(dst + fast, s.ctx->d_dets + (size_t)i * m->K + fast, sizeof(Det) * (ncopy - fast),
+      if (ncopy > fast) {  // rare: more than kDetCopy detections requested for one frame.  The slot's own
+        // device buffer: no later batch can have written it (the slot is busy until this returns)
+        HIPC(m, hipMemcpy(dst + fast, s.d_dets + (size_t)i * m->K + fast, sizeof(Det) * (ncopy - fast),
                           hipMemcpyDeviceToHost));
       }
       if (nd > s.cap) st = UFD_E_TRUNCATED;
@@ -1077,7 +1054,14 @@ int finish_slot(ufd_model* m, Slot& s) {
 
 Slot* find_free_slot(ufd_model* m) {
   for (auto& s : m->slots)
-    if (!s.busy) return &s;
+    if (!s.busy) {
+      // a fresh job: nothing of the slot's previous batch (a failed issue included) may leak into it
+      s.issue_rc = UFD_OK;
+      s.issue_err.clear();
+      s.job_jpegs = nullptr, s.job_lens = nullptr, s.job_staged = nullptr;
+      s.state = 0;
+      return &s;
+    }
   return nullptr;
 }
 
@@ -1343,7 +1327,7 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       }
       // 4:2:0 frames at the model size: the stem conv reads the sample planes itself (no f32 input
       // tensor); UFD_NO_STEM_FUSE=1 at ufd_create keeps the two-kernel path
-      if (all_420 && m->stem_fusable && !m->branch_streams) {
+      if (all_420 && m->stem_fusable) {
         tl_cur->stem_descs = d_descs;
         fused_stem = true;
       } else {
@@ -1404,7 +1388,7 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       tl_cur->consumed_valid[buf] = true;
     }
     enqueue_heads(m, count);
-    enqueue_nms(m, count);
+    enqueue_nms(m, s, count);
   }
   return enqueue_results_copy(m, s, count);
 }
@@ -1424,7 +1408,7 @@ int run_rgb_on_device(ufd_model* m, Slot& s, uint32_t w, uint32_t h, uint32_t co
   }
   enqueue_forward(m, count);
   enqueue_heads(m, count);
-  enqueue_nms(m, count);
+  enqueue_nms(m, s, count);
   return enqueue_results_copy(m, s, count);
 }
 
@@ -1532,16 +1516,18 @@ void destroy(ufd_model* m) {
       if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
     }
     dfree(c.d_planes), dfree(c.d_rgb), dfree(c.d_sync);
-    dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_dets), dfree(c.d_ndet);
+    dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_ndet);
     dfree(c.d_spill);
     dfree(c.d_nms_mat);
   }
+  for (float* t : m->tap_buf) dfree(t);
   for (auto& kv : m->taps)
     for (TapsDev* t : {&kv.second.first, &kv.second.second}) dfree(t->left), dfree(t->cnt), dfree(t->w);
   for (auto& s : m->slots) {
     if (s.h_descs) (void)hipHostFree(s.h_descs);
     if (s.h_coef) (void)hipHostFree(s.h_coef);
     if (s.h_dets) (void)hipHostFree(s.h_dets);
+    if (s.d_dets) (void)hipFree(s.d_dets);
     if (s.h_ndet) (void)hipHostFree(s.h_ndet);
     if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);
     if (s.h_blob) (void)hipHostFree(s.h_blob);
@@ -1553,11 +1539,6 @@ void destroy(ufd_model* m) {
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
   for (Ctx& c : m->ctx) {
     if (c.copy_stream && c.copy_stream != c.stream) (void)hipStreamDestroy(c.copy_stream);
-    for (int k = 0; k < 2; k++) {
-      if (c.aux[k]) (void)hipStreamDestroy(c.aux[k]);
-      if (c.ev_join[k]) (void)hipEventDestroy(c.ev_join[k]);
-    }
-    if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
     if (c.stream) (void)hipStreamDestroy(c.stream);
   }
   delete m;
@@ -1620,26 +1601,14 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
-  m->nms_matrix = !std::getenv("UFD_NO_NMS_MATRIX");
-  m->branch_streams = std::getenv("UFD_BRANCH") && std::atoi(std::getenv("UFD_BRANCH"));  // experiment knob
   // More than four live HSA queues cost throughput (host pipeline): if the process raised the
   // runtime's cap, stay at two contexts = four streams (34 k instead of 30 k frames/s at GPU_MAX_HW_QUEUES=8).
   if (const char* q = std::getenv("GPU_MAX_HW_QUEUES"))
     if (std::atoi(q) > 4) m->num_ctx = 2;
-  if (const char* e = std::getenv("UFD_CTX")) m->num_ctx = std::max(1, std::min(kMaxCtx, std::atoi(e)));  // tuning knob
-  const bool own_copy_stream = !(std::getenv("UFD_COPY_STREAM") && std::atoi(std::getenv("UFD_COPY_STREAM")) == 0);
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];
     HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    if (own_copy_stream) HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-    else c.copy_stream = c.stream;
-    if (m->branch_streams) {
-      for (int k = 0; k < 2; k++) {
-        HIPB(hipStreamCreateWithFlags(&c.aux[k], hipStreamNonBlocking));
-        HIPB(hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming));
-      }
-      HIPB(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-    }
+    HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
   }
 
   // ---- weights + priors
@@ -1669,14 +1638,14 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_WEIGHTS);
     }
   }
-  plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0 || m->branch_streams);
+  plan_tensors(m, (cfg->flags & UFD_FLAG_KEEP_LAYERS) != 0);
   {
     const Layer& L0 = m->layers[0];
     ConvArgs probe{};
     probe.k = L0.spec.k, probe.stride = L0.spec.stride, probe.dil = L0.spec.dil, probe.pad = L0.spec.pad;
     probe.cin = L0.spec.cin, probe.cout = L0.spec.cout, probe.depthwise = L0.spec.groups > 1;
     probe.ih = L0.ih, probe.iw = L0.iw, probe.oh = L0.oh, probe.ow = L0.ow;
-    m->stem_fusable = L0.kind == kKindConv3x3 && L0.leader == 0 && stem_planes_supported(probe) && !std::getenv("UFD_NO_STEM_FUSE");
+    m->stem_fusable = L0.kind == kKindConv3x3 && L0.leader == 0 && stem_planes_supported(probe) && !(cfg->flags & UFD_FLAG_NO_STEM_FUSE);
   }
   // shapes the kernels rely on (checked here once, not per launch)
   for (const Layer& L : m->layers) {
@@ -1744,11 +1713,14 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_boxes, B * m->K * 4 * sizeof(float)));
     HIPB(hipMalloc(&c.d_keys, B * m->key_stride * sizeof(unsigned long long)));
     HIPB(hipMalloc(&c.d_counts, B * sizeof(uint32_t)));
-    HIPB(hipMalloc(&c.d_dets, B * m->K * sizeof(Det)));
     HIPB(hipMalloc(&c.d_ndet, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
     HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B)));
-    HIPB(hipMemset(c.d_dets, 0, B * m->K * sizeof(Det)));
+  }
+  if (cfg->flags & UFD_FLAG_TAP_LAYERS) {
+    m->tap_buf.assign(m->tensors.size(), nullptr);
+    for (size_t t = 0; t < m->tensors.size(); t++)
+      HIPB(hipMalloc(&m->tap_buf[t], std::max<size_t>(m->tensors[t].per_frame() * B, 64) * sizeof(float)));
   }
   HIPB(hipDeviceSynchronize());
 #undef HIPB
@@ -2088,14 +2060,17 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
 int ufd_debug_layer_output(ufd_model* m, uint32_t layer, uint32_t frame, float* out, size_t cap_floats, size_t* floats) {
   return guarded(m, [&]() -> int {
     drain_worker0(m);
-    if (!(m->cfg.flags & UFD_FLAG_KEEP_LAYERS)) return m->fail(UFD_E_STATE, "needs UFD_FLAG_KEEP_LAYERS");
+    const bool taps = !m->tap_buf.empty();
+    if (!(m->cfg.flags & UFD_FLAG_KEEP_LAYERS) && !taps) return m->fail(UFD_E_STATE, "needs UFD_FLAG_KEEP_LAYERS or UFD_FLAG_TAP_LAYERS");
     if (layer >= (uint32_t)kNumConv || frame >= tl_cur->last_forward_count) return m->fail(UFD_E_ARG, "layer/frame out of range");
     const Layer& L = m->layers[layer];
-    const Tensor& t = m->tensors[L.out_tensor];
+    if (L.tap_tensor < 0) return m->fail(UFD_E_STATE, "this layer's output never exists in the issued plan (fused into the next launch)");
+    const Tensor& t = m->tensors[L.tap_tensor];
     const size_t plane = (size_t)L.oh * L.ow, nf = (size_t)L.spec.cout * plane;
     if (floats) *floats = nf;
     if (!out || cap_floats < nf) return m->fail(UFD_E_ARG, "output buffer too small");
-    const float* src = tensor_ptr(m, L.out_tensor) + ((size_t)frame * t.c + L.out_coff) * plane;
+    const float* base = taps ? m->tap_buf[L.tap_tensor] : tensor_ptr(m, L.tap_tensor);
+    const float* src = base + ((size_t)frame * t.c + L.tap_coff) * plane;
     HIPC(m, hipMemcpyAsync(out, src, nf * sizeof(float), hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipStreamSynchronize(tl_cur->stream));
     return UFD_OK;
@@ -2118,7 +2093,7 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
     HIPC(m, hipMemcpyAsync(tl_cur->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, tl_cur->stream));
     HIPC(m, hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream));
     launch_threshold(tl_cur->d_scores, m->K, count, m->cfg.min_confidence, tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->stream);
-    enqueue_nms(m, count);
+    enqueue_nms(m, *s, count);
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
     s->gpu_entropy = false;
     std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);

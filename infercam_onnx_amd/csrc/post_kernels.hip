@@ -449,7 +449,7 @@ void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_c
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
                      unsigned long long* d_mat, uint32_t B, hipStream_t s) {
-  static const int knob = std::getenv("UFD_NMS_MAT_MIN") ? std::atoi(std::getenv("UFD_NMS_MAT_MIN")) : kMatMin;  // tuning knob
+  const int knob = kMatMin;
   const bool use_matrix = d_mat != nullptr && K > (uint32_t)knob;
   hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
                      d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : kMatMax);

@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -32,28 +33,39 @@ class ThreadPool {
       for (unsigned i = 0; i < n; i++) fn(i);
       return;
     }
+    Job job;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn;
-      total_ = n;
-      next_.store(0);
-      pending_ = n;
       gen_++;
+      job = job_ = Job{&fn, n, gen_};
+      pending_ = n;
+      // generation and next index live in ONE atomic: a worker that wakes late for an older
+      // generation can never claim an index of this one
+      cursor_.store((uint64_t)gen_ << 32);
     }
     cv_.notify_all();
-    drain();
+    drain(job);
     std::unique_lock<std::mutex> lk(mu_);
-    // also wait until every worker has left drain(): none may straddle two generations
+    // also wait until every worker has left drain(): `fn` dies with this frame
     done_cv_.wait(lk, [this] { return pending_ == 0 && active_ == 0; });
-    fn_ = nullptr;
   }
 
  private:
-  void drain() {
+  struct Job {
+    const std::function<void(unsigned)>* fn = nullptr;
+    unsigned total = 0, gen = 0;
+  };
+  void drain(const Job& job) {
     for (;;) {
-      unsigned i = next_.fetch_add(1);
-      if (i >= total_) return;
-      (*fn_)(i);
+      uint64_t cur = cursor_.load();
+      unsigned i;
+      for (;;) {
+        if ((unsigned)(cur >> 32) != job.gen) return;  // a newer generation owns the cursor
+        i = (unsigned)cur;
+        if (i >= job.total) return;
+        if (cursor_.compare_exchange_weak(cur, cur + 1)) break;
+      }
+      (*job.fn)(i);
       std::lock_guard<std::mutex> lk(mu_);
       if (--pending_ == 0) done_cv_.notify_all();
     }
@@ -61,14 +73,16 @@ class ThreadPool {
   void worker() {
     unsigned seen = 0;
     for (;;) {
+      Job job;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
         if (stop_) return;
         seen = gen_;
+        job = job_;  // {fn, total, gen} of one generation, read under the lock that published them
         active_++;
       }
-      drain();
+      drain(job);
       {
         std::lock_guard<std::mutex> lk(mu_);
         if (--active_ == 0) done_cv_.notify_all();
@@ -78,9 +92,9 @@ class ThreadPool {
   std::vector<std::thread> workers_;
   std::mutex mu_;
   std::condition_variable cv_, done_cv_;
-  const std::function<void(unsigned)>* fn_ = nullptr;
-  std::atomic<unsigned> next_{0};
-  unsigned total_ = 0, pending_ = 0, gen_ = 0, active_ = 0;
+  Job job_;
+  std::atomic<uint64_t> cursor_{0};
+  unsigned pending_ = 0, gen_ = 0, active_ = 0;
   bool stop_ = false;
 };
 

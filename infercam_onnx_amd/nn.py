@@ -19,6 +19,7 @@ UFD_OK = 0
 UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
 UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
+UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_MAX_SLOTS = 8
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
@@ -172,7 +173,8 @@ class UltrafaceModel(InferModel):
 
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
                  weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
-                 device_entropy=False, host_entropy=False):
+                 device_entropy=False, host_entropy=False, tap_layers=False, no_chain=False, no_rfb_sum=False,
+                 no_stem_fuse=False):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -188,7 +190,9 @@ class UltrafaceModel(InferModel):
         cfg.max_src_width, cfg.max_src_height = int(max_src[0]), int(max_src[1])
         cfg.host_threads = int(host_threads)
         cfg.flags = ((UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0) |
-                     (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0))
+                     (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0) |
+                     (UFD_FLAG_TAP_LAYERS if tap_layers else 0) | (UFD_FLAG_NO_CHAIN if no_chain else 0) |
+                     (UFD_FLAG_NO_RFB_SUM if no_rfb_sum else 0) | (UFD_FLAG_NO_STEM_FUSE if no_stem_fuse else 0))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()
@@ -355,8 +359,10 @@ class UltrafaceModel(InferModel):
         return scores, boxes
 
     def debug_layer_output(self, layer, frame=0):
+        """Output of conv `layer` for `frame` of the last forward (keep_layers: the unfused plan;
+        tap_layers: the issued plan -- raises UFD_E_STATE for a layer fused into the next launch)."""
         nf = ctypes.c_size_t()
-        self._lib.ufd_debug_layer_output(self._h, layer, frame, None, 0, ctypes.byref(nf))
+        self._check(self._lib.ufd_debug_layer_output(self._h, layer, frame, None, 0, ctypes.byref(nf)), allow=(UFD_E_ARG,))
         out = np.empty(nf.value, np.float32)
         self._check(self._lib.ufd_debug_layer_output(self._h, layer, frame, out.ctypes.data, out.size, ctypes.byref(nf)))
         return out

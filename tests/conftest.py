@@ -25,3 +25,12 @@ def weights():
     from infercam_onnx_amd import synth
 
     return synth.synthetic_weights()
+
+
+def pytest_terminal_summary(terminalreporter):
+    try:
+        from helpers import EXCUSED
+    except Exception:
+        return
+    terminalreporter.write_line("assert_dets_match: borderline excuse fired for %d detections in %d frames" %
+                                (EXCUSED["detections"], EXCUSED["frames"]))

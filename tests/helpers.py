@@ -29,7 +29,7 @@ def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-
        and such leftovers must stay below 1 % of the list."""
     got, ref = np.asarray(got, np.float32).reshape(-1, 5), np.asarray(ref, np.float32).reshape(-1, 5)
     if got.shape == ref.shape and (got.size == 0 or np.abs(got - ref).max() <= atol):
-        return
+        return 0
     used = np.zeros(len(ref), bool)
     left_got = []
     for g in got:
@@ -53,3 +53,25 @@ def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-
     if bad or n_left > max(2, 0.01 * max(len(got), len(ref))):
         raise AssertionError("%s detections differ: got %d, oracle %d, unmatched %d (%d not borderline)\n got=%s\n ref=%s" %
                              (what, len(got), len(ref), n_left, len(bad), np.array(left_got[:4]), np.array(left_ref[:4])))
+    EXCUSED["frames"] += 1 if n_left else 0
+    EXCUSED["detections"] += n_left
+    return n_left  # number of excused (borderline) detections: callers log how often the excuse fires
+
+
+# how often assert_dets_match excused a borderline decision in this test session (printed by conftest)
+EXCUSED = {"frames": 0, "detections": 0}
+
+
+def dets_from_ctypes(out, cnt, cap, i):
+    """Frame i of a UfdDet array laid out [count][cap] -> [n,5] f32 without per-element ctypes access."""
+    n = min(int(cnt[i]), cap)
+    a = np.frombuffer(out, np.float32).reshape(-1, cap, 5)
+    return a[i, :n].copy()
+
+
+def oracle_many(fn, items, threads=16):
+    """Runs the (GIL-releasing, ctypes) oracle over many frames on a few host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(fn, items))

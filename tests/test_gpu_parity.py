@@ -429,16 +429,11 @@ def test_chained_blocks_kernel_is_bit_identical_to_the_unfused_pair(weights, ora
     """m1 -> m2 and m3 -> m4 run as one launch each (k_dwpw2_mfma, the 32-channel tensor between the
     blocks never exists) and keep the unfused fma order: scores and boxes are bit-identical to the two-launch path, for
     frames whose borders exercise the zero padding, and at batch sizes that leave dead lanes."""
-    import os
     from infercam_onnx_amd import synth
 
     W, H = (640, 480) if variant == 640 else (320, 240)
     x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(91, i, W, H)) for i in range(3)])
-    os.environ["UFD_NO_FUSE2"] = "1"
-    try:
-        ref_model = make_model(variant, weights, max_batch=3, profile=True)
-    finally:
-        del os.environ["UFD_NO_FUSE2"]
+    ref_model = make_model(variant, weights, max_batch=3, profile=True, no_chain=True)
     fused_model = make_model(variant, weights, max_batch=3, profile=True)
     try:
         for count in (3, 1):
@@ -560,18 +555,13 @@ def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracl
     (k_stem_planes_mfma: upsampling + colour + normalisation per lane).  Same integer formulas and
     MFMA order as k_upsample_norm_420 + the row kernel: detections are bit-identical, for frames
     whose first/last rows and columns exercise the padding, with a failed frame in the batch."""
-    import os
     from infercam_onnx_amd import synth
 
     jpegs = [synth.encode_jpeg(synth.synth_frame(92, i, 640, 480), **kw)
              for i, kw in enumerate(({}, {"restart_rows": 1}, {"quality": 35}, {"quality": 98}))]
     jpegs.insert(2, jpegs[0][: len(jpegs[0]) // 2])  # a frame that fails to decode
-    os.environ["UFD_NO_STEM_FUSE"] = "1"
-    try:
-        ref_model = make_model(640, weights, max_batch=5, profile=True)
-        ref, st_ref = ref_model.infer_jpeg_batch(jpegs)
-    finally:
-        del os.environ["UFD_NO_STEM_FUSE"]
+    ref_model = make_model(640, weights, max_batch=5, profile=True, no_stem_fuse=True)
+    ref, st_ref = ref_model.infer_jpeg_batch(jpegs)
     fused_model = make_model(640, weights, max_batch=5, profile=True)
     try:
         got, st = fused_model.infer_jpeg_batch(jpegs)
@@ -589,17 +579,12 @@ def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
     """relu(ConvLinear(cat) + shortcut(x)) as one 1x1 conv over both inputs' channels: one fma chain
     instead of two, so fp32 rounding apart (<= 5e-6 on scores / boxes) from the two-launch form,
     and within the usual bar of the oracle."""
-    import os
     from infercam_onnx_amd import synth
 
     W, H = 640, 480
     pri = synth.gen_priors(W, H)
     x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(93, i, W, H)) for i in range(3)])
-    os.environ["UFD_NO_FUSE_RFB"] = "1"
-    try:
-        ref_model = make_model(640, weights, max_batch=3, profile=True)
-    finally:
-        del os.environ["UFD_NO_FUSE_RFB"]
+    ref_model = make_model(640, weights, max_batch=3, profile=True, no_rfb_sum=True)
     fused_model = make_model(640, weights, max_batch=3, profile=True)
     try:
         s0, b0 = ref_model.debug_forward(x)
