@@ -318,6 +318,33 @@ bool load_ultraface_onnx(const std::string& path, int width, int height, std::ve
       break;
     }
   }
+  if (priors->empty()) {
+    // torch's tracer evaluates `priors[..., :2]` / `priors[..., 2:]` at export time, so an exported
+    // SSD graph holds the priors as [1,K,2] halves: the constant ADDED to the scaled centre offsets
+    // is (cx, cy), the constant MULTIPLIED with them (and with exp(size offsets)) is (w, h).
+    const TensorData *centres = nullptr, *sizes = nullptr;
+    auto half = [&](const std::string& name) -> const TensorData* {
+      auto it = tensors.find(name);
+      if (it == tensors.end()) return nullptr;
+      const TensorData& t = it->second;
+      if (t.f.size() != (size_t)K * 2 || t.dims.size() < 2 || t.dims.back() != 2 || t.dims[t.dims.size() - 2] != K) return nullptr;
+      return &t;
+    };
+    for (const auto& n : nodes) {
+      if (n.op != "Add" && n.op != "Mul") continue;
+      for (const auto& in : n.in)
+        if (const TensorData* t = half(in)) (n.op == "Add" ? centres : sizes) = t;
+    }
+    if (centres && sizes) {
+      priors->resize((size_t)K * 4);
+      for (int k = 0; k < K; k++) {
+        (*priors)[k * 4 + 0] = centres->f[k * 2 + 0];
+        (*priors)[k * 4 + 1] = centres->f[k * 2 + 1];
+        (*priors)[k * 4 + 2] = sizes->f[k * 2 + 0];
+        (*priors)[k * 4 + 3] = sizes->f[k * 2 + 1];
+      }
+    }
+  }
   return true;
 }
 
