@@ -59,6 +59,8 @@ def stage_of(label):
     """Stage of SURVEY 8(d)'s breakdown a profiled kernel label belongs to."""
     if label.startswith("h2d_"):
         return "h2d"
+    if label.startswith("host_"):
+        return "host_" + ("plan" if label == "host_plan" else "issue_total")
     if label.startswith("huff_") or label in ("dc_prefix", "zero_coef"):
         return "entropy"
     if label in ("idct", "upsample_norm", "upsample_norm_420", "upsample_rgb", "resize_norm"):
@@ -100,8 +102,6 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
     path cannot be built here) timed on this host on a bounded sample of the bench's frames:
     (a) one thread -- the reference's operating point is a single Inferer task (infer_server.rs:48-50);
     (b) one worker per hardware thread, frames being independent."""
-    from concurrent.futures import ThreadPoolExecutor
-
     import oracle
 
     oracle.build()
@@ -115,17 +115,15 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
             break
     one = n / el
     cores = os.cpu_count() or 1
-    # all cores: each worker runs whole frames (ctypes releases the GIL inside the C call)
-    per_worker = max(2, int(one * budget_s * 0.8))
-    jobs = [jpegs[i % len(jpegs)] for i in range(per_worker * cores)]
+    # all cores: worker threads inside the C library, each running whole frames
+    total = max(2 * cores, int(one * budget_s * 0.6) * cores)
     t1 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jobs))
+    done, _ = oracle.infer_jpeg_many_threads(jpegs, total, cores, W, H, weights, priors, 0.5, 0.5)
     el_all = time.perf_counter() - t1
     return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el),
-            "all_cores": {"value": round(len(jobs) / el_all, 2), "unit": "frames/s", "cores": cores,
-                          "sample": "%d frames, one worker thread per hardware thread, %.1f s" % (len(jobs), el_all)}}
+            "all_cores": {"value": round(done / el_all, 2), "unit": "frames/s", "cores": cores,
+                          "sample": "%d frames, one worker thread per hardware thread, %.1f s" % (done, el_all)}}
 
 
 def kernel_source_sha():
@@ -330,7 +328,7 @@ def main():
         # ---- roofline of the dominant kernel (device time from HIP events on the library's streams,
         # sampled over the timed region)
         agg = aggregate(stats)
-        kern = {k: v for k, v in agg.items() if not k.startswith("h2d_")}
+        kern = {k: v for k, v in agg.items() if not k.startswith(("h2d_", "host_"))}
         roof = None
         if kern:
             dom = max(kern, key=lambda k: kern[k]["ms"])

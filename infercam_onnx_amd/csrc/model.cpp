@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -97,7 +98,10 @@ struct Slot {
   Det* d_dets = nullptr;  // [B][K] detections of this slot's batch: stays valid until the slot is released (tail reads at ufd_wait)
   uint32_t* h_ndet = nullptr;
   uint32_t* h_gpu_status = nullptr;  // per frame: device entropy decoder flagged a corrupt stream
-  uint8_t* h_blob = nullptr;        // pinned staging of the batch's JPEG bytes
+  // One pinned block per slot, copied to the device with ONE hipMemcpyAsync:
+  //   [frame descriptors][scan layouts][restart intervals (n_iv)][JPEG bytes, frames packed back to back]
+  uint8_t* h_stage = nullptr;
+  uint8_t* h_blob = nullptr;        // = h_stage + blob_base of the batch (set by plan_device_entropy)
   HuffScan* h_scans = nullptr;
   HuffInterval* h_ivs = nullptr;
   std::vector<GpuScanPlan> plans;
@@ -135,15 +139,13 @@ struct Worker {
 // of one batch (small feature maps, NMS) overlap the bandwidth-bound stages of the other.
 struct Ctx {
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // H2D of the next batch overlaps the kernels of the current one
+  hipStream_t copy_stream = nullptr;  // the handle's one copy stream (shared by the contexts): H2D of the next batch overlaps kernels
   float* d_arena = nullptr;
   float* d_input = nullptr;
   JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
   int16_t* d_coef_buf[2] = {nullptr, nullptr};
   // device entropy decoding: JPEG bytes, scan layouts and restart intervals of the batch
-  uint8_t* d_blob_buf[2] = {nullptr, nullptr};
-  HuffScan* d_scans_buf[2] = {nullptr, nullptr};
-  HuffInterval* d_ivs_buf[2] = {nullptr, nullptr};
+  uint8_t* d_stage_buf[2] = {nullptr, nullptr};  // device image of Slot::h_stage (d_descs_buf points at its head)
   uint8_t* d_sync = nullptr;  // scratch of the self-synchronising entropy decoder
   const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 sample planes (fused stem)
   SyncBuffers sync;
@@ -191,6 +193,7 @@ struct ufd_model {
   int next_ctx = 0;
   std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
   std::mutex err_mu;     // error string
+  std::mutex copy_mu;    // enqueue order on the shared copy stream
   std::unique_ptr<ThreadPool> pool;
   unsigned host_threads = 1;
 
@@ -213,6 +216,8 @@ struct ufd_model {
   std::vector<std::array<HuffLut, 4>> lut_sets;
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
+  size_t scans_off = 0, ivs_off = 0, stage_cap = 0;  // layout of the staging block (descriptors at 0)
+  hipStream_t copy_stream = nullptr;
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
@@ -242,7 +247,9 @@ struct DevicePlan {
   bool ok = false;         // every decodable frame of the batch can take the device decoder
   bool any_ok = false;
   uint32_t n_iv = 0;       // intervals in h_ivs
-  size_t used_blob = 0, used_coef = 0;
+  size_t used_blob = 0, used_coef = 0;  // bytes of JPEG data in the packed blob; largest coefficient slab
+  size_t blob_base = 0;    // offset of the packed JPEG bytes inside the staging block
+  size_t stage_bytes = 0;  // bytes of the staging block to copy
   uint32_t max_nsub = 0, max_bpm = 1;
 };
 
@@ -254,6 +261,7 @@ struct ufd_staged {
   DevicePlan plan;
   std::vector<JpegFrameDesc> h_descs;
   std::vector<int32_t> st;
+  uint8_t* d_stage = nullptr;  // device image of the staging block
   uint8_t* d_blob = nullptr;
   JpegFrameDesc* d_descs = nullptr;
   HuffScan* d_scans = nullptr;
@@ -316,6 +324,26 @@ struct ProfScope {
     (void)hipEventRecord(pe.e1, st);
     std::lock_guard<std::mutex> lk(m->shared_mu);
     m->prof_pending.push_back(pe);
+  }
+};
+
+// Host-side sections of the pipeline (header scan, staging copies, launch enqueue): wall time on the
+// issuing thread, reported beside the kernels as "host_*" entries (launches = batches).
+struct HostScope {
+  ufd_model* m;
+  const char* name;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  HostScope(ufd_model* mm, const char* n) : m(mm), name(n), on(mm->profile && tl_prof) {
+    if (on) t0 = std::chrono::steady_clock::now();
+  }
+  ~HostScope() {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(m->shared_mu);
+    auto& st = m->prof_stats[prof_name_id(m, name)];
+    st.launches++;
+    st.total_ms += ms;
   }
 };
 
@@ -728,15 +756,15 @@ int upload_weights(ufd_model* m, const float* blob) {
 
 int alloc_slot(ufd_model* m, Slot& s) {
   if (s.h_descs) return UFD_OK;
-  HIPC(m, hipHostMalloc(&s.h_descs, sizeof(JpegFrameDesc) * m->B, hipHostMallocDefault));
+  HIPC(m, hipHostMalloc(&s.h_stage, m->stage_cap, hipHostMallocDefault));
+  s.h_descs = reinterpret_cast<JpegFrameDesc*>(s.h_stage);
+  s.h_scans = reinterpret_cast<HuffScan*>(s.h_stage + m->scans_off);
+  s.h_ivs = reinterpret_cast<HuffInterval*>(s.h_stage + m->ivs_off);
   HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
   HIPC(m, hipMalloc(&s.d_dets, sizeof(Det) * m->K * m->B));
   HIPC(m, hipMemset(s.d_dets, 0, sizeof(Det) * m->K * m->B));
   HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
   HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * m->B, hipHostMallocDefault));
-  HIPC(m, hipHostMalloc(&s.h_blob, m->blob_stride * m->B, hipHostMallocDefault));
-  HIPC(m, hipHostMalloc(&s.h_scans, sizeof(HuffScan) * m->B, hipHostMallocDefault));
-  HIPC(m, hipHostMalloc(&s.h_ivs, sizeof(HuffInterval) * m->iv_cap, hipHostMallocDefault));
   s.plans.resize(m->B);
   HIPC(m, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.st.resize(m->B);
@@ -1098,6 +1126,7 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
 // scan layouts, table sets and intervals into the slot's pinned arrays, JPEG bytes into h_blob.
 DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
   DevicePlan p;
+  HostScope hs(m, "host_plan");
   tl_pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
@@ -1111,6 +1140,11 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     if (s.st[i] == kJpegOk) n_iv += s.plans[i].n_intervals;
   }
   if (n_iv > m->iv_cap) return p;
+  // JPEG bytes packed back to back behind the interval table (16-byte aligned starts, 64 bytes of
+  // slack behind every frame: the unstuff kernel reads whole 16-byte pieces)
+  p.blob_base = (m->ivs_off + (size_t)n_iv * sizeof(HuffInterval) + 255) & ~(size_t)255;
+  s.h_blob = s.h_stage + p.blob_base;
+  size_t blob_fill = 0;
   uint32_t k = 0;
   for (uint32_t i = 0; i < count; i++) {
     std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
@@ -1118,10 +1152,10 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     const int set = lut_set_for(m, s.plans[i].luts);
     if (set < 0) return p;
     HuffScan sc = s.plans[i].scan;
-    sc.blob_off = 0;
     sc.lut_base = (uint32_t)set * 4;
     sc.seg_base = sc.nseg = sc.sub_bytes = sc.nsub = sc.pad = 0;
-    sc.blob_off = (uint32_t)(i * m->blob_stride);
+    sc.blob_off = (uint32_t)blob_fill;
+    blob_fill += (lens[i] + 64 + 63) & ~(size_t)63;
     const uint32_t nseg = s.plans[i].n_intervals;
     {
       // subsequence slots: every segment starts on a subsequence boundary and keeps 32 bytes of
@@ -1147,13 +1181,15 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     }
     s.h_scans[i] = sc;
   }
+  if (p.blob_base + blob_fill > m->stage_cap) return p;
   tl_pool->parallel_for(count, [&](unsigned i) {
-    if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + (size_t)i * m->blob_stride, jpegs[i], lens[i]);
+    if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + s.h_scans[i].blob_off, jpegs[i], lens[i]);
   });
+  p.used_blob = blob_fill;
+  p.stage_bytes = p.blob_base + blob_fill;
   for (uint32_t i = 0; i < count; i++) {
     if (s.st[i] == kJpegOk) {
       p.any_ok = true;
-      p.used_blob = std::max(p.used_blob, (lens[i] + 15) & ~(size_t)15);
       p.used_coef = std::max(p.used_coef, (size_t)s.h_descs[i].coef_total);
     } else {
       std::memset(&s.h_descs[i], 0, sizeof(JpegFrameDesc));
@@ -1176,7 +1212,7 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
   HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
   {
     std::unique_ptr<ProfScope> scope;
-    const double bytes = (double)p.used_blob * count;
+    const double bytes = (double)p.used_blob;
     const HuffStageHook hook = [&](const char* kernel, bool begin) {
       if (begin) scope.reset(new ProfScope(m, kernel, bytes, 0));
       else scope.reset();
@@ -1204,19 +1240,19 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
       const int buf = c.flip;
       c.flip ^= 1;
       *buf_out = buf;
-      if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
-      HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
-      HIPC(m, hipMemcpyAsync(c.d_scans_buf[buf], s.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice, c.copy_stream));
-      HIPC(m, hipMemcpyAsync(c.d_ivs_buf[buf], s.h_ivs, sizeof(HuffInterval) * p.n_iv, hipMemcpyHostToDevice, c.copy_stream));
       {
-        ProfScope ps(m, "h2d_jpeg", (double)p.used_blob * count, 0, c.copy_stream);
-        HIPC(m, hipMemcpy2DAsync(c.d_blob_buf[buf], m->blob_stride, s.h_blob, m->blob_stride, p.used_blob, count,
-                                 hipMemcpyHostToDevice, c.copy_stream));
+        // the handle's one copy stream carries the copies of all contexts: its enqueue order is
+        // serialised here (descriptors + scan plans + intervals + JPEG bytes in ONE contiguous copy)
+        std::lock_guard<std::mutex> lk(m->copy_mu);
+        if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
+        ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.copy_stream);
+        HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.copy_stream));
+        HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
       }
-      HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
       HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
-      return enqueue_device_entropy(m, c, p, count, c.d_blob_buf[buf], c.d_descs_buf[buf], c.d_scans_buf[buf], c.d_ivs_buf[buf],
-                                    c.d_coef_buf[buf]);
+      uint8_t* ds = c.d_stage_buf[buf];
+      return enqueue_device_entropy(m, c, p, count, ds + p.blob_base, c.d_descs_buf[buf], reinterpret_cast<const HuffScan*>(ds + m->scans_off),
+                                    reinterpret_cast<const HuffInterval*>(ds + m->ivs_off), c.d_coef_buf[buf]);
     }
   }
   // ---- host entropy decoding
@@ -1245,6 +1281,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   c.flip ^= 1;
   *buf_out = buf;
   // copy stream: wait until the kernels of two batches ago have consumed this buffer
+  std::lock_guard<std::mutex> copy_lk(m->copy_mu);
   if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
   HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
   {
@@ -1440,6 +1477,7 @@ void worker_main(ufd_model* m, Worker* w) {
     tl_prof = s->job_prof;
     int rc = UFD_OK;
     try {
+      HostScope hs(m, "host_issue");  // everything the worker does for one batch (host_plan included)
       rc = s->job_staged ? submit_staged(m, *s, *s->job_staged) : submit_jpegs(m, *s, s->job_jpegs, s->job_lens, s->count);
     } catch (const std::exception& e) {
       rc = m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
@@ -1499,10 +1537,9 @@ void destroy(ufd_model* m) {
     w.cv.notify_all();
     w.th.join();
   }
-  for (Ctx& c : m->ctx) {
-    if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+  if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
+  for (Ctx& c : m->ctx)
     if (c.stream) (void)hipStreamSynchronize(c.stream);
-  }
   auto dfree = [](void* p) {
     if (p) (void)hipFree(p);
   };
@@ -1510,8 +1547,7 @@ void destroy(ufd_model* m) {
   for (Ctx& c : m->ctx) {
     dfree(c.d_arena), dfree(c.d_input), dfree(c.d_status);
     for (int i = 0; i < 2; i++) {
-      dfree(c.d_descs_buf[i]), dfree(c.d_coef_buf[i]);
-      dfree(c.d_blob_buf[i]), dfree(c.d_scans_buf[i]), dfree(c.d_ivs_buf[i]);
+      dfree(c.d_stage_buf[i]), dfree(c.d_coef_buf[i]);
       if (c.ev_copied[i]) (void)hipEventDestroy(c.ev_copied[i]);
       if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
     }
@@ -1524,23 +1560,20 @@ void destroy(ufd_model* m) {
   for (auto& kv : m->taps)
     for (TapsDev* t : {&kv.second.first, &kv.second.second}) dfree(t->left), dfree(t->cnt), dfree(t->w);
   for (auto& s : m->slots) {
-    if (s.h_descs) (void)hipHostFree(s.h_descs);
+    if (s.h_stage) (void)hipHostFree(s.h_stage);
     if (s.h_coef) (void)hipHostFree(s.h_coef);
     if (s.h_dets) (void)hipHostFree(s.h_dets);
     if (s.d_dets) (void)hipFree(s.d_dets);
     if (s.h_ndet) (void)hipHostFree(s.h_ndet);
     if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);
-    if (s.h_blob) (void)hipHostFree(s.h_blob);
-    if (s.h_scans) (void)hipHostFree(s.h_scans);
-    if (s.h_ivs) (void)hipHostFree(s.h_ivs);
     if (s.done) (void)hipEventDestroy(s.done);
   }
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
   for (Ctx& c : m->ctx) {
-    if (c.copy_stream && c.copy_stream != c.stream) (void)hipStreamDestroy(c.copy_stream);
     if (c.stream) (void)hipStreamDestroy(c.stream);
   }
+  if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
   delete m;
 }
 
@@ -1608,7 +1641,10 @@ int create(const ufd_config* cfg, ufd_model** out) {
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];
     HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIPB(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    // (3 compute streams + 1 copy stream = the runtime's 4 hardware queues: a copy stream per
+    // context made 6 streams share 4 queues, and the host-boundary rate fell to 0.69 of the staged one)
+    if (!m->copy_stream) HIPB(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    c.copy_stream = m->copy_stream;
   }
 
   // ---- weights + priors
@@ -1685,6 +1721,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
   // a JPEG is rarely larger than one byte per pixel; bigger frames take the host entropy path
   m->blob_stride = (((size_t)m->max_w * m->max_h) + 64 + 4095) & ~(size_t)4095;
   m->iv_cap = (uint32_t)B * 160;
+  m->scans_off = (sizeof(JpegFrameDesc) * B + 255) & ~(size_t)255;
+  m->ivs_off = (m->scans_off + sizeof(HuffScan) * B + 255) & ~(size_t)255;
+  m->stage_cap = ((m->ivs_off + sizeof(HuffInterval) * m->iv_cap + 255) & ~(size_t)255) + m->blob_stride * B;
   m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_HOST_ENTROPY) == 0;
   HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
@@ -1694,11 +1733,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
     HIPB(hipMalloc(&c.d_input, B * 3 * m->W * m->H * sizeof(float)));
     for (int i = 0; i < 2; i++) {
-      HIPB(hipMalloc(&c.d_descs_buf[i], sizeof(JpegFrameDesc) * B));
+      HIPB(hipMalloc(&c.d_stage_buf[i], m->stage_cap));
+      c.d_descs_buf[i] = reinterpret_cast<JpegFrameDesc*>(c.d_stage_buf[i]);
       HIPB(hipMalloc(&c.d_coef_buf[i], sizeof(int16_t) * m->coef_stride * B));
-      HIPB(hipMalloc(&c.d_blob_buf[i], m->blob_stride * B));
-      HIPB(hipMalloc(&c.d_scans_buf[i], sizeof(HuffScan) * B));
-      HIPB(hipMalloc(&c.d_ivs_buf[i], sizeof(HuffInterval) * m->iv_cap));
       HIPB(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
       HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
     }
@@ -1887,20 +1924,17 @@ int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t
     g->plan = p;
     g->h_descs.assign(tmp.h_descs, tmp.h_descs + count);
     g->st.assign(tmp.st.begin(), tmp.st.begin() + count);
-    const uint32_t n_iv = std::max(p.n_iv, 1u);
-    bool ok = hipMalloc(&g->d_blob, m->blob_stride * count) == hipSuccess &&
-              hipMalloc(&g->d_descs, sizeof(JpegFrameDesc) * count) == hipSuccess &&
-              hipMalloc(&g->d_scans, sizeof(HuffScan) * count) == hipSuccess &&
-              hipMalloc(&g->d_ivs, sizeof(HuffInterval) * n_iv) == hipSuccess;
-    ok = ok && hipMemcpy(g->d_blob, tmp.h_blob, m->blob_stride * count, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(g->d_descs, tmp.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(g->d_scans, tmp.h_scans, sizeof(HuffScan) * count, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(g->d_ivs, tmp.h_ivs, sizeof(HuffInterval) * p.n_iv, hipMemcpyHostToDevice) == hipSuccess;
+    bool ok = hipMalloc(&g->d_stage, p.stage_bytes) == hipSuccess &&
+              hipMemcpy(g->d_stage, tmp.h_stage, p.stage_bytes, hipMemcpyHostToDevice) == hipSuccess;
     release();
     if (!ok) {
-      (void)hipFree(g->d_blob), (void)hipFree(g->d_descs), (void)hipFree(g->d_scans), (void)hipFree(g->d_ivs);
+      (void)hipFree(g->d_stage);
       return m->fail(UFD_E_DEVICE, "staging a batch in device memory failed");
     }
+    g->d_descs = reinterpret_cast<JpegFrameDesc*>(g->d_stage);
+    g->d_scans = reinterpret_cast<HuffScan*>(g->d_stage + m->scans_off);
+    g->d_ivs = reinterpret_cast<HuffInterval*>(g->d_stage + m->ivs_off);
+    g->d_blob = g->d_stage + p.blob_base;
     *staged = g.release();
     return UFD_OK;
   });
@@ -1915,7 +1949,7 @@ int ufd_submit_staged(ufd_model* m, const ufd_staged* staged, ufd_det* out, uint
 void ufd_staged_free(ufd_model* m, ufd_staged* staged) {
   if (!staged) return;
   if (m) (void)hipSetDevice(m->cfg.device_id);
-  (void)hipFree(staged->d_blob), (void)hipFree(staged->d_descs), (void)hipFree(staged->d_scans), (void)hipFree(staged->d_ivs);
+  (void)hipFree(staged->d_stage);
   delete staged;
 }
 

@@ -138,3 +138,59 @@ int ufo_infer_jpeg(const uint8_t* jpeg, size_t len, int model_w, int model_h, co
   free(rgb);
   return rc;
 }
+
+/* ---- bench.py's cpu_baseline leg: the same per-frame path on `threads` host threads (frames are
+ * independent, SURVEY 8d "(b) one worker per core").  Each worker takes the next frame index from
+ * a shared counter and runs ufo_infer_jpeg on it; returns frames done, *dets_total = detections. */
+#include <pthread.h>
+#include <stdatomic.h>
+
+typedef struct {
+  const uint8_t* const* jpegs;
+  const size_t* lens;
+  int n_frames, total;
+  int model_w, model_h;
+  const float *weights, *priors;
+  float min_confidence, max_iou;
+  int cap;
+  atomic_int next, done;
+  atomic_long dets;
+} ufo_mt_job;
+
+static void* ufo_mt_worker(void* p) {
+  ufo_mt_job* j = (ufo_mt_job*)p;
+  ufo_det* out = (ufo_det*)malloc(sizeof(ufo_det) * (size_t)j->cap);
+  if (!out) return NULL;
+  for (;;) {
+    int i = atomic_fetch_add(&j->next, 1);
+    if (i >= j->total) break;
+    int f = i % j->n_frames;
+    int n = ufo_infer_jpeg(j->jpegs[f], j->lens[f], j->model_w, j->model_h, j->weights, j->priors, j->min_confidence,
+                           j->max_iou, out, j->cap);
+    if (n >= 0) {
+      atomic_fetch_add(&j->dets, n);
+      atomic_fetch_add(&j->done, 1);
+    }
+  }
+  free(out);
+  return NULL;
+}
+
+int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_frames, int total, int threads, int model_w,
+                      int model_h, const float* weights, const float* priors, float min_confidence, float max_iou, int cap,
+                      long* dets_total) {
+  if (n_frames < 1 || total < 1 || threads < 1 || threads > 1024) return UFO_E_ARG;
+  ufo_mt_job j;
+  j.jpegs = jpegs, j.lens = lens, j.n_frames = n_frames, j.total = total, j.model_w = model_w, j.model_h = model_h;
+  j.weights = weights, j.priors = priors, j.min_confidence = min_confidence, j.max_iou = max_iou, j.cap = cap;
+  atomic_init(&j.next, 0);
+  atomic_init(&j.done, 0);
+  atomic_init(&j.dets, 0);
+  pthread_t th[1024];
+  int started = 0;
+  for (int t = 0; t < threads; t++)
+    if (pthread_create(&th[started], NULL, ufo_mt_worker, &j) == 0) started++;
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  if (dets_total) *dets_total = atomic_load(&j.dets);
+  return atomic_load(&j.done);
+}
