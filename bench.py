@@ -114,16 +114,40 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
         if el >= budget_s or n >= 4 * len(jpegs):
             break
     one = n / el
-    cores = os.cpu_count() or 1
-    # all cores: worker threads inside the C library, each running whole frames
-    total = max(2 * cores, int(one * budget_s * 0.6) * cores)
+    cores = usable_cpus()
+    # all cores: worker threads inside the C library, each running whole frames, for the same time budget
     t1 = time.perf_counter()
-    done, _ = oracle.infer_jpeg_many_threads(jpegs, total, cores, W, H, weights, priors, 0.5, 0.5)
+    done, _ = oracle.infer_jpeg_many_threads(jpegs, 1 << 30, cores, W, H, weights, priors, 0.5, 0.5, budget_s=budget_s)
     el_all = time.perf_counter() - t1
     return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el),
             "all_cores": {"value": round(done / el_all, 2), "unit": "frames/s", "cores": cores,
-                          "sample": "%d frames, one worker thread per hardware thread, %.1f s" % (done, el_all)}}
+                          "sample": "%d frames, one worker thread per usable hardware thread (affinity mask / cgroup quota; "
+                                    "the machine reports %d), %.1f s" % (done, os.cpu_count() or 1, el_all)}}
+
+
+def usable_cpus():
+    """Hardware threads this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box reports all 256 threads of the host but gives one GPU's job a share of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def kernel_source_sha():
@@ -171,7 +195,7 @@ def main():
     if args.input == "hbm" and not device_entropy:
         raise SystemExit("--input hbm needs the device entropy decoder")
     # host workers: this rank's share of the box (8 ranks must not oversubscribe it)
-    host_threads = args.host_threads or max(2, min(32, (os.cpu_count() or 8) // world))
+    host_threads = args.host_threads or max(2, min(32, usable_cpus() // world))
     model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights, priors=priors,
                               max_src=(SW, SH), host_threads=host_threads, profile=True, det_cap=256,
                               host_entropy=not device_entropy)
@@ -306,7 +330,7 @@ def main():
             model.wait(t, collect=False)
             arr = np.frombuffer(b.out, np.float32).reshape(b.count, model.det_cap, 5)
             got += [(arr[i, :min(b.cnt[i], model.det_cap)].copy(), int(b.cnt[i])) for i in range(b.count)]
-        with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        with ThreadPoolExecutor(min(32, usable_cpus())) as ex:
             refs = list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jpegs[:nver * B]))
         max_err, bad = 0.0, 0
         for (g, n), r in zip(got, refs):

@@ -1,3 +1,4 @@
+#define _POSIX_C_SOURCE 200809L /* clock_gettime: time budget of the all-cores baseline leg */
 /*
  * postproc_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see ufd_oracle.h) for rows A7-A10
  * and the run()/decode glue.  This part of the path is first-party reference code and is
@@ -141,14 +142,23 @@ int ufo_infer_jpeg(const uint8_t* jpeg, size_t len, int model_w, int model_h, co
 
 /* ---- bench.py's cpu_baseline leg: the same per-frame path on `threads` host threads (frames are
  * independent, SURVEY 8d "(b) one worker per core").  Each worker takes the next frame index from
- * a shared counter and runs ufo_infer_jpeg on it; returns frames done, *dets_total = detections. */
+ * a shared counter and runs ufo_infer_jpeg on it until `total` frames are taken or `budget_s` seconds
+ * have passed (a frame in progress is finished); returns frames done, *dets_total = detections. */
 #include <pthread.h>
 #include <stdatomic.h>
+#include <time.h>
+
+static double ufo_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 typedef struct {
   const uint8_t* const* jpegs;
   const size_t* lens;
   int n_frames, total;
+  double deadline; /* CLOCK_MONOTONIC seconds after which no new frame is started */
   int model_w, model_h;
   const float *weights, *priors;
   float min_confidence, max_iou;
@@ -163,7 +173,7 @@ static void* ufo_mt_worker(void* p) {
   if (!out) return NULL;
   for (;;) {
     int i = atomic_fetch_add(&j->next, 1);
-    if (i >= j->total) break;
+    if (i >= j->total || ufo_now() >= j->deadline) break;
     int f = i % j->n_frames;
     int n = ufo_infer_jpeg(j->jpegs[f], j->lens[f], j->model_w, j->model_h, j->weights, j->priors, j->min_confidence,
                            j->max_iou, out, j->cap);
@@ -176,11 +186,12 @@ static void* ufo_mt_worker(void* p) {
   return NULL;
 }
 
-int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_frames, int total, int threads, int model_w,
-                      int model_h, const float* weights, const float* priors, float min_confidence, float max_iou, int cap,
+int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_frames, int total, double budget_s, int threads,
+                      int model_w, int model_h, const float* weights, const float* priors, float min_confidence, float max_iou, int cap,
                       long* dets_total) {
   if (n_frames < 1 || total < 1 || threads < 1 || threads > 1024) return UFO_E_ARG;
   ufo_mt_job j;
+  j.deadline = ufo_now() + (budget_s > 0 ? budget_s : 1e9);
   j.jpegs = jpegs, j.lens = lens, j.n_frames = n_frames, j.total = total, j.model_w = model_w, j.model_h = model_h;
   j.weights = weights, j.priors = priors, j.min_confidence = min_confidence, j.max_iou = max_iou, j.cap = cap;
   atomic_init(&j.next, 0);

@@ -68,7 +68,7 @@ def lib():
         L.ufo_postproc.argtypes = [vp, vp, c_int, c_f, c_f, vp, c_int]
         L.ufo_infer_rgb.argtypes = [vp, c_int, c_int, c_int, c_int, vp, vp, c_f, c_f, vp, c_int]
         L.ufo_infer_jpeg.argtypes = [vp, sz, c_int, c_int, vp, vp, c_f, c_f, vp, c_int]
-        L.ufo_infer_jpeg_mt.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, c_f, c_f, c_int, vp]
+        L.ufo_infer_jpeg_mt.argtypes = [vp, vp, c_int, c_int, ctypes.c_double, c_int, c_int, c_int, vp, vp, c_f, c_f, c_int, vp]
         _lib = L
     return _lib
 
@@ -220,16 +220,17 @@ def infer_jpeg(data, model_w, model_h, weights, priors, min_confidence=0.5, max_
     return _dets(out, n)
 
 
-def infer_jpeg_many_threads(jpegs, total, threads, model_w, model_h, weights, priors, min_confidence=0.5, max_iou=0.5):
-    """bench.py's all-cores cpu_baseline leg: `total` frames (cycling over `jpegs`) on `threads` host
-    threads inside the C library; returns (frames done, detections found)."""
+def infer_jpeg_many_threads(jpegs, total, threads, model_w, model_h, weights, priors, min_confidence=0.5, max_iou=0.5,
+                            budget_s=0.0):
+    """bench.py's all-cores cpu_baseline leg: up to `total` frames (cycling over `jpegs`) on `threads` host
+    threads inside the C library, no frame started after `budget_s` seconds; returns (frames done, detections found)."""
     weights = np.ascontiguousarray(weights, np.float32)
     priors = np.ascontiguousarray(priors, np.float32)
     bufs = [_buf(j) for j in jpegs]
     ptrs = (ctypes.c_void_p * len(bufs))(*[ctypes.addressof(b) for b in bufs])
     lens = (ctypes.c_size_t * len(bufs))(*[len(j) for j in jpegs])
     dets = ctypes.c_long()
-    n = _chk(lib().ufo_infer_jpeg_mt(ptrs, lens, len(bufs), int(total), int(threads), model_w, model_h, weights.ctypes.data,
+    n = _chk(lib().ufo_infer_jpeg_mt(ptrs, lens, len(bufs), int(total), float(budget_s), int(threads), model_w, model_h, weights.ctypes.data,
                                      priors.ctypes.data, min_confidence, max_iou, priors.shape[0], ctypes.byref(dets)),
              "infer_jpeg_mt")
     return n, dets.value

@@ -104,10 +104,11 @@ int ufo_infer_rgb(const uint8_t* rgb, int w, int h, int model_w, int model_h, co
 /* Inferer::run steps inferer.rs:35-37: decompress_image -> infer_faces */
 int ufo_infer_jpeg(const uint8_t* jpeg, size_t len, int model_w, int model_h, const float* weights,
                    const float* priors, float min_confidence, float max_iou, ufo_det* out, int cap);
-/* bench.py cpu_baseline, all-cores leg: `total` frames (cycling over the n_frames given) on `threads`
- * host threads, each running ufo_infer_jpeg; returns the number of frames done. */
-int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_frames, int total, int threads, int model_w,
-                      int model_h, const float* weights, const float* priors, float min_confidence, float max_iou, int cap,
+/* bench.py cpu_baseline, all-cores leg: up to `total` frames (cycling over the n_frames given) on `threads`
+ * host threads, each running ufo_infer_jpeg, no frame started after `budget_s` seconds (<= 0: no limit);
+ * returns the number of frames done. */
+int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_frames, int total, double budget_s, int threads,
+                      int model_w, int model_h, const float* weights, const float* priors, float min_confidence, float max_iou, int cap,
                       long* dets_total);
 
 #ifdef __cplusplus
