@@ -37,6 +37,7 @@ def build(force=False):
     return _LIB_PATH
 
 
+sz_t = ctypes.c_size_t
 _lib = None
 
 
@@ -69,6 +70,20 @@ def lib():
         L.ufo_infer_rgb.argtypes = [vp, c_int, c_int, c_int, c_int, vp, vp, c_f, c_f, vp, c_int]
         L.ufo_infer_jpeg.argtypes = [vp, sz, c_int, c_int, vp, vp, c_f, c_f, vp, c_int]
         L.ufo_infer_jpeg_mt.argtypes = [vp, vp, c_int, c_int, ctypes.c_double, c_int, c_int, c_int, vp, vp, c_f, c_f, c_int, vp]
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        L.ufo_rect_of_det.argtypes = [vp, c_f, c_f, i64p, i64p, i64p, i64p]
+        L.ufo_draw_hollow_rects.argtypes = [vp, c_int, c_int, vp, c_int, c_f, c_f]
+        L.ufo_draw_hollow_rects.restype = None
+        L.ufo_jpeg_quant_table.argtypes = [c_int, c_int, vp]
+        L.ufo_jpeg_quant_table.restype = None
+        L.ufo_jpeg_encode_bound.argtypes = [c_int, c_int]
+        L.ufo_jpeg_encode_bound.restype = sz
+        L.ufo_jpeg_encode_rgb.argtypes = [vp, c_int, c_int, c_int, c_int, vp, sz, ctypes.POINTER(sz)]
+        L.ufo_jpeg_encode_coefficients.argtypes = [vp, c_int, c_int, c_int, c_int, vp]
+        L.ufo_stream_item.argtypes = [vp, sz, vp, sz]
+        L.ufo_stream_item.restype = sz
+        L.ufo_annotate_encode_jpeg.argtypes = [vp, sz, c_int, c_int, vp, vp, c_f, c_f, c_f, c_f, c_int, vp, c_int, vp, sz,
+                                               ctypes.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -234,3 +249,80 @@ def infer_jpeg_many_threads(jpegs, total, threads, model_w, model_h, weights, pr
                                      priors.ctypes.data, min_confidence, max_iou, priors.shape[0], ctypes.byref(dets)),
              "infer_jpeg_mt")
     return n, dets.value
+
+
+# ---- N1: rectangles + JPEG re-encode (inferer.rs:38-40), multipart framing (lib.rs:48-57)
+def _det_array(dets):
+    dets = np.asarray(dets, np.float32).reshape(-1, 5)
+    arr = (Det * max(len(dets), 1))()
+    for i, d in enumerate(dets):
+        arr[i].x_tl, arr[i].y_tl, arr[i].x_br, arr[i].y_br, arr[i].conf = (float(v) for v in d)
+    return arr, len(dets)
+
+
+def rect_of_det(det, label_w, label_h):
+    """inferer.rs:66-76: inclusive pixel rectangle (left, top, right, bottom) of one detection, or None when
+    Rect::of_size would assert."""
+    arr, _ = _det_array([det])
+    v = [ctypes.c_int64() for _ in range(4)]
+    ok = lib().ufo_rect_of_det(arr, label_w, label_h, *[ctypes.byref(x) for x in v])
+    return tuple(x.value for x in v) if ok else None
+
+
+def draw_hollow_rects(rgb, dets, label_w, label_h):
+    """draw_bboxes_on_image without the text; returns a new HxWx3 array."""
+    out = np.ascontiguousarray(rgb, np.uint8).copy()
+    arr, n = _det_array(dets)
+    lib().ufo_draw_hollow_rects(out.ctypes.data, out.shape[1], out.shape[0], arr, n, label_w, label_h)
+    return out
+
+
+def quant_table(quality, chroma):
+    out = np.empty(64, np.uint8)
+    lib().ufo_jpeg_quant_table(quality, int(chroma), out.ctypes.data)
+    return out
+
+
+def jpeg_encode_rgb(rgb, quality=95, dct=-1):
+    """turbojpeg::compress_image(&frame, quality, Sub2x2): dct 0 ISLOW, 1 IFAST, -1 tjCompress2's choice."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    cap = lib().ufo_jpeg_encode_bound(w, h)
+    out = np.empty(cap, np.uint8)
+    n = sz_t()
+    _chk(lib().ufo_jpeg_encode_rgb(rgb.ctypes.data, w, h, quality, dct, out.ctypes.data, cap, ctypes.byref(n)), "jpeg_encode")
+    return out[:n.value].tobytes()
+
+
+def jpeg_encode_coefficients(rgb, quality=95, dct=-1):
+    """Quantised coefficients [mcus][6][64] (natural order) of that stream."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    if dct < 0:
+        dct = 0 if quality >= 96 else 1
+    out = np.empty((((w + 15) // 16) * ((h + 15) // 16), 6, 64), np.int16)
+    _chk(lib().ufo_jpeg_encode_coefficients(rgb.ctypes.data, w, h, quality, dct, out.ctypes.data), "jpeg_encode_coefficients")
+    return out
+
+
+def stream_item(jpeg):
+    n = lib().ufo_stream_item(_buf(jpeg), len(jpeg), None, 0)
+    out = ctypes.create_string_buffer(n)
+    lib().ufo_stream_item(_buf(jpeg), len(jpeg), out, n)
+    return out.raw
+
+
+def annotate_encode_jpeg(data, model_w, model_h, weights, priors, label_w, label_h, min_confidence=0.5, max_iou=0.5, quality=95):
+    """Inferer::run, inferer.rs:35-40 (no text): returns (detections [n,5], annotated JPEG bytes)."""
+    weights = np.ascontiguousarray(weights, np.float32)
+    priors = np.ascontiguousarray(priors, np.float32)
+    info = jpeg_probe(data)
+    K = priors.shape[0]
+    dets = (Det * K)()
+    cap = lib().ufo_jpeg_encode_bound(info.width, info.height)
+    out = np.empty(cap, np.uint8)
+    n_out = sz_t()
+    n = _chk(lib().ufo_annotate_encode_jpeg(_buf(data), len(data), model_w, model_h, weights.ctypes.data, priors.ctypes.data,
+                                            min_confidence, max_iou, label_w, label_h, quality, dets, K, out.ctypes.data, cap,
+                                            ctypes.byref(n_out)), "annotate_encode_jpeg")
+    return _dets(dets, n), out[:n_out.value].tobytes()
