@@ -140,7 +140,51 @@ int ufd_submit_staged(ufd_model* m, const ufd_staged* staged, ufd_det* out, uint
                       uint32_t* ticket);
 void ufd_staged_free(ufd_model* m, ufd_staged* staged);
 
+/* ---- N1: the rest of the Inferer::run iteration (inferer.rs:38-46) on the frame that is already decoded in HBM ----
+ * draw_bboxes_on_image(image, boxes, width, height) (inferer.rs:58-92): one hollow rectangle per detection at
+ * bbox * (label_width, label_height) with the reference's `as i32` / `as u32` casts, colour (0, 255, 0), clipped
+ * to the decoded frame.  NOTE: label_width / label_height are the slot's StaticImage.0 / .1, which the router stamps
+ * with 1280 x 720 whatever the JPEG's own size is (router.rs:66-67).  A rectangle narrower or lower than one pixel
+ * (imageproc's Rect::of_size would assert and the reference task panic) is skipped.  The confidence text
+ * (draw_text, inferer.rs:80-88) is NOT drawn: rusttype glyph rasterisation is deferred.
+ * turbojpeg::compress_image(&frame, quality, Subsamp::Sub2x2) (inferer.rs:39, quality 95): baseline 4:2:0 stream
+ * byte-identical to libjpeg-turbo's (fast integer DCT below quality 96 as tjCompress2 selects, accurate from 96).
+ * UFD_ANNOT_MULTIPART wraps every stream as as_jpeg_stream_item does (lib.rs:48-57).
+ *
+ * The streams of a batch are written back to back into jpeg_out (each starts on a 16-byte boundary):
+ * frame i = jpeg_out[jpeg_off[i] .. jpeg_off[i] + jpeg_len[i]); a frame that failed to decode has length 0; a frame
+ * whose stream does not fit in jpeg_cap gets status UFD_E_TRUNCATED (its detections are still valid) and length 0.
+ * ufd_encode_bound(w, h) bytes per frame always suffice.  Detections, n[] and status[] as ufd_submit_jpeg_batch. */
+#define UFD_ANNOT_MULTIPART 1u
+typedef struct ufd_annotate {
+  uint32_t struct_size;   /* = sizeof(ufd_annotate) */
+  float label_width;      /* inferer.rs:32-33: recv_ref.0 / .1 (1280 / 720 in the reference's router) */
+  float label_height;
+  uint32_t quality;       /* inferer.rs:39 passes 95 */
+  uint32_t flags;         /* UFD_ANNOT_* */
+  uint8_t* jpeg_out;      /* output for the whole batch; pinned memory (ufd_host_alloc) avoids a staging copy */
+  size_t jpeg_cap;
+  size_t* jpeg_off;       /* [count] */
+  size_t* jpeg_len;       /* [count] */
+} ufd_annotate;
+int ufd_submit_annotate_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                              const ufd_annotate* annot, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status,
+                              uint32_t* ticket);
+/* submit + wait */
+int ufd_annotate_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                            const ufd_annotate* annot, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status);
+/* Worst-case bytes of one finished stream of a w x h frame (header, byte stuffing and framing included). */
+size_t ufd_encode_bound(uint32_t w, uint32_t h);
+/* Page-locked host memory for jpeg_out (and for input rings): the D2H copy then runs at PCIe speed. */
+void* ufd_host_alloc(size_t bytes);
+void ufd_host_free(void* p);
+
 /* ---- stage taps (parity tests call the path stage by stage through these) ---- */
+/* N1 stages alone: the rectangles of `n` detections on an RGB8 frame (in place), and the encoder on an RGB8 frame. */
+int ufd_debug_draw_rects(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
+                         float label_width, float label_height);
+int ufd_debug_encode_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t quality,
+                         uint32_t flags, uint8_t* out, size_t cap, size_t* len);
 /* A1 only: decode on the GPU and copy the interleaved RGB8 frame back (cap_bytes >= h*w*3). */
 int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes,
                           uint32_t* w, uint32_t* h);

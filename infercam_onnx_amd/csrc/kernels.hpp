@@ -209,4 +209,49 @@ void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32
                      unsigned long long* d_mat, uint32_t B, hipStream_t s);
 size_t nms_matrix_bytes(uint32_t B);
 
+// ---------------- N1: rectangles + JPEG re-encode (encode_kernels.hip, encode_host.cpp) ----------------
+// inferer.rs:38-40 on frames resident in HBM as tight RGB8 (pitch 3 * width, frame stride rgb_stride).  Frames whose
+// descriptor has width 0 (failed decode) are skipped: their output length is 0.
+#define UFD_ENC_MAX_FRAMES 1024
+// jcdctmgr.c reciprocal quantisation of table t (0 luma, 1 chroma), natural order:
+// q = ((|v| + corr) * recip) >> shift, sign restored.
+struct EncQuant {
+  uint16_t recip[2][64], corr[2][64];
+  uint8_t shift[2][64];
+};
+// Device working set of the encoder for one batch (one per context, allocated on first use).
+struct EncBuffers {
+  int16_t* coef = nullptr;       // [frame][mcu][Y00 Y01 Y10 Y11 Cb Cr][64] quantised, zigzag order
+  size_t coef_stride = 0;        // int16 per frame
+  uint32_t* bits = nullptr;      // [frame][block] code length, then (in place) bit offset
+  size_t blk_stride = 0;
+  uint32_t* total_bits = nullptr;  // [frame]
+  uint32_t* words = nullptr;     // [frame] bit stream before byte stuffing, 32-bit words MSB first
+  size_t word_stride = 0;
+  uint32_t* chunk_ff = nullptr;  // [frame][4 KiB chunk] 0xFF bytes
+  size_t chunk_stride = 0;
+  const uint32_t* tables = nullptr;  // [2][272] (size << 16) | code: 16 DC + 256 AC entries, luma / chroma
+  const uint8_t* header = nullptr;   // [framing prefix][SOI .. SOS][framing suffix]
+  uint32_t pre_len = 0, hdr_len = 0, dim_off = 0, post_len = 0;  // dim_off: offset of SOF0's height field in the header
+  uint32_t* out_len = nullptr;   // [frame] bytes of the finished stream (0: skipped)
+  uint32_t* out_off = nullptr;   // [frame] offset in `out` (16-byte aligned)
+  uint32_t* out_total = nullptr; // [1] bytes used in `out`
+  uint8_t* out = nullptr;        // finished streams, packed
+};
+using EncStageHook = std::function<void(const char* stage, bool begin)>;
+void launch_draw_rects(const JpegFrameDesc* d_descs, const Det* d_dets, uint32_t det_stride, const uint32_t* d_ndet, uint8_t* d_rgb,
+                       size_t rgb_stride, float label_w, float label_h, uint32_t count, hipStream_t s);
+void launch_jpeg_encode(const JpegFrameDesc* d_descs, const uint8_t* d_rgb, size_t rgb_stride, uint32_t max_w, uint32_t max_h,
+                        uint32_t count, const EncQuant& q, bool ifast, const EncBuffers& e, hipStream_t s,
+                        const EncStageHook* hook = nullptr);
+// host side (encode_host.cpp): tables of jpeg_set_quality(quality, TRUE), their reciprocal form, the Annex-K code
+// tables in the kernels' layout and the marker segments SOI .. SOS (+ optional multipart framing, lib.rs:48-57).
+void enc_quant_tables(int quality, uint8_t luma[64], uint8_t chroma[64]);
+void enc_make_quant(const uint8_t luma[64], const uint8_t chroma[64], bool ifast, EncQuant* out);
+void enc_make_code_tables(uint32_t out[2 * 272]);
+size_t enc_make_header(const uint8_t luma[64], const uint8_t chroma[64], bool multipart, uint8_t* out /*>= 768*/, uint32_t* pre_len,
+                       uint32_t* hdr_len, uint32_t* dim_off, uint32_t* post_len);
+// worst-case sizes for a frame of mcus 16x16 MCUs: entropy-coded bytes before stuffing (26 bits per coefficient)
+inline size_t enc_stream_bound(size_t mcus) { return mcus * 6 * 64 * 26 / 8 + 64; }
+
 }  // namespace ufd

@@ -118,6 +118,16 @@ struct Slot {
   const size_t* job_lens = nullptr;
   const ufd_staged* job_staged = nullptr;  // non-null: the batch is resident in HBM
   bool job_prof = true;
+  // N1 (ufd_submit_annotate_batch): rectangles + re-encode after NMS.  The finished streams of the batch land in the
+  // slot's own device buffer (it stays valid until the slot is released: the host fetches them in ufd_wait, when
+  // their total size is known) -- the encoder's scratch belongs to the context.
+  bool annot = false, annot_ran = false;
+  ufd_annotate annot_args{};
+  uint8_t* d_enc_out = nullptr;
+  size_t enc_out_cap = 0;
+  uint32_t* d_enc_meta = nullptr;  // [B] length, [B] offset, [1] total
+  uint32_t* h_enc_meta = nullptr;  // pinned copy
+  hipEvent_t enc_copied = nullptr;
   int issue_rc = 0;          // result of the worker's entropy stage + enqueue
   std::string issue_err;
   int state = 0;             // 0 free, 1 queued for the worker, 2 issued to the GPU (guarded by Worker::mu)
@@ -163,6 +173,14 @@ struct Ctx {
   float4* d_spill = nullptr;
   unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
   uint32_t last_forward_count = 0;
+  // N1 encoder scratch (allocated by the first annotate batch on this context) and the quality it is set up for
+  EncBuffers enc;
+  EncQuant enc_q{};
+  bool enc_ready = false, enc_ifast = true;
+  int enc_quality = -1, enc_multipart = -1;
+  uint32_t* d_enc_tables = nullptr;
+  uint8_t* d_enc_header = nullptr;
+  JpegFrameDesc* d_enc_descs = nullptr;  // descriptors of frames that did not come out of the decoder (debug taps)
 };
 constexpr int kMaxCtx = 8;
 
@@ -1037,6 +1055,38 @@ int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   return UFD_OK;
 }
 
+// N1: the finished streams of the slot's batch -> the caller's buffer.  Their sizes are known only now, so this is the
+// second half of a two-step copy: one D2H of everything that fits, on the handle's copy stream.
+int fetch_streams(ufd_model* m, Slot& s) {
+  const ufd_annotate& a = s.annot_args;
+  for (uint32_t i = 0; i < s.count; i++) a.jpeg_off[i] = 0, a.jpeg_len[i] = 0;
+  if (!s.annot_ran) return UFD_OK;  // nothing decoded
+  const uint32_t* len = s.h_enc_meta;
+  const uint32_t* off = s.h_enc_meta + m->B;
+  size_t fit = 0;  // bytes of the packed output that hold whole streams and fit the caller's buffer
+  int rc = UFD_OK;
+  for (uint32_t i = 0; i < s.count; i++) {
+    const bool failed = (s.status ? s.status[i] : UFD_OK) != UFD_OK && (s.status ? s.status[i] : UFD_OK) != UFD_E_TRUNCATED;
+    if (failed || !len[i]) continue;
+    if ((size_t)off[i] + len[i] > a.jpeg_cap) {
+      if (s.status && s.status[i] == UFD_OK) s.status[i] = UFD_E_TRUNCATED;
+      if (!s.status && rc == UFD_OK) rc = UFD_E_TRUNCATED;
+      continue;
+    }
+    a.jpeg_off[i] = off[i], a.jpeg_len[i] = len[i];
+    fit = std::max(fit, (size_t)off[i] + len[i]);
+  }
+  if (fit) {
+    {
+      std::lock_guard<std::mutex> lk(m->copy_mu);
+      HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, m->copy_stream));
+      HIPC(m, hipEventRecord(s.enc_copied, m->copy_stream));
+    }
+    HIPC(m, hipEventSynchronize(s.enc_copied));
+  }
+  return rc;
+}
+
 // waits for the slot's batch and hands results to the caller's arrays
 int finish_slot(ufd_model* m, Slot& s) {
   if (s.issue_rc != UFD_OK) {  // the worker could not issue the batch
@@ -1076,6 +1126,10 @@ int finish_slot(ufd_model* m, Slot& s) {
     if (s.status) s.status[i] = st;
     if (st != UFD_OK && rc == UFD_OK && !s.status) rc = st;
   }
+  if (s.annot) {
+    const int arc = fetch_streams(m, s);
+    if (arc != UFD_OK && rc == UFD_OK) rc = arc;
+  }
   s.busy = false;
   return rc;
 }
@@ -1087,6 +1141,7 @@ Slot* find_free_slot(ufd_model* m) {
       s.issue_rc = UFD_OK;
       s.issue_err.clear();
       s.job_jpegs = nullptr, s.job_lens = nullptr, s.job_staged = nullptr;
+      s.annot = false, s.annot_ran = false;
       s.state = 0;
       return &s;
     }
@@ -1295,6 +1350,92 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   return UFD_OK;
 }
 
+// ---------------------------------------------------------------- N1: rectangles + JPEG re-encode (inferer.rs:38-40)
+size_t enc_frame_bound(uint32_t w, uint32_t h) {
+  const size_t mcus = (size_t)((w + 15) / 16) * ((h + 15) / 16);
+  return 2 * enc_stream_bound(mcus) + 1024;  // every entropy-coded byte stuffed + header, EOI, framing
+}
+
+// Encoder scratch of a context (first annotate batch) and the tables of the requested quality.
+int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart) {
+  if (quality < 1 || quality > 100) return m->fail(UFD_E_ARG, "quality must be in 1..100");
+  EncBuffers& e = c.enc;
+  if (!c.enc_ready) {
+    const size_t mcus = (size_t)((m->max_w + 15) / 16) * ((m->max_h + 15) / 16);
+    const size_t sb = enc_stream_bound(mcus);
+    e.coef_stride = mcus * 6 * 64;
+    e.blk_stride = mcus * 6;
+    e.word_stride = (((sb + 3) / 4 + 3) & ~(size_t)3) + 8;  // whole 16-byte groups + the padding the scan zeroes
+    e.chunk_stride = (sb + 4095) / 4096 + 1;
+    HIPC(m, hipMalloc(&e.coef, sizeof(int16_t) * e.coef_stride * m->B));
+    HIPC(m, hipMalloc(&e.bits, sizeof(uint32_t) * e.blk_stride * m->B));
+    HIPC(m, hipMalloc(&e.total_bits, sizeof(uint32_t) * m->B));
+    HIPC(m, hipMalloc(&e.words, sizeof(uint32_t) * e.word_stride * m->B));
+    HIPC(m, hipMalloc(&e.chunk_ff, sizeof(uint32_t) * e.chunk_stride * m->B));
+    HIPC(m, hipMalloc(&c.d_enc_tables, sizeof(uint32_t) * 2 * 272));
+    HIPC(m, hipMalloc(&c.d_enc_header, 1024));
+    HIPC(m, hipMalloc(&c.d_enc_descs, sizeof(JpegFrameDesc) * m->B));
+    uint32_t tabs[2 * 272];
+    enc_make_code_tables(tabs);
+    HIPC(m, hipMemcpy(c.d_enc_tables, tabs, sizeof(tabs), hipMemcpyHostToDevice));
+    e.tables = c.d_enc_tables;
+    e.header = c.d_enc_header;
+    c.enc_ready = true;
+  }
+  if (c.enc_quality != (int)quality || c.enc_multipart != (int)multipart) {
+    uint8_t ql[64], qc[64], hdr[1024];
+    enc_quant_tables((int)quality, ql, qc);
+    c.enc_ifast = quality < 96;  // turbojpeg.c setCompDefaults: JDCT_ISLOW from quality 96 on, JDCT_FASTEST below
+    enc_make_quant(ql, qc, c.enc_ifast, &c.enc_q);
+    const size_t n = enc_make_header(ql, qc, multipart, hdr, &e.pre_len, &e.hdr_len, &e.dim_off, &e.post_len);
+    // earlier encodes of this context still read the old header: order the update behind them
+    HIPC(m, hipStreamSynchronize(c.stream));
+    HIPC(m, hipMemcpy(c.d_enc_header, hdr, n, hipMemcpyHostToDevice));
+    c.enc_quality = (int)quality, c.enc_multipart = (int)multipart;
+  }
+  return UFD_OK;
+}
+
+int ensure_slot_encoder(ufd_model* m, Slot& s) {
+  if (s.d_enc_out) return UFD_OK;
+  s.enc_out_cap = enc_frame_bound(m->max_w, m->max_h) * m->B;
+  HIPC(m, hipMalloc(&s.d_enc_out, s.enc_out_cap));
+  HIPC(m, hipMalloc(&s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1)));
+  HIPC(m, hipHostMalloc(&s.h_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipHostMallocDefault));
+  HIPC(m, hipEventCreateWithFlags(&s.enc_copied, hipEventDisableTiming));
+  return UFD_OK;
+}
+
+// Rectangles of the slot's detections into the context's RGB frames, then the encoder; lengths / offsets of the
+// finished streams follow the detections to the host.  On the context's stream, behind the NMS.
+int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count) {
+  Ctx& c = *tl_cur;
+  int rc = ensure_encoder(m, c, s.annot_args.quality, (s.annot_args.flags & UFD_ANNOT_MULTIPART) != 0);
+  if (rc) return rc;
+  rc = ensure_slot_encoder(m, s);
+  if (rc) return rc;
+  {
+    ProfScope ps(m, "draw_rects", 0, 0);
+    launch_draw_rects(d_descs, s.d_dets, (uint32_t)m->K, c.d_ndet, c.d_rgb, m->rgb_stride, s.annot_args.label_width,
+                      s.annot_args.label_height, count, c.stream);
+  }
+  EncBuffers e = c.enc;
+  e.out = s.d_enc_out;
+  e.out_len = s.d_enc_meta, e.out_off = s.d_enc_meta + m->B, e.out_total = s.d_enc_meta + 2 * m->B;
+  {
+    std::unique_ptr<ProfScope> scope;
+    const double bytes = (double)count * mw * mh * 3.0;
+    const EncStageHook hook = [&](const char* stage, bool begin) {
+      if (begin) scope.reset(new ProfScope(m, stage, bytes, 0));
+      else scope.reset();
+    };
+    launch_jpeg_encode(d_descs, c.d_rgb, m->rgb_stride, mw, mh, count, c.enc_q, c.enc_ifast, e, c.stream, &hook);
+  }
+  HIPC(m, hipMemcpyAsync(s.h_enc_meta, s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, c.stream));
+  s.annot_ran = true;
+  return UFD_OK;
+}
+
 int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFrameDesc* d_descs, int16_t* d_coef, int buf);
 
 int submit_jpegs(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
@@ -1351,6 +1492,10 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
     {
       ProfScope ps(m, "idct", 0, 0);
       launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream);
+    }
+    if (all_model_size && s.annot) {  // N1 encodes the decoded frame: the RGB image the fused paths never make
+      ProfScope ps(m, "upsample_rgb", 0, 0);
+      launch_upsample_rgb(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
     }
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
@@ -1426,6 +1571,13 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
     }
     enqueue_heads(m, count);
     enqueue_nms(m, s, count);
+    if (s.annot) {
+      rc = enqueue_annotate(m, s, d_descs, mw, mh, count);
+      if (rc) return rc;
+      // the encoder was the last reader of this buffer's descriptors
+      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
+      tl_cur->consumed_valid[buf] = true;
+    }
   }
   return enqueue_results_copy(m, s, count);
 }
@@ -1555,6 +1707,8 @@ void destroy(ufd_model* m) {
     dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_ndet);
     dfree(c.d_spill);
     dfree(c.d_nms_mat);
+    dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
+    dfree(c.d_enc_tables), dfree(c.d_enc_header), dfree(c.d_enc_descs);
   }
   for (float* t : m->tap_buf) dfree(t);
   for (auto& kv : m->taps)
@@ -1567,6 +1721,10 @@ void destroy(ufd_model* m) {
     if (s.h_ndet) (void)hipHostFree(s.h_ndet);
     if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.d_enc_out) (void)hipFree(s.d_enc_out);
+    if (s.d_enc_meta) (void)hipFree(s.d_enc_meta);
+    if (s.h_enc_meta) (void)hipHostFree(s.h_enc_meta);
+    if (s.enc_copied) (void)hipEventDestroy(s.enc_copied);
   }
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
@@ -1861,10 +2019,17 @@ int ufd_infer_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint
 }
 
 static int submit_common(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, const ufd_staged* staged, uint32_t count,
-                         ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
+                         ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket,
+                         const ufd_annotate* annot = nullptr) {
   return guarded(m, [&]() -> int {
     int rc = check_outputs(m, out, cap, n);
     if (rc) return rc;
+    if (annot) {
+      if (annot->struct_size != sizeof(ufd_annotate)) return m->fail(UFD_E_ARG, "ufd_annotate.struct_size mismatch");
+      if ((!annot->jpeg_out && annot->jpeg_cap) || !annot->jpeg_off || !annot->jpeg_len)
+        return m->fail(UFD_E_ARG, "null annotate output pointer");
+      if (annot->quality < 1 || annot->quality > 100) return m->fail(UFD_E_ARG, "quality must be in 1..100");
+    }
     if ((!staged && (!jpegs || !lens)) || !ticket) return m->fail(UFD_E_ARG, "null argument");
     if (count < 1 || count > m->B) return m->fail(UFD_E_TOO_LARGE, "count must be in 1..max_batch");
     Slot* s = find_free_slot(m);
@@ -1880,6 +2045,8 @@ static int submit_common(ufd_model* m, const uint8_t* const* jpegs, const size_t
     s->job_jpegs = jpegs, s->job_lens = lens, s->job_staged = staged;
     s->job_prof = (m->prof_batch++ % m->prof_every) == 0;
     s->issue_rc = UFD_OK;
+    s->annot = annot != nullptr, s->annot_ran = false;
+    if (annot) s->annot_args = *annot;
     s->ctx = w.ctx;
     s->busy = true;
     s->ticket = m->next_ticket++;
@@ -1898,6 +2065,38 @@ static int submit_common(ufd_model* m, const uint8_t* const* jpegs, const size_t
 int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_det* out,
                           uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket) {
   return submit_common(m, jpegs, lens, nullptr, count, out, cap, n, status, ticket);
+}
+
+int ufd_submit_annotate_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                              const ufd_annotate* annot, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status,
+                              uint32_t* ticket) {
+  if (m && !annot) return m->fail(UFD_E_ARG, "null ufd_annotate");
+  return submit_common(m, jpegs, lens, nullptr, count, out, cap, n, status, ticket, annot);
+}
+
+int ufd_annotate_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
+                            const ufd_annotate* annot, ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status) {
+  if (m && count == 0) return UFD_OK;
+  uint32_t ticket = 0;
+  std::vector<int32_t> local;
+  if (!status) {
+    local.resize(count ? count : 1);
+    status = local.data();
+  }
+  int rc = ufd_submit_annotate_batch(m, jpegs, lens, count, annot, out, cap, n, status, &ticket);
+  if (rc) return rc;
+  return ufd_wait(m, ticket);
+}
+
+size_t ufd_encode_bound(uint32_t w, uint32_t h) { return enc_frame_bound(w, h) + 64; }
+
+void* ufd_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void ufd_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_staged** staged) {
@@ -2017,6 +2216,70 @@ int ufd_infer_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, ufd_det* out, 
 }
 
 // ---------------------------------------------------------------- stage taps
+// N1 stages on a caller-provided RGB frame (context 0, synchronous)
+static int upload_plain_frame(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch) {
+  int rc = upload_rgb(m, rgb, w, h, pitch, 1);
+  if (rc) return rc;
+  JpegFrameDesc d;
+  std::memset(&d, 0, sizeof(d));
+  d.width = (int32_t)w, d.height = (int32_t)h;
+  HIPC(m, hipMemcpyAsync(tl_cur->d_enc_descs, &d, sizeof(d), hipMemcpyHostToDevice, tl_cur->stream));
+  return UFD_OK;
+}
+
+int ufd_debug_draw_rects(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
+                         float label_width, float label_height) {
+  return guarded(m, [&]() -> int {
+    drain_worker0(m);
+    if (!rgb || (!dets && n)) return m->fail(UFD_E_ARG, "null argument");
+    if (n > (uint32_t)m->K) return m->fail(UFD_E_TOO_LARGE, "more detections than priors");
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy");
+    int rc = alloc_slot(m, *s);
+    if (rc) return rc;
+    rc = ensure_encoder(m, *tl_cur, 95, false);
+    if (rc) return rc;
+    rc = upload_plain_frame(m, rgb, w, h, pitch);
+    if (rc) return rc;
+    if (n) HIPC(m, hipMemcpyAsync(s->d_dets, dets, sizeof(Det) * n, hipMemcpyHostToDevice, tl_cur->stream));
+    HIPC(m, hipMemcpyAsync(tl_cur->d_ndet, &n, sizeof(uint32_t), hipMemcpyHostToDevice, tl_cur->stream));
+    launch_draw_rects(tl_cur->d_enc_descs, s->d_dets, (uint32_t)m->K, tl_cur->d_ndet, tl_cur->d_rgb, m->rgb_stride, label_width,
+                      label_height, 1, tl_cur->stream);
+    HIPC(m, hipMemcpy2DAsync(rgb, pitch, tl_cur->d_rgb, (size_t)w * 3, (size_t)w * 3, h, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
+    return UFD_OK;
+  });
+}
+
+int ufd_debug_encode_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t quality,
+                         uint32_t flags, uint8_t* out, size_t cap, size_t* len) {
+  return guarded(m, [&]() -> int {
+    drain_worker0(m);
+    if (!rgb || !out || !len) return m->fail(UFD_E_ARG, "null argument");
+    Slot* s = find_free_slot(m);
+    if (!s) return m->fail(UFD_E_STATE, "all slots busy");
+    int rc = alloc_slot(m, *s);
+    if (rc) return rc;
+    rc = ensure_encoder(m, *tl_cur, quality, (flags & UFD_ANNOT_MULTIPART) != 0);
+    if (rc) return rc;
+    rc = ensure_slot_encoder(m, *s);
+    if (rc) return rc;
+    rc = upload_plain_frame(m, rgb, w, h, pitch);
+    if (rc) return rc;
+    EncBuffers e = tl_cur->enc;
+    e.out = s->d_enc_out;
+    e.out_len = s->d_enc_meta, e.out_off = s->d_enc_meta + m->B, e.out_total = s->d_enc_meta + 2 * m->B;
+    launch_jpeg_encode(tl_cur->d_enc_descs, tl_cur->d_rgb, m->rgb_stride, w, h, 1, tl_cur->enc_q, tl_cur->enc_ifast, e,
+                       tl_cur->stream);
+    HIPC(m, hipMemcpyAsync(s->h_enc_meta, s->d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipStreamSynchronize(tl_cur->stream));
+    *len = s->h_enc_meta[0];
+    if (*len > cap) return m->fail(UFD_E_TRUNCATED, "encoded stream larger than the output buffer");
+    HIPC(m, hipMemcpy(out, s->d_enc_out + s->h_enc_meta[m->B], *len, hipMemcpyDeviceToHost));
+    return UFD_OK;
+  });
+}
+
 int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t* rgb, size_t cap_bytes, uint32_t* w,
                           uint32_t* h) {
   return guarded(m, [&]() -> int {

@@ -21,6 +21,7 @@ UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_MAX_SLOTS = 8
+UFD_ANNOT_MULTIPART = 1
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
                  -5: "UFD_E_DEVICE", -6: "UFD_E_WEIGHTS", -7: "UFD_E_STATE", -8: "UFD_E_TOO_LARGE"}
@@ -39,6 +40,13 @@ class UfdConfig(ctypes.Structure):
                 ("priors_floats", ctypes.c_size_t)]
 
 
+class UfdAnnotate(ctypes.Structure):
+    """Arguments of the draw + re-encode step (inferer.rs:38-40): the slot's label size, quality, output buffers."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("label_width", ctypes.c_float), ("label_height", ctypes.c_float),
+                ("quality", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("jpeg_out", ctypes.c_void_p),
+                ("jpeg_cap", ctypes.c_size_t), ("jpeg_off", ctypes.c_void_p), ("jpeg_len", ctypes.c_void_p)]
+
+
 class UfdKernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
@@ -51,6 +59,8 @@ ABI_SYMBOLS = (
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
     "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
     "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
+    "ufd_submit_annotate_batch", "ufd_annotate_jpeg_batch", "ufd_encode_bound", "ufd_host_alloc", "ufd_host_free",
+    "ufd_debug_draw_rects", "ufd_debug_encode_rgb",
 )
 
 _lib = None
@@ -96,6 +106,16 @@ def load_library():
     L.ufd_debug_postproc.argtypes = [vp, vp, vp, u32, vp, u32, vp]
     L.ufd_debug_jpeg_coefficients.argtypes = [vp, sz, vp, sz, pu32, pu32, pu32]
     L.ufd_debug_load_onnx.argtypes = [ctypes.c_char_p, u32, vp, sz, vp, sz, pu32, ctypes.c_char_p, sz]
+    L.ufd_submit_annotate_batch.argtypes = [vp, vp, vp, u32, ctypes.POINTER(UfdAnnotate), vp, u32, vp, vp, pu32]
+    L.ufd_annotate_jpeg_batch.argtypes = [vp, vp, vp, u32, ctypes.POINTER(UfdAnnotate), vp, u32, vp, vp]
+    L.ufd_encode_bound.argtypes = [u32, u32]
+    L.ufd_encode_bound.restype = sz
+    L.ufd_host_alloc.argtypes = [sz]
+    L.ufd_host_alloc.restype = vp
+    L.ufd_host_free.argtypes = [vp]
+    L.ufd_host_free.restype = None
+    L.ufd_debug_draw_rects.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_float, ctypes.c_float]
+    L.ufd_debug_encode_rgb.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, sz, ctypes.POINTER(sz)]
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
@@ -328,7 +348,99 @@ class UltrafaceModel(InferModel):
     def wait(self, ticket, collect=True):
         b = self._pending.pop(ticket)
         self._check(self._lib.ufd_wait(self._h, ticket))
+        if getattr(b, "annot", None) is not None:
+            return self._collect_annot(b) if collect else (b.cnt, b.status, b.jpeg_len)
         return self._collect(b) if collect else (b.cnt, b.status)
+
+    # -- N1: the rest of the Inferer::run iteration (inferer.rs:38-46): rectangles + JPEG re-encode on the GPU
+    class _AnnotBatch(_Batch):
+        __slots__ = ("annot", "jpeg_buf", "jpeg_mem", "jpeg_off", "jpeg_len", "owner")
+
+        def __del__(self):
+            mem, owner = getattr(self, "jpeg_mem", None), getattr(self, "owner", None)
+            if mem and owner is not None:
+                owner.ufd_host_free(mem)
+                self.jpeg_mem = None
+
+    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None):
+        """Buffers of one annotate batch (reusable): pinned output memory from ufd_host_alloc.  label_size = the
+        slot's (width, height) -- 1280 x 720 in the reference's router, whatever the JPEG's size (router.rs:66-67)."""
+        base = self._prep_batch(jpegs)
+        b = UltrafaceModel._AnnotBatch()
+        for k in UltrafaceModel._Batch.__slots__:
+            if hasattr(base, k):
+                setattr(b, k, getattr(base, k))
+        if out_bytes_per_frame is None:  # worst case of the largest frame in the batch
+            out_bytes_per_frame = 0
+            for x in b.bufs:
+                try:
+                    _, w, h = jpeg_coefficients_header(bytes(x))
+                except UfdError:
+                    continue
+                out_bytes_per_frame = max(out_bytes_per_frame, self._lib.ufd_encode_bound(w, h))
+        cap = max(int(out_bytes_per_frame), 1024) * b.count
+        b.owner = self._lib
+        b.jpeg_mem = self._lib.ufd_host_alloc(cap)
+        if not b.jpeg_mem:
+            raise MemoryError("ufd_host_alloc(%d)" % cap)
+        b.jpeg_buf = (ctypes.c_ubyte * cap).from_address(b.jpeg_mem)
+        b.jpeg_off = (ctypes.c_size_t * b.count)()
+        b.jpeg_len = (ctypes.c_size_t * b.count)()
+        a = UfdAnnotate()
+        a.struct_size = ctypes.sizeof(UfdAnnotate)
+        a.label_width, a.label_height = float(label_size[0]), float(label_size[1])
+        a.quality, a.flags = int(quality), (UFD_ANNOT_MULTIPART if multipart else 0)
+        a.jpeg_out, a.jpeg_cap = b.jpeg_mem, cap
+        a.jpeg_off, a.jpeg_len = ctypes.addressof(b.jpeg_off), ctypes.addressof(b.jpeg_len)
+        b.annot = a
+        return b
+
+    def submit_annotate_batch(self, b):
+        t = ctypes.c_uint32()
+        self._check(self._lib.ufd_submit_annotate_batch(self._h, b.ptrs, b.lens, b.count, ctypes.byref(b.annot), b.out,
+                                                        self.det_cap, b.cnt, b.status, ctypes.byref(t)))
+        b.ticket = t.value
+        self._pending[t.value] = b
+        return t.value
+
+    def _collect_annot(self, b):
+        dets, status = self._collect(b)
+        view = memoryview(b.jpeg_buf)
+        streams = [bytes(view[b.jpeg_off[i]:b.jpeg_off[i] + b.jpeg_len[i]]) if b.jpeg_len[i] else None for i in range(b.count)]
+        return dets, status, streams
+
+    def annotate_jpeg_batch(self, jpegs, label_size, quality=95, multipart=False):
+        """decode -> infer -> rectangles -> re-encode for a batch: ([detections], [status], [annotated JPEG bytes or None])."""
+        b = self.prep_annotate_batch(jpegs, label_size, quality, multipart)
+        return self.wait(self.submit_annotate_batch(b))
+
+    def annotate_jpeg(self, jpeg, label_size, quality=95, multipart=False):
+        dets, status, streams = self.annotate_jpeg_batch([jpeg], label_size, quality, multipart)
+        if status[0] not in (UFD_OK, UFD_E_TRUNCATED):
+            raise UfdError(status[0], "frame skipped")
+        return dets[0], streams[0]
+
+    def debug_draw_rects(self, rgb, dets, label_size):
+        """N1 drawing stage alone on the GPU: HxWx3 uint8 + [(bbox, conf)] or [n,5] -> annotated copy."""
+        out = np.ascontiguousarray(rgb, np.uint8).copy()
+        h, w, _ = out.shape
+        if not isinstance(dets, np.ndarray):
+            dets = [list(b) + [c] for b, c in dets]
+        d = np.ascontiguousarray(np.asarray(dets, np.float32).reshape(-1, 5))
+        self._check(self._lib.ufd_debug_draw_rects(self._h, out.ctypes.data, w, h, w * 3, d.ctypes.data, len(d),
+                                                   float(label_size[0]), float(label_size[1])))
+        return out
+
+    def debug_encode_rgb(self, rgb, quality=95, multipart=False):
+        """N1 encoder alone on the GPU: HxWx3 uint8 -> JPEG bytes (turbojpeg::compress_image(.., quality, Sub2x2))."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w, _ = rgb.shape
+        cap = self._lib.ufd_encode_bound(w, h)
+        out = np.empty(cap, np.uint8)
+        n = ctypes.c_size_t()
+        self._check(self._lib.ufd_debug_encode_rgb(self._h, rgb.ctypes.data, w, h, w * 3, int(quality),
+                                                   UFD_ANNOT_MULTIPART if multipart else 0, out.ctypes.data, cap, ctypes.byref(n)))
+        return out[:n.value].tobytes()
 
     # -- stage taps used by the parity tests
     def debug_decode_jpeg(self, jpeg):

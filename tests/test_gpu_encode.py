@@ -1,0 +1,156 @@
+"""Row N1 on the GPU, through the C ABI: rectangles (inferer.rs:58-92) and the JPEG re-encode
+(inferer.rs:39) against the CPU oracle, which is pinned byte for byte to libjpeg-turbo's own streams
+(tests/test_oracle_encode.py).  Streams must be IDENTICAL; rectangle pixels exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import assert_dets_match, dets_array
+from infercam_onnx_amd import nn, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PICS = os.path.join(ROOT, "tests", "golden", "test_pics")
+
+
+def _model(variant, weights, **kw):
+    v = nn.UltrafaceVariant.W640H480 if variant == 640 else nn.UltrafaceVariant.W320H240
+    W, H = v.width_height()
+    return nn.UltrafaceModel(v, 0.5, 0.5, weights=weights, priors=synth.gen_priors(W, H), **kw)
+
+
+@pytest.fixture(scope="module")
+def model320(weights):
+    with _model(320, weights, max_batch=8, max_src=(1280, 960), det_cap=512) as m:
+        yield m
+
+
+SIZES = [(640, 480), (320, 240), (1280, 720), (333, 217), (150, 100), (64, 52), (40, 24), (37, 29), (17, 9), (8, 8), (1, 1),
+         (136, 8), (16, 200)]
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_encoder_streams_equal_the_oracle(model320, size):
+    """MCU-aligned and ragged frames (replicated edge samples, dummy blocks), the reference's quality 95 (fast DCT)."""
+    w, h = size
+    rgb = synth.synth_frame(21, w * 7 + h, max(w, 16), max(h, 16))[:h, :w]
+    assert model320.debug_encode_rgb(rgb, 95) == oracle.jpeg_encode_rgb(rgb, 95)
+
+
+@pytest.mark.parametrize("quality", [96, 100, 75, 50, 10])
+def test_encoder_other_qualities(model320, quality):
+    """tjCompress2 switches to the accurate DCT from quality 96 on; other tables exercise the reciprocal quantiser."""
+    rgb = synth.synth_frame(5, quality, 200, 120)
+    assert model320.debug_encode_rgb(rgb, quality) == oracle.jpeg_encode_rgb(rgb, quality)
+
+
+def test_encoder_hard_content(model320):
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (96, 112, 3), dtype=np.uint8)  # saturated noise: 16-bit wrap-around, many 0xFF bytes
+    chk = np.zeros((64, 64, 3), np.uint8)
+    chk[::2, 1::2] = 255
+    chk[1::2, ::2] = 255
+    flat = np.full((48, 80, 3), 255, np.uint8)
+    for rgb in (noise, chk, flat):
+        for q in (95, 100):
+            got = model320.debug_encode_rgb(rgb, q)
+            assert got == oracle.jpeg_encode_rgb(rgb, q)
+    # the stream really holds stuffed bytes
+    assert b"\xff\x00" in model320.debug_encode_rgb(noise, 100)
+
+
+def test_encoder_multipart_framing(model320):
+    rgb = synth.synth_frame(5, 5, 96, 64)
+    jpeg = oracle.jpeg_encode_rgb(rgb, 95)
+    assert model320.debug_encode_rgb(rgb, 95, multipart=True) == oracle.stream_item(jpeg)
+    assert model320.debug_encode_rgb(rgb, 95) == jpeg  # and back to the plain header
+
+
+def test_rectangles_equal_the_oracle(model320):
+    rng = np.random.default_rng(11)
+    rgb = synth.synth_frame(1, 3, 320, 240)
+    dets = np.concatenate([
+        rng.uniform(-0.3, 1.3, (40, 5)).astype(np.float32),                       # any order of corners, off-frame
+        np.array([[0.0, 0.0, 1.0, 1.0, 0.9], [0.5, 0.5, 0.5, 0.9, 0.8],           # whole frame; zero width
+                  [0.25, 0.25, 0.2534, 0.75, 0.7], [np.nan, 0.1, 0.5, 0.5, 0.6],   # one pixel wide; NaN corner
+                  [-5.0, -5.0, 6.0, 6.0, 0.5], [0.999, 0.999, 1.5, 1.5, 0.5]], np.float32)])
+    for label in ((320, 240), (1280, 720), (100.5, 77.25)):
+        got = model320.debug_draw_rects(rgb, dets, label)
+        assert np.array_equal(got, oracle.draw_hollow_rects(rgb, dets, *label)), label
+    assert np.array_equal(model320.debug_draw_rects(rgb, np.zeros((0, 5), np.float32), (320, 240)), rgb)
+
+
+def _expected_stream(jpeg, dets, label, quality=95):
+    """The oracle's draw + encode of the oracle's decode, with the detections the GPU reported (detections are
+    compared with the oracle's separately: a rectangle corner may sit on an integer boundary)."""
+    frame = oracle.draw_hollow_rects(oracle.jpeg_decode_rgb(jpeg), dets_array(dets), *label)
+    return oracle.jpeg_encode_rgb(frame, quality)
+
+
+def test_annotate_batch_end_to_end_640(weights):
+    """C3's workload through ufd_annotate_jpeg_batch: fused 4:2:0 path, label size = frame size and the router's 1280x720."""
+    W, H = 640, 480
+    jpegs = synth.synth_jpeg_pool(0, 8, W, H, quality=90, subsampling="4:2:0")
+    priors = synth.gen_priors(W, H)
+    with _model(640, weights, max_batch=8, max_src=(W, H), det_cap=1024) as m:
+        for label in ((W, H), (1280, 720)):
+            dets, status, streams = m.annotate_jpeg_batch(jpegs, label)
+            assert status == [0] * 8
+            for j, d, s in zip(jpegs, dets, streams):
+                assert_dets_match(dets_array(d), oracle.infer_jpeg(j, W, H, weights, priors), what="annotate")
+                assert s == _expected_stream(j, d, label)
+                assert oracle.jpeg_decode_rgb(s).shape == (H, W, 3)
+
+
+def test_annotate_pipelined_with_a_corrupt_frame(weights):
+    """Six annotate batches in flight over the three contexts; a corrupt slot yields status DECODE and no stream,
+    the other frames of its batch are unaffected (inferer.rs:35-36 would panic the task)."""
+    W, H = 320, 240
+    pool = synth.synth_jpeg_pool(3, 24, W, H, quality=90, subsampling="4:2:0")
+    pool[5] = pool[5][:200] + bytes(50) + pool[5][260:len(pool[5]) // 2]
+    with _model(320, weights, max_batch=4, max_src=(W, H), det_cap=512) as m:
+        batches = [m.prep_annotate_batch(pool[i * 4:(i + 1) * 4], (1280, 720), multipart=True) for i in range(6)]
+        for rnd in range(2):
+            tickets = [m.submit_annotate_batch(b) for b in batches]
+            for bi, t in enumerate(tickets):
+                dets, status, streams = m.wait(t)
+                for k in range(4):
+                    j = pool[bi * 4 + k]
+                    if bi * 4 + k == 5:
+                        assert status[k] == nn.UFD_E_DECODE and streams[k] is None
+                        continue
+                    assert status[k] == 0
+                    assert streams[k] == oracle.stream_item(_expected_stream(j, dets[k], (1280, 720)))
+
+
+def test_annotate_server_default_1280x720_to_320(weights):
+    """The reference server's operating point: 1280x720 camera frames, UltraFace-320, rectangles on the full frame."""
+    jpegs = synth.synth_jpeg_pool(1, 3, 1280, 720, quality=90, subsampling="4:2:0")
+    jpegs.append(synth.encode_jpeg(synth.synth_frame(9, 9, 1280, 720), quality=85, subsampling="4:2:2"))
+    with _model(320, weights, max_batch=4, max_src=(1280, 720), det_cap=512) as m:
+        dets, status, streams = m.annotate_jpeg_batch(jpegs, (1280, 720))
+        assert status == [0] * 4
+        for j, d, s in zip(jpegs, dets, streams):
+            assert s == _expected_stream(j, d, (1280, 720))
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(PICS)) if os.path.isdir(PICS) else [])
+def test_annotate_reference_test_pictures(model320, name):
+    """The reference's own fixtures (progressive, 640 x {427..960}: ragged MCU rows, a dummy block row at 676)."""
+    jpeg = open(os.path.join(PICS, name), "rb").read()
+    d, s = model320.annotate_jpeg(jpeg, (1280, 720))
+    assert s == _expected_stream(jpeg, d, (1280, 720))
+
+
+def test_annotate_output_buffer_too_small(weights):
+    W, H = 320, 240
+    jpegs = synth.synth_jpeg_pool(2, 4, W, H, quality=90, subsampling="4:2:0")
+    with _model(320, weights, max_batch=4, max_src=(W, H), det_cap=512) as m:
+        ref_d, ref_st, ref_s = m.annotate_jpeg_batch(jpegs, (W, H))
+        b = m.prep_annotate_batch(jpegs, (W, H), out_bytes_per_frame=(len(ref_s[0]) + len(ref_s[1]) + 64) // 4)
+        dets, status, streams = m.wait(m.submit_annotate_batch(b))
+        assert streams[0] == ref_s[0] and streams[1] == ref_s[1]
+        assert status[:2] == [0, 0] and status[2:] == [nn.UFD_E_TRUNCATED] * 2 and streams[2] is None and streams[3] is None
+        assert dets[2] == ref_d[2]  # detections of a truncated frame are still reported
