@@ -67,6 +67,8 @@ def stage_of(label):
         return "idct_preproc"
     if label in ("head_decode", "sort_nms"):
         return "post"
+    if label == "draw_rects" or label.startswith("enc_"):
+        return "annotate_encode"
     return "cnn"  # (the fused stem -- upsampling + colour + normalise + conv 0 -- counts as CNN)
 
 
@@ -303,6 +305,32 @@ def main():
                 sb.setdefault(stg, {})[name + "_ms"] = round(ms, 4)
         extras["stages"] = sb
         model.profile_sampling(1 << 30)
+        # ---- N1: the whole Inferer::run iteration, inferer.rs:35-46 -- decode -> infer -> rectangles -> JPEG q95
+        # re-encode on the GPU, annotated streams back in (pinned) host memory; label size = the router's 1280 x 720
+        nab = min(nb, args.depth)
+        abs_ = [model.prep_annotate_batch(jpegs[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=SW * SH) for i in range(nab)]
+
+        def run_annotate(k):
+            inflight, out_bytes = [], 0
+            for s_ in range(k):
+                if len(inflight) >= nab:
+                    _, _, lens_ = model.wait(inflight.pop(0), collect=False)
+                    out_bytes += sum(lens_)
+                inflight.append(model.submit_annotate_batch(abs_[s_ % nab]))
+            for t_ in inflight:
+                _, _, lens_ = model.wait(t_, collect=False)
+                out_bytes += sum(lens_)
+            return out_bytes
+
+        run_annotate(max(args.warmup, nab))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ob = run_annotate(args.steps)
+        torch.cuda.synchronize()
+        el_a = time.perf_counter() - t1
+        extras["annotate"] = {"fps": round(B * args.steps / el_a, 1), "bytes_out_per_frame": round(ob / (B * args.steps)),
+                              "what": "ufd_submit_annotate_batch: host JPEG bytes -> detections + annotated q95 4:2:0 JPEG in host memory"}
+        del abs_
         # ---- per-frame latency at batch 1, one frame in flight, host bytes -> host detections
         lat = []
         for i in range(60):
@@ -406,6 +434,8 @@ def main():
             out["stages"] = extras["stages"]
         if "latency_ms_batch1" in extras:
             out["latency_ms_batch1"] = extras["latency_ms_batch1"]
+        if "annotate" in extras:
+            out["annotate"] = extras["annotate"]
         if verified is not None:
             out["verified"] = verified
         if prof_steps:

@@ -19,6 +19,7 @@
 // "acc = bias; for ci, ky, kx: acc = fma(w, x, acc)" (zero taps add exactly 0), so results are
 // bit-identical to a plain fmaf loop nest in that order.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
 
 // ------------------------------------------------------------------------------------------------
 // Two depthwise->pointwise blocks in one launch:
-//   [dw 3x3 s1 (C1 ch, +bias, ReLU) -> pw C1->32 (+bias, act)] -> [dw 3x3 s2 (32 ch, +bias, ReLU) -> pw 32->cout<=32]
+//   [dw 3x3 s1 (C1 ch, +bias, ReLU) -> pw C1->32 (+bias, act)] -> [dw 3x3 s2 (32 ch, +bias, ReLU) -> pw 32->cout<=64]
 // The tensor between the blocks (X1: 32 channels at full resolution, 315 MB per 32-frame batch for
 // m1 -> m2 of the 640x480 model, written once and read once) never exists in memory.
 // A group of 4 output pixels (oy, ox..ox+3) of the second block reads rows 2oy-1..2oy+1 and columns
@@ -594,12 +595,21 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
 // conv is per channel, so each row is folded straight into the lane's 16 x 2 second-block sums:
 //   pixel A: taps (left lane's x3, x0, x1)      pixel B: taps (x1, x2, x3)
 // for both parities.  The fma order is the unfused one (bias; rows top to bottom; taps left to
-// right).  Rows 2oy+1 and 2(oy+1)-1 coincide, so the first block is computed 1.5x: it is the
-// cheap one (K = C1).  Before the second pointwise conv the halves exchange channels so that
-// k-step s multiplies channels (2s, 2s+1) in ascending order like k_dwpw_mfma.
+// right).
+// ROW ROLLING: a wave owns a BAND of a2.band output rows of its column strip and walks down the
+// 2 * band + 1 X1 rows under it.  X1 row 2(oy0 + j) - 1 is the bottom tap row of output row
+// oy0 + j - 1 and the top tap row of output row oy0 + j: it is computed once and folded into both
+// sums (two live sets), then the finished output row goes through the second pointwise conv.  Every
+// X1 row of a band is computed once (band = 1: 3 X1 rows per output row; band = 5: 2.2) and every
+// input row read once per band plus a two-row halo.  Lanes are numbered over (frame, band, column
+// group), so a wave's columns may straddle bands, rows and frames: a lane's left / right neighbour
+// is either the same row's neighbouring group or beyond an image border (zero padding).
+// Before the second pointwise conv the halves exchange channels so that k-step s multiplies
+// channels (2s, 2s+1) in ascending order like k_dwpw_mfma.
 // Tiles advance by 30 lane columns = 15 output groups; columns 0 and 31 only provide halos.
 // a[0]: first block (in, w2 = dw [C1][12], w = packed pw, bias, relu); a[1]: second block
-// (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0.
+// (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0,
+// a[1].oh % a[1].band == 0.
 template <int C1, int CT2>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
@@ -610,6 +620,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* s_w1 = s_dw1 + 3 * C1 * 12;   // [KS1][64]
   float* s_dw2 = s_w1 + KS1 * 64;      // [2][32][12]: the packed table, then a copy with all taps zero
   float* s_w2 = s_dw2 + 2 * 32 * 12;   // [CT2][KS2][64]
+  float* s_b1 = s_w2 + CT2 * KS2 * 64; // [32] bias of the first pointwise conv
+  float* s_b2 = s_b1 + 32;             // [32 * CT2] bias of the second (0 beyond cout)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Workgroup ids are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of
   // tiles, so that neighbouring tiles (which share input rows) meet in the same L2 close in time.
@@ -627,57 +639,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     copy4(s_dw2, a2.w2, 32 * 3);
     for (int i = threadIdx.x; i < 32 * 12; i += 256) s_dw2[32 * 12 + i] = 0.f;
     copy4(s_w2, a2.w, CT2 * KS2 * 16);
+    if (threadIdx.x < 32) s_b1[threadIdx.x] = a1.bias[threadIdx.x];
+    if (threadIdx.x < 32 * CT2) s_b2[threadIdx.x] = (int)threadIdx.x < a2.cout ? a2.bias[threadIdx.x] : 0.0f;
   }
   __syncthreads();
+  // (table reads inside the row loop go through an index the compiler cannot see through: hoisted out of the loop as
+  // loop invariants, the 16 + 16 + 32 bias values alone cost more registers than the kernel has to spare)
+  auto opaque = [](int v) {
+    // asm volatile("" : "+v"(v));
+    return v;
+  };
   const int half = lane >> 5, j32 = lane & 31;
-  const int ohw = a2.oh * a2.ow, gpf = ohw >> 2, gpr = a2.ow >> 2;
-  const long total = 2L * a2.B * gpf;  // X1 half-groups
+  const int R = a2.band, bands = a2.oh / R;
+  const int ohw = a2.oh * a2.ow, gpr = a2.ow >> 2, gpb = bands * gpr;  // column groups per row / per frame of bands
+  const long total = 2L * a2.B * gpb;  // X1 half-groups over (frame, band, group)
   const long q = ((long)tile * 4 + wave) * kDwGroups + j32 - 1;
   const bool inrange = q >= 0 && q < total;
   const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;
   const int sub = inrange ? (int)(q & 1) : 0;
   const long g = inrange ? (q >> 1) : 0;
-  const size_t frame = (size_t)(g / gpf);
-  const int rem = (int)(g - (long)frame * gpf);
-  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const size_t frame = (size_t)(g / gpb);
+  const int rem = (int)(g - (long)frame * gpb);
+  const int band = rem / gpr, ox = (rem - band * gpr) * 4, oy0 = band * R;
   const int H1 = a1.ih, W1 = a1.iw, ihw = H1 * W1;
   const int x0 = 2 * ox + 4 * sub;            // first X1 / input column of the lane
   const bool leftok = x0 > 0;                 // column x0 - 1 exists (else zero padding)
   const bool rightok = x0 + 4 < W1;           // column x0 + 4 exists
   const char* __restrict__ in = reinterpret_cast<const char*>(a1.in);
-  const uint32_t lane_base = (uint32_t)((frame * a1.in_ctotal + half) * ihw);
+  const uint32_t lane_base = (uint32_t)((frame * a1.in_ctotal + half) * ihw) + (uint32_t)x0;
   const size_t chan_step = 8u * (size_t)ihw;  // bytes between the channels of consecutive k-steps
 
-  // second block: depthwise sums of the lane's 16 channels x 2 output pixels
-  float t2[16][2];
+  // second block: depthwise sums of the lane's 16 channels x 2 output pixels -- of the output row being
+  // finished (t2) and, across an X1 row that both need, of the one below it (t2n)
+  float t2[16][2], t2n[16][2];
+  auto init_sums = [&](float (&tt)[16][2]) {
+    const float* b = s_dw2 + opaque(4 * half * 12 + 9);
 #pragma unroll
-  for (int r = 0; r < 16; r++) t2[r][0] = t2[r][1] = s_dw2[((r & 3) + 8 * (r >> 2) + 4 * half) * 12 + 9];
+    for (int r = 0; r < 16; r++) tt[r][0] = tt[r][1] = b[((r & 3) + 8 * (r >> 2)) * 12];
+  };
+  init_sums(t2);
 
-  // input rows 2oy-2 .. 2oy+2 (X1 row `row` reads rows row .. row+2 of them)
-  bool ok5[5];
-  uint32_t rowoff5[5];
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const int y0 = 2 * oy - 2 + k;
-    ok5[k] = y0 >= 0 && y0 < H1;
-    rowoff5[k] = 4u * (lane_base + (uint32_t)(min(max(y0, 0), H1 - 1) * W1 + x0));  // bytes
-  }
   // input windows: 3 rows x 4 columns of channel 2*ks + half; two k-steps are kept in flight
-  // ACROSS the three X1 rows (the ring never drains: the first windows of the next row are loaded
+  // ACROSS the X1 rows (the ring never drains: the first windows of the next row are loaded
   // while the current row is folded into the second depthwise conv)
   float4 win[2][3];
-  // (the row loop stays rolled -- unrolled, the three bodies keep 470 registers live -- so
-  // rowoff5[row + k] is a select on the wave-uniform row, not a register-array index)
-  auto pick = [](int row, auto v0, auto v1, auto v2) { return row == 0 ? v0 : (row == 1 ? v1 : v2); };
-  // (wave-uniform channel base + the lane's 32-bit byte offset of the row)
+  // (wave-uniform channel base + the lane's 32-bit byte offset of the row; the rows of an X1 row y1 are
+  // input rows y1 - 1 .. y1 + 1, clamped into the image: rows outside are zero padding through the taps)
+  auto row_offsets = [&](int y1, uint32_t (&ro)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) ro[k] = 4u * (lane_base + (uint32_t)(min(max(y1 - 1 + k, 0), H1 - 1) * W1));
+  };
   auto load_window = [&](const uint32_t (&ro)[3], int ks, float4 (&m)[3]) {
     const char* base = in + (size_t)ks * chan_step;
 #pragma unroll
     for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(base + ro[k]);
-  };
-  auto row_offsets = [&](int row, uint32_t (&ro)[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) ro[k] = pick(row, rowoff5[k], rowoff5[k + 1], rowoff5[k + 2]);
   };
   // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
   // zero padding: `wl` points into the copy of the LDS table that has those taps zeroed.
@@ -698,29 +713,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
   };
+  // one X1 row of the lane's 16 channels (in the accumulators) -> the second depthwise sums.  An X1 row outside the
+  // image is zero padding: taps from the all-zero copy (fma(0, x, t) == t).  Odd X1 rows are the middle tap row of one
+  // output row (BOTH = false: tap row 1 into t2); even ones the bottom tap row of the output row above and the top
+  // tap row of the one below: both sums are updated in one pass over the channels (tap row 2 into t2, tap row 0 into
+  // t2n after its bias), so an accumulator register is dead as soon as its channel is folded.
+  auto fold = [&](const floatx16 (&acc)[4], bool row1ok, int mode /* 0: middle tap row; 1: up + down; 2: down only; 3: up only */) {
+    const float* wl2 = s_dw2 + (row1ok ? 0 : 32 * 12) + 4 * half * 12;
+    const float* bl2 = s_dw2 + 4 * half * 12 + 9;  // (the bias always from the real table)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float* wd2 = wl2 + ((r & 3) + 8 * (r >> 2)) * 12;
+      float x[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) x[p] = a1.relu ? relu_acc(acc[p][r]) : acc[p][r];
+      const float from_prev = lane_prev(x[3]);
+      const float l = leftok ? from_prev : 0.f;
+      if (mode == 0) {
+        const float w0 = wd2[3], w1 = wd2[4], w2 = wd2[5];
+        t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
+        t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
+      } else {
+        if (mode != 2) {  // (the band's first X1 row has no output row above, its last none below)
+          const float w0 = wd2[6], w1 = wd2[7], w2 = wd2[8];
+          t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
+          t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
+        }
+        if (mode != 3) {
+          const float w0 = wd2[0], w1 = wd2[1], w2 = wd2[2], bb = bl2[((r & 3) + 8 * (r >> 2)) * 12];
+          float u0 = bb, u1 = bb;
+          u0 = fmaf(w0, l, u0), u0 = fmaf(w1, x[0], u0), u0 = fmaf(w2, x[1], u0);
+          u1 = fmaf(w0, x[1], u1), u1 = fmaf(w1, x[2], u1), u1 = fmaf(w2, x[3], u1);
+          t2n[r][0] = u0, t2n[r][1] = u1;
+        }
+      }
+      // (the scheduler would otherwise issue all the table reads of the row first: registers this kernel does not have)
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // second pointwise conv of the finished sums t2 -> output row oy.  The lane holds channels qq + 8b + 4*half
+  // (qq = r&3, b = r>>2); k-step s = 4b + u needs channel 8b + 2u from the half-0 lanes and 8b + 2u + 1 from the
+  // half-1 lanes:
+  //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
+  //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
+  auto finish = [&](int oy) {
+    float bop[KS2][2];  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      float own[4][2], got[2][2];
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) own[qq][j] = fmaxf(t2[4 * b + qq][j], 0.f);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        // half 0 sends qq = 1, 3; half 1 sends qq = 0, 2
+        const float s0 = half ? own[0][j] : own[1][j], s1 = half ? own[2][j] : own[3][j];
+        got[0][j] = __shfl_xor(s0, 32), got[1][j] = __shfl_xor(s1, 32);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        bop[4 * b + 0][j] = half ? got[0][j] : own[0][j];
+        bop[4 * b + 1][j] = half ? got[1][j] : own[2][j];
+        bop[4 * b + 2][j] = half ? own[1][j] : got[0][j];
+        bop[4 * b + 3][j] = half ? own[3][j] : got[1][j];
+      }
+    }
+    // (stores: wave-uniform channel base + the lane's 32-bit byte offset -- per-channel address arithmetic stays scalar)
+    const uint32_t out_off = 4u * (uint32_t)((frame * a2.out_ctotal + 4 * half) * ohw + (size_t)(oy * a2.ow + ox + 2 * sub));
+    char* const out_base = reinterpret_cast<char*>(a2.out + (size_t)a2.out_coff * ohw);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < CT2; ct++) {
+      floatx16 acc2[2];
+      const float* b2 = s_b2 + opaque(ct * 32 + 4 * half);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc2[0][r] = acc2[1][r] = b2[(r & 3) + 8 * (r >> 2)];
+      const float* w2l = s_w2 + opaque(ct * KS2 * 64 + lane);
+#pragma unroll
+      for (int ks = 0; ks < KS2; ks++) {
+        const float w = w2l[ks * 64];
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][0], acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][1], acc2[1], 0, 0, 0);
+      }
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < a2.cout) {
+            float2 v = make_float2(acc2[0][r], acc2[1][r]);
+            if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+            *reinterpret_cast<float2*>(out_base + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * ohw * 4 + out_off) = v;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int nrows = 2 * R + 1;
   {
     uint32_t ro[3];
-    row_offsets(0, ro);
+    row_offsets(2 * oy0 - 1, ro);
     load_window(ro, 0, win[0]);
     load_window(ro, 1, win[1]);
   }
-
 #pragma unroll 1
-  for (int row = 0; row < 3; row++) {
-    const int y1 = 2 * oy - 1 + row;  // X1 row
+  for (int row = 0; row < nrows; row++) {
+    const int y1 = 2 * oy0 - 1 + row;  // X1 row
     const bool row1ok = y1 >= 0 && y1 < H1;
+    const bool last = row == nrows - 1;
     uint32_t ro[3], ro_next[3];  // this X1 row's input rows, the next one's (the last row: its own)
-    row_offsets(row, ro);
-    row_offsets(row < 2 ? row + 1 : row, ro_next);
+    row_offsets(y1, ro);
+    row_offsets(last ? y1 : y1 + 1, ro_next);
     // (an X1 row outside the image has two padding input rows; it is computed from whatever the
     // clamped addresses hold and dropped below by the zero taps of the second depthwise conv)
-    const float* wl = s_dw1 + (dw_variant(pick(row, ok5[0], ok5[1], ok5[2]), pick(row, ok5[2], ok5[3], ok5[4])) * C1 + half) * 12;
+    const float* wl = s_dw1 + (dw_variant(y1 - 1 >= 0, y1 + 1 < H1) * C1 + half) * 12;
     floatx16 acc[4];
+    {
+      const float* b1 = s_b1 + opaque(4 * half);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float bb = a1.bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+      for (int r = 0; r < 16; r++) {
+        const float bb = b1[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
-      for (int p = 0; p < 4; p++) acc[p][r] = bb;
+        for (int p = 0; p < 4; p++) acc[p][r] = bb;
+      }
     }
     // software pipeline: the MFMAs of k-step ks run beside the depthwise arithmetic of ks + 1
     float tcur[4];
@@ -735,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (ks + 2 < KS1)
           load_window(ro, ks + 2, win[d]);
         else
-          load_window(ro_next, row < 2 ? ks + 2 - KS1 : KS1 - 1, win[d]);
+          load_window(ro_next, last ? KS1 - 1 : ks + 2 - KS1, win[d]);
         const float w = s_w1[ks * 64 + lane];
         float tnext[4];
         dw_compute(wl, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
@@ -748,76 +865,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int p = 0; p < 4; p++) tcur[p] = tnext[p];
       }
     }
-    // X1 row of the lane's 16 channels -> second depthwise sums (row `row` of the 3x3 taps);
-    // an X1 row outside the image is zero padding: taps from the all-zero copy (fma(0, x, t) == t)
-    const float* wl2 = s_dw2 + (row1ok ? 0 : 32 * 12) + 4 * half * 12 + 3 * row;
+    __builtin_amdgcn_sched_barrier(0);
+    if (row & 1) {  // X1 row 2(oy0 + j): the middle tap row of output row oy0 + j
+      fold(acc, row1ok, 0);
+    } else {        // X1 row 2(oy0 + j) - 1: bottom tap row of output row oy0 + j - 1, top tap row of oy0 + j
+      if (row == 0) fold(acc, row1ok, 2);
+      else if (last) fold(acc, row1ok, 3);
+      else fold(acc, row1ok, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (row > 0) finish(oy0 + (row >> 1) - 1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float* wd2 = wl2 + ((r & 3) + 8 * (r >> 2)) * 12;
-      const float w0 = wd2[0], w1 = wd2[1], w2 = wd2[2];
-      float x[4];
-#pragma unroll
-      for (int p = 0; p < 4; p++) x[p] = a1.relu ? relu_acc(acc[p][r]) : acc[p][r];
-      const float from_prev = lane_prev(x[3]);
-      const float l = leftok ? from_prev : 0.f;
-      t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
-      t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
-    }
-  }
-
-  // second pointwise conv.  The lane holds channels qq + 8b + 4*half (qq = r&3, b = r>>2); k-step
-  // s = 4b + u needs channel 8b + 2u from the half-0 lanes and 8b + 2u + 1 from the half-1 lanes:
-  //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
-  //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
-  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
-  float bop[KS2][2];
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    float own[4][2], got[2][2];
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) own[qq][j] = fmaxf(t2[4 * b + qq][j], 0.f);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      // half 0 sends qq = 1, 3; half 1 sends qq = 0, 2
-      const float s0 = half ? own[0][j] : own[1][j], s1 = half ? own[2][j] : own[3][j];
-      got[0][j] = __shfl_xor(s0, 32), got[1][j] = __shfl_xor(s1, 32);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      bop[4 * b + 0][j] = half ? got[0][j] : own[0][j];
-      bop[4 * b + 1][j] = half ? got[1][j] : own[2][j];
-      bop[4 * b + 2][j] = half ? own[1][j] : got[0][j];
-      bop[4 * b + 3][j] = half ? own[3][j] : got[1][j];
-    }
-  }
-  const int pix = oy * a2.ow + ox + 2 * sub;
-#pragma unroll
-  for (int ct = 0; ct < CT2; ct++) {
-    floatx16 acc2[2];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float bb = co < a2.cout ? a2.bias[co] : 0.0f;
-      acc2[0][r] = acc2[1][r] = bb;
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS2; ks++) {
-      const float w = s_w2[(ct * KS2 + ks) * 64 + lane];
-      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][0], acc2[0], 0, 0, 0);
-      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][1], acc2[1], 0, 0, 0);
-    }
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a2.cout) {
-          float2 v = make_float2(acc2[0][r], acc2[1][r]);
-          if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
-          *reinterpret_cast<float2*>(a2.out + (frame * a2.out_ctotal + a2.out_coff + co) * ohw + pix) = v;
-        }
-      }
+      for (int r = 0; r < 16; r++) t2[r][0] = t2n[r][0], t2[r][1] = t2n[r][1];
     }
   }
 }
@@ -1459,16 +1517,38 @@ bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
          first.oh == 2 * second.oh && first.res == nullptr && second.res == nullptr;
 }
 
+// Rows per band.  Measured on MI355X (rocprofv3, one batch in flight): a wave is bound by the SIMD's shared fp32
+// matrix / vector issue whatever the band, so a taller band pays (fewer X1 rows computed) only while the launch still
+// fills the GPU -- 2048 waves of this kernel are resident at once (two per SIMD).  m1 -> m2 of the 640 model at batch
+// 32 (10240 waves at band 1): band 1 124 us, 2 116, 3 119, 5 104 (exactly one round of 2048 waves), 6 111, 8 137;
+// m3 -> m4 (2560 waves at band 1): band 1 67 us, 2 70, 3 70.  Hence: the divisor of the output height that brings the
+// launch closest to one full round, for launches of three rounds or more; band 1 otherwise.
+static int dwpw2_band(const ConvArgs& second) {
+  const long waves1 = (2L * second.B * (second.oh * second.ow / 4) + kDwGroups - 1) / kDwGroups;
+  const double rounds = (double)waves1 / 2048.0;
+  if (rounds < 3.0) return 1;
+  int best = 1;
+  double best_d = 1e30;
+  for (int r = 1; r <= 8; r++) {
+    if (second.oh % r) continue;
+    const double d = std::fabs(rounds / r - 1.0) + (rounds / r > 1.02 ? 0.5 : 0.0);  // (just over one round = two rounds)
+    if (d < best_d) best_d = d, best = r;
+  }
+  return best;
+}
+
 void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipStream_t s) {
   ConvArgs3 p{};
   p.a[0] = first;
   p.a[1] = second;
-  const long half_groups = 2L * second.B * (second.oh * second.ow / 4);  // one lane column per 2 output pixels
+  const int band = dwpw2_band(second);
+  const long half_groups = 2L * second.B * ((second.oh / band) * second.ow / 4);  // one lane column per 2 output pixels of a band
   const long wave_tiles = (half_groups + kDwGroups - 1) / kDwGroups;
   p.a[1].tiles = (int)((wave_tiles + 3) / 4);
   p.a[1].cts = 1;
+  p.a[1].band = band;
   const int ct2 = (second.cout + 31) / 32;
-  const size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64) * sizeof(float);
+  const size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64 + 32 + 32 * ct2) * sizeof(float);
   const dim3 grid((unsigned)((p.a[1].tiles + 7) / 8 * 8));
   if (first.cin == 16 && ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<16, 1>), grid, dim3(256), lds, s, p);
   else if (first.cin == 16) hipLaunchKernelGGL((k_dwpw2_mfma<16, 2>), grid, dim3(256), lds, s, p);

@@ -133,6 +133,7 @@ struct ConvArgs {
   int32_t in2_ctotal, ksplit;  // with in2: its channel count, first k-step (2 channels each) read from it
   int32_t dbg;         // ablation switches (UFD_CONV_DBG), timing experiments only
   int32_t tiles, cts;  // MFMA kernels: pixel tiles (blocks) and 32-cout tiles, set by the launcher
+  int32_t band;        // chained dw->pw kernel: output rows per wave (row rolling), set by the launcher
 };
 // Up to three convolutions that share a launch configuration (same shapes, different weights /
 // outputs: cls+reg head pairs, the three RFB reduce convs) run as one launch, blockIdx.y selects.

@@ -454,6 +454,35 @@ def test_chained_blocks_kernel_is_bit_identical_to_the_unfused_pair(weights, ora
         fused_model.close()
 
 
+@pytest.mark.parametrize("variant,batch", [(640, 32), (640, 5), (320, 32), (320, 16)])
+def test_chained_blocks_kernel_row_rolling_at_bench_batches(weights, oracle_lib, variant, batch):
+    """The chained kernel walks bands of output rows whose height the launcher picks from the launch size (row rolling:
+    5 rows at batch 32 of the 640 model, other divisors of the map height elsewhere).  Whatever the band, m2.pw's and
+    m4.pw's outputs must equal the two-launch path's bit for bit (same fma order), bands, frames and image borders
+    straddled by one wave included."""
+    from infercam_onnx_amd import synth
+
+    W, H = (640, 480) if variant == 640 else (320, 240)
+    base = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(97, i, W, H)) for i in range(4)])
+    x = np.concatenate([base] * ((batch + 3) // 4))[:batch].copy()
+    x[1::2] = x[1::2][:, :, ::-1, :]  # (different content per frame: flipped copies)
+    ref_model = make_model(variant, weights, max_batch=batch, tap_layers=True, no_chain=True)
+    fused_model = make_model(variant, weights, max_batch=batch, tap_layers=True)
+    try:
+        ref_model.debug_forward(x)
+        fused_model.debug_forward(x)
+        for layer in (4, 8):  # m2.pw, m4.pw: the outputs of the two chained launches
+            for frame in (0, 1, batch // 2, batch - 1):
+                a, b = ref_model.debug_layer_output(layer, frame), fused_model.debug_layer_output(layer, frame)
+                if variant == 640 or layer == 4:
+                    assert np.array_equal(a, b), (layer, frame)
+                else:  # (m4 of the 320 model is split-K in the unfused form: fp32 rounding apart)
+                    assert np.abs(a - b).max() <= 5e-6, (layer, frame)
+    finally:
+        ref_model.close()
+        fused_model.close()
+
+
 @pytest.fixture(scope="module")
 def model320_auto(weights):
     m = make_model(320, weights, max_batch=4)  # no entropy flags: the product default
