@@ -91,6 +91,8 @@ void ufd_destroy(ufd_model* m);
 const char* ufd_last_error(const ufd_model* m);
 /* UltrafaceVariant::width_height (nn.rs:36-41) and K (number of priors) of the loaded model. */
 int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32_t* num_priors);
+/* Limits given at ufd_create (defaults resolved): frames per batch, largest decoded frame. */
+int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height);
 
 /* InferModel::run(&self, input: &RgbImage) -> Result<Vec<(Bbox, f32)>> (nn.rs:24-26,178-186).
  * rgb: interleaved RGB8, `pitch` bytes per row (>= 3*w), any w x h up to the create-time limit.
@@ -178,6 +180,77 @@ size_t ufd_encode_bound(uint32_t w, uint32_t h);
 /* Page-locked host memory for jpeg_out (and for input rings): the D2H copy then runs at PCIe speed. */
 void* ufd_host_alloc(size_t bytes);
 void ufd_host_free(void* p);
+
+/* ---- N4: multi-stream batching scheduler ----
+ * The FrameRouter -> INFER_IMAGES_CHANNEL -> Inferer leg of the reference (router.rs:64-71, lib.rs:32-37,
+ * inferer.rs:29-50) for MANY camera streams per GPU.  The reference serialises every stream through one task and one
+ * fixed model (UltraFace-320, inferer.rs:23); here every stream is bound to a variant (320 / 640) and to what it wants
+ * back (detections, or detections + the annotated JPEG of N1), frames are copied into the stream's own ring
+ * (drop-on-full exactly like `infer_tx.try_send_ref()`, router.rs:65: a full ring drops the NEW frame), and a
+ * dispatcher thread forms batches per (variant, output kind):
+ *   - fairness: one frame per stream per pass, round-robin, starting after the stream served last -- a 30 fps camera
+ *     cannot starve a 1 fps one;
+ *   - a batch leaves when it is full, when its oldest frame has waited max_wait_us, or at once when the model has
+ *     nothing in flight (a lone frame never waits for company);
+ *   - up to max_inflight batches per model in flight (the handle overlaps them on its three device contexts).
+ * Results are delivered on a completion thread through on_result, per frame, in dispatch order per stream. */
+#define UFD_E_FULL (-9) /* ufd_sched_push: the stream's ring is full, the frame was dropped (router.rs:65) */
+typedef struct ufd_sched ufd_sched;
+typedef struct ufd_frame_result {
+  uint64_t stream_id;  /* as given in ufd_stream_config (e.g. lib.rs:39-46 hashed(name)) */
+  uint64_t tag;        /* as given to ufd_sched_push */
+  int32_t status;      /* UFD_OK, UFD_E_DECODE / UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE (frame skipped), UFD_E_TRUNCATED */
+  uint32_t variant;    /* 320 / 640 */
+  uint32_t n;          /* detections found; min(n, det_cap) entries in dets */
+  uint32_t batch_fill; /* frames in the batch this one travelled in */
+  const ufd_det* dets; /* valid during the callback only */
+  const uint8_t* jpeg; /* annotated stream (NULL for a detections-only stream or a skipped frame); callback only */
+  size_t jpeg_len;
+  double queue_ms;     /* push -> batch dispatched */
+  double total_ms;     /* push -> this callback */
+} ufd_frame_result;
+typedef void (*ufd_result_fn)(void* user, const ufd_frame_result* result);
+typedef struct ufd_sched_config {
+  uint32_t struct_size;      /* = sizeof(ufd_sched_config) */
+  ufd_model* model_320;      /* handles the scheduler submits to (not owned; either may be NULL) */
+  ufd_model* model_640;
+  uint32_t ring_slots;       /* frames a stream may have queued; 0 -> 10 (INFER_IMAGES_CHANNEL, lib.rs:37) */
+  uint32_t max_wait_us;      /* 0 -> 2000 */
+  uint32_t max_inflight;     /* per model; 0 -> 6 */
+  uint32_t det_cap;          /* 0 -> 256 */
+  uint32_t jpeg_bytes_per_frame; /* output reserved per annotated frame; 0 -> 524288 (larger streams: UFD_E_TRUNCATED) */
+  ufd_result_fn on_result;
+  void* user;
+} ufd_sched_config;
+typedef struct ufd_stream_config {
+  uint32_t struct_size;  /* = sizeof(ufd_stream_config) */
+  uint64_t stream_id;
+  uint32_t variant;      /* 320 / 640 */
+  uint32_t annotate;     /* 0: detections only; 1: + annotated JPEG (ufd_submit_annotate_batch) */
+  float label_width;     /* annotate: as ufd_annotate */
+  float label_height;
+  uint32_t quality;      /* annotate; 0 -> 95 */
+  uint32_t flags;        /* annotate: UFD_ANNOT_* */
+} ufd_stream_config;
+typedef struct ufd_sched_stats {
+  uint64_t pushed, dropped, delivered, batches, frames_in_batches;
+  uint64_t sent_full, sent_deadline, sent_idle; /* why batches left */
+} ufd_sched_stats;
+int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out);
+/* Delivers everything queued, then stops the threads. */
+void ufd_sched_destroy(ufd_sched* s);
+int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* stream);
+int ufd_sched_remove_stream(ufd_sched* s, uint32_t stream);
+/* router.rs:64-71: copies the JPEG into a free slot of the stream's ring (the caller's buffer is free on return);
+ * UFD_E_FULL when there is none. */
+int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag);
+/* Blocks until every frame pushed before the call has been delivered. */
+int ufd_sched_flush(ufd_sched* s);
+int ufd_sched_get_stats(ufd_sched* s, ufd_sched_stats* out);
+/* The batching rule alone (no GPU, no threads): queued[i] frames wait in stream i (streams of one batch class);
+ * starting after stream `last`, one frame per stream per pass until max_batch: take[i] = frames taken from stream i.
+ * Returns the batch size. */
+uint32_t ufd_sched_debug_plan(const uint32_t* queued, uint32_t n_streams, uint32_t last, uint32_t max_batch, uint32_t* take);
 
 /* ---- stage taps (parity tests call the path stage by stage through these) ---- */
 /* N1 stages alone: the rectangles of `n` detections on an RGB8 frame (in place), and the encoder on an RGB8 frame. */

@@ -1991,6 +1991,14 @@ int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32
   return UFD_OK;
 }
 
+int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height) {
+  if (!m) return UFD_E_ARG;
+  if (max_batch) *max_batch = m->B;
+  if (max_src_width) *max_src_width = m->max_w;
+  if (max_src_height) *max_src_height = m->max_h;
+  return UFD_OK;
+}
+
 int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t count,
                         ufd_det* out, uint32_t cap, uint32_t* n) {
   return guarded(m, [&]() -> int {

@@ -1,0 +1,400 @@
+// sched.cpp -- SURVEY 8(f) row N4: multi-stream batching scheduler on the C side of the ABI.
+// Replaces, for many camera streams per GPU, the reference's leg
+//   FrameRouter::run  -> infer_tx.try_send_ref() (drop on a full ring)      infer_server/src/router.rs:64-71
+//   INFER_IMAGES_CHANNEL: StaticChannel<StaticImage, 10>                     infer_server/src/lib.rs:32-37
+//   Inferer::run: one task, one fixed model, one slot at a time              infer_server/src/inferer.rs:23,29-50
+// with per-stream rings, per-stream model variant / output kind, round-robin batch formation under a deadline, and
+// several batches in flight per model.  Pure host code over the public entry points of ufd.h (no HIP calls here).
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/ufd.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+double ms_between(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+struct Frame {  // one ring slot: the reference's StaticImage with the bytes copied in place (router.rs:66-69)
+  std::vector<uint8_t> jpeg;
+  uint64_t tag = 0;
+  Clock::time_point pushed;
+};
+
+struct Stream {
+  ufd_stream_config cfg{};
+  bool alive = false;
+  int klass = -1;
+  std::deque<Frame*> queued;   // waiting for a batch, oldest first
+  std::vector<Frame*> free_;   // ring slots not in use
+  std::vector<std::unique_ptr<Frame>> slots;
+  uint32_t in_batches = 0;     // frames currently inside dispatched batches
+};
+
+// Streams that can share a batch: same model and same kind of output.
+struct Klass {
+  uint32_t variant = 0, annotate = 0, quality = 95, flags = 0;
+  float label_w = 0, label_h = 0;
+  ufd_model* model = nullptr;
+  std::vector<uint32_t> streams;
+  uint32_t last = 0;  // position (in streams) of the stream served last
+};
+
+struct Batch {
+  int klass = -1;
+  uint32_t count = 0, ticket = 0;
+  int why = 0;  // 0 full, 1 deadline, 2 idle
+  std::vector<uint32_t> stream;
+  std::vector<Frame*> frame;
+  std::vector<const uint8_t*> ptrs;
+  std::vector<size_t> lens, joff, jlen;
+  std::vector<ufd_det> dets;
+  std::vector<uint32_t> n;
+  std::vector<int32_t> status;
+  uint8_t* jpeg_out = nullptr;  // pinned (ufd_host_alloc), allocated for the first annotate batch that uses this object
+  size_t jpeg_cap = 0;
+  Clock::time_point dispatched;
+};
+
+}  // namespace
+
+struct ufd_sched {
+  ufd_sched_config cfg{};
+  uint32_t max_batch[2] = {0, 0};
+  std::mutex mu;
+  std::condition_variable cv_dispatch, cv_complete, cv_flush;
+  std::deque<Stream> streams;  // (a deque: entries never move, the completion thread reads them without the lock)
+  std::vector<Klass> klasses;
+  std::deque<Batch*> inflight;             // dispatch order
+  std::vector<std::unique_ptr<Batch>> pool;
+  std::vector<Batch*> free_batches;
+  uint32_t inflight_of[2] = {0, 0};
+  bool stop = false, dispatcher_done = false;
+  ufd_sched_stats stats{};
+  uint64_t flush_target = 0;
+  std::thread dispatcher, completer;
+};
+
+extern "C" uint32_t ufd_sched_debug_plan(const uint32_t* queued, uint32_t n_streams, uint32_t last, uint32_t max_batch, uint32_t* take) {
+  if (!queued || !take || !n_streams) return 0;
+  for (uint32_t i = 0; i < n_streams; i++) take[i] = 0;
+  uint32_t total = 0;
+  bool any = true;
+  while (total < max_batch && any) {  // one frame per stream per pass, starting after the stream served last
+    any = false;
+    for (uint32_t k = 1; k <= n_streams && total < max_batch; k++) {
+      const uint32_t i = (last + k) % n_streams;
+      if (take[i] < queued[i]) take[i]++, total++, any = true;
+    }
+  }
+  return total;
+}
+
+namespace {
+
+int variant_index(uint32_t v) { return v == 320 ? 0 : (v == 640 ? 1 : -1); }
+
+// With the lock held: the next batch of class k if one should leave now, else nullptr; *wake = when to look again.
+Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point* wake) {
+  Klass& kl = s->klasses[k];
+  const int vi = variant_index(kl.variant);
+  if (kl.streams.empty() || s->inflight_of[vi] >= s->cfg.max_inflight) return nullptr;
+  std::vector<uint32_t> queued(kl.streams.size()), take(kl.streams.size());
+  uint32_t waiting = 0;
+  Clock::time_point oldest = Clock::time_point::max();
+  for (size_t i = 0; i < kl.streams.size(); i++) {
+    const Stream& st = s->streams[kl.streams[i]];
+    queued[i] = (uint32_t)st.queued.size();
+    waiting += queued[i];
+    if (!st.queued.empty()) oldest = std::min(oldest, st.queued.front()->pushed);
+  }
+  if (!waiting) return nullptr;
+  const auto deadline = oldest + std::chrono::microseconds(s->cfg.max_wait_us);
+  int why;
+  if (waiting >= s->max_batch[vi]) why = 0;
+  else if (now >= deadline) why = 1;
+  else if (s->inflight_of[vi] == 0) why = 2;  // the model is idle: a lone frame does not wait for company
+  else {
+    *wake = std::min(*wake, deadline);
+    return nullptr;
+  }
+  if (s->free_batches.empty()) {
+    s->pool.emplace_back(new Batch);
+    s->free_batches.push_back(s->pool.back().get());
+  }
+  Batch* b = s->free_batches.back();
+  s->free_batches.pop_back();
+  const uint32_t count = ufd_sched_debug_plan(queued.data(), (uint32_t)queued.size(), kl.last, s->max_batch[vi], take.data());
+  b->klass = k, b->count = count, b->why = why;
+  b->stream.clear(), b->frame.clear(), b->ptrs.clear(), b->lens.clear();
+  // frames in round-robin order too, so that a stream's frames keep their order and streams share the head of the batch
+  std::vector<uint32_t> left = take;
+  const uint32_t start = kl.last;
+  bool any = true;
+  while (any) {
+    any = false;
+    for (uint32_t q = 1; q <= kl.streams.size(); q++) {
+      const uint32_t i = (start + q) % (uint32_t)kl.streams.size();
+      if (!left[i]) continue;
+      kl.last = i;  // the stream served last: the next batch starts after it
+      Stream& st = s->streams[kl.streams[i]];
+      Frame* f = st.queued.front();
+      st.queued.pop_front();
+      st.in_batches++;
+      left[i]--, any = true;
+      b->stream.push_back(kl.streams[i]);
+      b->frame.push_back(f);
+      b->ptrs.push_back(f->jpeg.data());
+      b->lens.push_back(f->jpeg.size());
+    }
+  }
+  b->dets.resize((size_t)count * s->cfg.det_cap);
+  b->n.assign(count, 0);
+  b->status.assign(count, 0);
+  b->joff.assign(count, 0);
+  b->jlen.assign(count, 0);
+  return b;
+}
+
+void dispatcher_main(ufd_sched* s) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    bool sent = false;
+    auto wake = Clock::time_point::max();
+    const auto now = Clock::now();
+    for (int k = 0; k < (int)s->klasses.size(); k++) {
+      Batch* b = form_batch(s, k, now, &wake);
+      if (!b) continue;
+      Klass& kl = s->klasses[k];
+      const int vi = variant_index(kl.variant);
+      b->dispatched = now;
+      s->inflight_of[vi]++;
+      s->stats.batches++, s->stats.frames_in_batches += b->count;
+      (b->why == 0 ? s->stats.sent_full : (b->why == 1 ? s->stats.sent_deadline : s->stats.sent_idle))++;
+      // the submit only queues the batch on the handle's worker: cheap enough to do under the lock
+      int rc;
+      if (kl.annotate) {
+        const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * s->max_batch[vi];
+        if (b->jpeg_cap < need) {
+          if (b->jpeg_out) ufd_host_free(b->jpeg_out);
+          b->jpeg_out = static_cast<uint8_t*>(ufd_host_alloc(need));
+          b->jpeg_cap = b->jpeg_out ? need : 0;
+        }
+        ufd_annotate a;
+        std::memset(&a, 0, sizeof(a));
+        a.struct_size = sizeof(a);
+        a.label_width = kl.label_w, a.label_height = kl.label_h;
+        a.quality = kl.quality, a.flags = kl.flags;
+        a.jpeg_out = b->jpeg_out, a.jpeg_cap = b->jpeg_cap;
+        a.jpeg_off = b->joff.data(), a.jpeg_len = b->jlen.data();
+        rc = ufd_submit_annotate_batch(kl.model, b->ptrs.data(), b->lens.data(), b->count, &a, b->dets.data(), s->cfg.det_cap,
+                                       b->n.data(), b->status.data(), &b->ticket);
+      } else {
+        rc = ufd_submit_jpeg_batch(kl.model, b->ptrs.data(), b->lens.data(), b->count, b->dets.data(), s->cfg.det_cap, b->n.data(),
+                                   b->status.data(), &b->ticket);
+      }
+      if (rc != UFD_OK) {  // nothing ran (all slots busy, bad handle): every frame of the batch reports the failure
+        for (auto& st : b->status) st = rc;
+        b->ticket = 0;
+      }
+      s->inflight.push_back(b);
+      sent = true;
+    }
+    if (sent) {
+      s->cv_complete.notify_all();
+      continue;
+    }
+    if (s->stop) {  // destroy: leave once everything queued has been dispatched
+      bool empty = true;
+      for (const Stream& st : s->streams) empty = empty && st.queued.empty();
+      if (empty) break;
+    }
+    if (wake == Clock::time_point::max()) s->cv_dispatch.wait(lk);
+    else s->cv_dispatch.wait_until(lk, wake);
+  }
+  s->dispatcher_done = true;
+  s->cv_complete.notify_all();
+}
+
+void completer_main(ufd_sched* s) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    s->cv_complete.wait(lk, [&] { return !s->inflight.empty() || s->dispatcher_done; });
+    if (s->inflight.empty()) break;  // the dispatcher has left and nothing is in flight
+    Batch* b = s->inflight.front();
+    const Klass kl = s->klasses[b->klass];
+    lk.unlock();
+    if (b->ticket) {
+      const int rc = ufd_wait(kl.model, b->ticket);
+      if (rc != UFD_OK && rc != UFD_E_TRUNCATED)
+        for (uint32_t i = 0; i < b->count; i++)
+          if (b->status[i] == UFD_OK) b->status[i] = rc;
+    }
+    const auto done = Clock::now();
+    if (s->cfg.on_result) {
+      for (uint32_t i = 0; i < b->count; i++) {
+        ufd_frame_result r;
+        std::memset(&r, 0, sizeof(r));
+        // (stream table entries are stable: removed streams keep their slot until the scheduler is destroyed)
+        r.stream_id = s->streams[b->stream[i]].cfg.stream_id;
+        r.tag = b->frame[i]->tag;
+        r.status = b->status[i];
+        r.variant = kl.variant;
+        const bool ok = r.status == UFD_OK || r.status == UFD_E_TRUNCATED;
+        r.n = ok ? b->n[i] : 0;
+        r.batch_fill = b->count;
+        r.dets = ok ? b->dets.data() + (size_t)i * s->cfg.det_cap : nullptr;
+        if (kl.annotate && ok && b->jlen[i]) r.jpeg = b->jpeg_out + b->joff[i], r.jpeg_len = b->jlen[i];
+        r.queue_ms = ms_between(b->frame[i]->pushed, b->dispatched);
+        r.total_ms = ms_between(b->frame[i]->pushed, done);
+        s->cfg.on_result(s->cfg.user, &r);
+      }
+    }
+    lk.lock();
+    s->inflight.pop_front();
+    s->inflight_of[variant_index(kl.variant)]--;
+    for (uint32_t i = 0; i < b->count; i++) {
+      Stream& st = s->streams[b->stream[i]];
+      st.free_.push_back(b->frame[i]);
+      st.in_batches--;
+    }
+    s->stats.delivered += b->count;
+    s->free_batches.push_back(b);
+    s->cv_dispatch.notify_all();
+    s->cv_flush.notify_all();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(ufd_sched_config)) return UFD_E_ARG;
+  if (!cfg->model_320 && !cfg->model_640) return UFD_E_ARG;
+  std::unique_ptr<ufd_sched> s(new ufd_sched);
+  s->cfg = *cfg;
+  if (!s->cfg.ring_slots) s->cfg.ring_slots = 10;
+  if (!s->cfg.max_wait_us) s->cfg.max_wait_us = 2000;
+  if (!s->cfg.max_inflight) s->cfg.max_inflight = 6;
+  s->cfg.max_inflight = std::min<uint32_t>(s->cfg.max_inflight, UFD_MAX_SLOTS);
+  if (!s->cfg.det_cap) s->cfg.det_cap = 256;
+  if (!s->cfg.jpeg_bytes_per_frame) s->cfg.jpeg_bytes_per_frame = 512 * 1024;
+  ufd_model* models[2] = {cfg->model_320, cfg->model_640};
+  for (int i = 0; i < 2; i++) {
+    if (!models[i]) continue;
+    uint32_t w = 0, mb = 0;
+    if (ufd_model_info(models[i], &w, nullptr, nullptr) != UFD_OK || w != (i ? 640u : 320u)) return UFD_E_ARG;
+    if (ufd_model_limits(models[i], &mb, nullptr, nullptr) != UFD_OK || !mb) return UFD_E_ARG;
+    s->max_batch[i] = mb;
+  }
+  ufd_sched* p = s.release();
+  p->dispatcher = std::thread(dispatcher_main, p);
+  p->completer = std::thread(completer_main, p);
+  *out = p;
+  return UFD_OK;
+}
+
+void ufd_sched_destroy(ufd_sched* s) {
+  if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->stop = true;
+  }
+  s->cv_dispatch.notify_all();
+  if (s->dispatcher.joinable()) s->dispatcher.join();
+  s->cv_complete.notify_all();
+  if (s->completer.joinable()) s->completer.join();
+  for (auto& b : s->pool)
+    if (b->jpeg_out) ufd_host_free(b->jpeg_out);
+  delete s;
+}
+
+int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* stream) {
+  if (!s || !cfg || !stream || cfg->struct_size != sizeof(ufd_stream_config)) return UFD_E_ARG;
+  const int vi = variant_index(cfg->variant);
+  if (vi < 0 || !(vi ? s->cfg.model_640 : s->cfg.model_320)) return UFD_E_ARG;
+  const uint32_t quality = cfg->quality ? cfg->quality : 95;
+  if (cfg->annotate && (quality < 1 || quality > 100)) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  int k = -1;
+  for (size_t i = 0; i < s->klasses.size(); i++) {
+    const Klass& c = s->klasses[i];
+    if (c.variant == cfg->variant && c.annotate == (cfg->annotate ? 1u : 0u) &&
+        (!cfg->annotate || (c.quality == quality && c.flags == cfg->flags && c.label_w == cfg->label_width && c.label_h == cfg->label_height)))
+      k = (int)i;
+  }
+  if (k < 0) {
+    Klass c;
+    c.variant = cfg->variant, c.annotate = cfg->annotate ? 1 : 0, c.quality = quality, c.flags = cfg->flags;
+    c.label_w = cfg->label_width, c.label_h = cfg->label_height;
+    c.model = vi ? s->cfg.model_640 : s->cfg.model_320;
+    s->klasses.push_back(c);
+    k = (int)s->klasses.size() - 1;
+  }
+  s->streams.emplace_back();
+  Stream& st = s->streams.back();
+  st.cfg = *cfg, st.alive = true, st.klass = k;
+  for (uint32_t i = 0; i < s->cfg.ring_slots; i++) {
+    st.slots.emplace_back(new Frame);
+    st.free_.push_back(st.slots.back().get());
+  }
+  *stream = (uint32_t)s->streams.size() - 1;
+  s->klasses[k].streams.push_back(*stream);
+  return UFD_OK;
+}
+
+int ufd_sched_remove_stream(ufd_sched* s, uint32_t stream) {
+  if (!s) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (stream >= s->streams.size() || !s->streams[stream].alive) return UFD_E_ARG;
+  Stream& st = s->streams[stream];
+  st.alive = false;  // frames already queued are still delivered; nothing new is accepted
+  return UFD_OK;
+}
+
+int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag) {
+  if (!s || !jpeg || !len) return UFD_E_ARG;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->stop || stream >= s->streams.size() || !s->streams[stream].alive) return UFD_E_STATE;
+    Stream& st = s->streams[stream];
+    s->stats.pushed++;
+    if (st.free_.empty()) {  // router.rs:65: `if let Ok(mut frame) = self.infer_tx.try_send_ref()` -- else the frame is dropped
+      s->stats.dropped++;
+      return UFD_E_FULL;
+    }
+    Frame* f = st.free_.back();
+    st.free_.pop_back();
+    f->jpeg.assign(jpeg, jpeg + len);  // frame.2.clear(); frame.2.extend_from_slice(..) (router.rs:68-69)
+    f->tag = tag;
+    f->pushed = Clock::now();
+    st.queued.push_back(f);
+  }
+  s->cv_dispatch.notify_all();
+  return UFD_OK;
+}
+
+int ufd_sched_flush(ufd_sched* s) {
+  if (!s) return UFD_E_ARG;
+  std::unique_lock<std::mutex> lk(s->mu);
+  const uint64_t target = s->stats.pushed - s->stats.dropped;
+  s->cv_flush.wait(lk, [&] { return s->stats.delivered >= target; });
+  return UFD_OK;
+}
+
+int ufd_sched_get_stats(ufd_sched* s, ufd_sched_stats* out) {
+  if (!s || !out) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  *out = s->stats;
+  return UFD_OK;
+}
+
+}  // extern "C"

@@ -22,9 +22,10 @@ UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_E
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_MAX_SLOTS = 8
 UFD_ANNOT_MULTIPART = 1
+UFD_E_FULL = -9
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
-                 -5: "UFD_E_DEVICE", -6: "UFD_E_WEIGHTS", -7: "UFD_E_STATE", -8: "UFD_E_TOO_LARGE"}
+                 -5: "UFD_E_DEVICE", -6: "UFD_E_WEIGHTS", -7: "UFD_E_STATE", -8: "UFD_E_TOO_LARGE", -9: "UFD_E_FULL"}
 
 
 class UfdDet(ctypes.Structure):
@@ -47,6 +48,34 @@ class UfdAnnotate(ctypes.Structure):
                 ("jpeg_cap", ctypes.c_size_t), ("jpeg_off", ctypes.c_void_p), ("jpeg_len", ctypes.c_void_p)]
 
 
+class UfdFrameResult(ctypes.Structure):
+    _fields_ = [("stream_id", ctypes.c_uint64), ("tag", ctypes.c_uint64), ("status", ctypes.c_int32), ("variant", ctypes.c_uint32),
+                ("n", ctypes.c_uint32), ("batch_fill", ctypes.c_uint32), ("dets", ctypes.POINTER(UfdDet)),
+                ("jpeg", ctypes.POINTER(ctypes.c_ubyte)), ("jpeg_len", ctypes.c_size_t), ("queue_ms", ctypes.c_double),
+                ("total_ms", ctypes.c_double)]
+
+
+UFD_RESULT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(UfdFrameResult))
+
+
+class UfdSchedConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("model_320", ctypes.c_void_p), ("model_640", ctypes.c_void_p),
+                ("ring_slots", ctypes.c_uint32), ("max_wait_us", ctypes.c_uint32), ("max_inflight", ctypes.c_uint32),
+                ("det_cap", ctypes.c_uint32), ("jpeg_bytes_per_frame", ctypes.c_uint32), ("on_result", UFD_RESULT_FN),
+                ("user", ctypes.c_void_p)]
+
+
+class UfdStreamConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("stream_id", ctypes.c_uint64), ("variant", ctypes.c_uint32),
+                ("annotate", ctypes.c_uint32), ("label_width", ctypes.c_float), ("label_height", ctypes.c_float),
+                ("quality", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+class UfdSchedStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("pushed", "dropped", "delivered", "batches", "frames_in_batches", "sent_full",
+                                               "sent_deadline", "sent_idle")]
+
+
 class UfdKernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
@@ -60,7 +89,9 @@ ABI_SYMBOLS = (
     "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
     "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
     "ufd_submit_annotate_batch", "ufd_annotate_jpeg_batch", "ufd_encode_bound", "ufd_host_alloc", "ufd_host_free",
-    "ufd_debug_draw_rects", "ufd_debug_encode_rgb",
+    "ufd_debug_draw_rects", "ufd_debug_encode_rgb", "ufd_model_limits",
+    "ufd_sched_create", "ufd_sched_destroy", "ufd_sched_add_stream", "ufd_sched_remove_stream", "ufd_sched_push",
+    "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
 )
 
 _lib = None
@@ -116,6 +147,17 @@ def load_library():
     L.ufd_host_free.restype = None
     L.ufd_debug_draw_rects.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_float, ctypes.c_float]
     L.ufd_debug_encode_rgb.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, sz, ctypes.POINTER(sz)]
+    L.ufd_model_limits.argtypes = [vp, pu32, pu32, pu32]
+    L.ufd_sched_create.argtypes = [ctypes.POINTER(UfdSchedConfig), ctypes.POINTER(vp)]
+    L.ufd_sched_destroy.argtypes = [vp]
+    L.ufd_sched_destroy.restype = None
+    L.ufd_sched_add_stream.argtypes = [vp, ctypes.POINTER(UfdStreamConfig), pu32]
+    L.ufd_sched_remove_stream.argtypes = [vp, u32]
+    L.ufd_sched_push.argtypes = [vp, u32, vp, sz, ctypes.c_uint64]
+    L.ufd_sched_flush.argtypes = [vp]
+    L.ufd_sched_get_stats.argtypes = [vp, ctypes.POINTER(UfdSchedStats)]
+    L.ufd_sched_debug_plan.argtypes = [pu32, u32, u32, u32, pu32]
+    L.ufd_sched_debug_plan.restype = u32
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]

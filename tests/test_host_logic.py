@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
 
     lib = nn.load_library()
     header = open(os.path.join(ROOT, "include", "ufd.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void\*?|size_t|const char\*)\s+(ufd_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:int|void\*?|size_t|uint32_t|const char\*)\s+(ufd_\w+)\s*\(", header, re.M))
     assert declared == set(nn.ABI_SYMBOLS), declared ^ set(nn.ABI_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
