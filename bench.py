@@ -95,6 +95,9 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=0, help="host workers of the handle (0: hardware threads / ranks, <= 32)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--annotate", action="store_true",
+                    help="time the whole Inferer::run iteration instead (decode -> infer -> rectangles -> JPEG re-encode, "
+                         "ufd_submit_annotate_batch): a side workload for profiling N1, not BASELINE.json's metric")
     ap.add_argument("--profile-every", type=int, default=8, help="record kernel events for every n-th timed step (0: never)")
     return ap.parse_args()
 
@@ -213,7 +216,24 @@ def main():
             staged_batches = [model.stage_jpeg_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
         return staged_batches
 
+    annot_batches = []
+
     def run_steps(k, staged, depth=None, mdl=None, bts=None):
+        if args.annotate:  # N1 profiling mode: the same pool through ufd_submit_annotate_batch
+            if not annot_batches:
+                for i in range(min(nb, args.depth)):
+                    annot_batches.append(model.prep_annotate_batch(jpegs[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=SW * SH))
+            d_ = min(depth or args.depth, len(annot_batches))
+            infl, dets_ = [], 0
+            for s_ in range(k):
+                if len(infl) >= d_:
+                    cnt_, _, _ = model.wait(infl.pop(0), collect=False)
+                    dets_ += sum(cnt_)
+                infl.append(model.submit_annotate_batch(annot_batches[s_ % d_]))
+            for t_ in infl:
+                cnt_, _, _ = model.wait(t_, collect=False)
+                dets_ += sum(cnt_)
+            return dets_
         mdl = mdl or model
         bts = bts or get_batches(staged)
         depth = min(depth or args.depth, len(bts))  # a batch object (its output arrays) is in flight once at a time
@@ -283,6 +303,8 @@ def main():
         return out
 
     extras = {}
+    if args.annotate:
+        args.no_extras = True
     if world == 1 and not args.no_extras:
         # ---- the same workload over the other boundary
         if device_entropy:
@@ -410,7 +432,8 @@ def main():
                          "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
         flops_frame = 798315520 if args.variant == 640 else 200837120  # 2 x MACs of the 52 convs
         out = {
-            "metric": "frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, W, H),
+            "metric": ("frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, W, H)) if not args.annotate else
+                      ("frames/sec decode->NMS->rectangles->JPEG q95 re-encode (N1 side workload), UltraFace-%d @ %dx%d" % (args.variant, W, H)),
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -9,9 +9,11 @@
 //   as_jpeg_stream_item   (lib.rs:48-57: multipart framing, optional)
 // Byte work, HBM/latency bound, no matrix cores.  Stages (all per batch, one launch each):
 //   k_draw_rects   one workgroup per detection: the four clipped edges into the RGB frame
-//   k_enc_fdct     one thread per 8x8 block: RGB -> Y / box-filtered Cb, Cr (edge samples replicated as jcsample /
-//                  jcprepct do) -> forward DCT -> quantised coefficients in zigzag order, [mcu][Y00 Y01 Y10 Y11 Cb Cr][64];
-//                  dummy blocks beyond a component's block grid as jccoefct.c makes them (DC of the block before, AC 0)
+//   k_enc_ycc      one thread per 8 x 2 pixels: RGB -> Y / box-filtered Cb, Cr planes, MCU padded (edge samples
+//                  replicated as jcsample / jcprepct do)
+//   k_enc_fdct     one thread per 8x8 block of the planes: forward DCT -> quantised coefficients in zigzag order,
+//                  [mcu][Y00 Y01 Y10 Y11 Cb Cr][64]; dummy blocks beyond a component's block grid as jccoefct.c makes
+//                  them (DC of the block before, AC 0)
 //   k_enc_bits     one thread per block: length in bits of its Huffman code
 //   k_enc_scan     one workgroup per frame: exclusive scan -> bit offset of every block; zeroes the bit buffer
 //   k_enc_write    one thread per block: code words at its bit offset (whole words stored, shared edge words OR-ed)
@@ -144,16 +146,86 @@ __device__ __forceinline__ int quant1(int v, const EncQuant& q, int t, int i) {
   return v < 0 ? -r : r;
 }
 
+// RGB -> the encoder's sample planes: Y at full size and box-filtered Cb, Cr (h2v2), all padded to whole MCUs the way
+// libjpeg pads them -- columns past the image repeat the last pixel (jcsample.c expand_right_edge), rows past it the
+// last row of each component (jcprepct.c: the last chroma row that exists is made of rows 2g, min(2g + 1, h - 1)).
+// One thread per 8 x 2 pixels: 2 x 24 bytes in, 2 x 8 luma + 2 x 4 chroma bytes out.
+// Frame layout: Y [16 mcuy][16 mcux] | Cb [8 mcuy][8 mcux] | Cr.
+__global__ __launch_bounds__(256) void k_enc_ycc(const JpegFrameDesc* __restrict__ descs, const uint8_t* __restrict__ rgb,
+                                                 size_t rgb_stride, uint8_t* __restrict__ planes, size_t plane_stride) {
+  const int frame = blockIdx.y;
+  const int w = descs[frame].width, h = descs[frame].height;
+  if (w <= 0 || h <= 0) return;
+  const int mcux = (w + 15) >> 4, mcuy = (h + 15) >> 4;
+  const int yw = 16 * mcux, cw = 8 * mcux, crows = 8 * mcuy;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2 * mcux * crows) return;
+  const int cy = t / (2 * mcux), x0 = (t - cy * 2 * mcux) * 8;
+  const int groups = (h + 1) >> 1;
+  const int cyc = min(cy, groups - 1);
+  const int r0 = 2 * cyc, r1 = min(2 * cyc + 1, h - 1);
+  const uint8_t* img = rgb + (size_t)frame * rgb_stride;
+  const uint8_t* p0 = img + (size_t)r0 * w * 3;
+  const uint8_t* p1 = img + (size_t)r1 * w * 3;
+  int px[2][24];
+  if (x0 + 8 <= w && ((reinterpret_cast<uintptr_t>(p0 + 3 * x0) | reinterpret_cast<uintptr_t>(p1 + 3 * x0)) & 3) == 0) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>((r ? p1 : p0) + 3 * x0);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const uint32_t v = q[i];
+        px[r][4 * i] = v & 255, px[r][4 * i + 1] = (v >> 8) & 255, px[r][4 * i + 2] = (v >> 16) & 255, px[r][4 * i + 3] = v >> 24;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int x = min(x0 + j, w - 1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) px[0][3 * j + c] = p0[3 * x + c], px[1][3 * j + c] = p1[3 * x + c];
+    }
+  }
+  uint8_t* fp = planes + (size_t)frame * plane_stride;
+  uint32_t yv[2][2] = {{0, 0}, {0, 0}};
+  int cb[2][8], cr[2][8];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int R = px[r][3 * j], G = px[r][3 * j + 1], B = px[r][3 * j + 2];
+      yv[r][j >> 2] |= (uint32_t)ycc_y(R, G, B) << (8 * (j & 3));
+      cb[r][j] = ycc_cb(R, G, B), cr[r][j] = ycc_cr(R, G, B);
+    }
+  // luma rows 2cy and 2cy + 1: below the image both repeat row h - 1 (= r1 there)
+  const bool below = cy >= groups;
+  uint8_t* yo = fp + (size_t)(2 * cy) * yw + x0;
+  *reinterpret_cast<uint2*>(yo) = below ? make_uint2(yv[1][0], yv[1][1]) : make_uint2(yv[0][0], yv[0][1]);
+  *reinterpret_cast<uint2*>(yo + yw) = make_uint2(yv[1][0], yv[1][1]);
+  uint32_t cbo = 0, cro = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // h2v2_downsample: bias 1, 2, 1, 2, ... by output column (x0 / 2 is a multiple of 4)
+    const int bias = (k & 1) ? 2 : 1;
+    cbo |= (uint32_t)((cb[0][2 * k] + cb[0][2 * k + 1] + cb[1][2 * k] + cb[1][2 * k + 1] + bias) >> 2) << (8 * k);
+    cro |= (uint32_t)((cr[0][2 * k] + cr[0][2 * k + 1] + cr[1][2 * k] + cr[1][2 * k + 1] + bias) >> 2) << (8 * k);
+  }
+  const size_t ysz = (size_t)yw * 16 * mcuy, csz = (size_t)cw * crows;
+  *reinterpret_cast<uint32_t*>(fp + ysz + (size_t)cy * cw + (x0 >> 1)) = cbo;
+  *reinterpret_cast<uint32_t*>(fp + ysz + csz + (size_t)cy * cw + (x0 >> 1)) = cro;
+}
+
+// One thread per 8x8 block of the planes: forward DCT + quantisation -> [mcu][Y00 Y01 Y10 Y11 Cb Cr][64] in zigzag order.
 template <bool IFAST>
-__global__ __launch_bounds__(256) void k_enc_fdct(const JpegFrameDesc* __restrict__ descs, const uint8_t* __restrict__ rgb,
-                                                  size_t rgb_stride, EncQuant q, int16_t* __restrict__ coef, size_t coef_stride) {
+__global__ __launch_bounds__(256) void k_enc_fdct(const JpegFrameDesc* __restrict__ descs, const uint8_t* __restrict__ planes,
+                                                  size_t plane_stride, EncQuant q, int16_t* __restrict__ coef, size_t coef_stride) {
   const int frame = blockIdx.y;
   const int w = descs[frame].width, h = descs[frame].height;
   if (w <= 0 || h <= 0) return;
   const int mcux = (w + 15) >> 4, mcuy = (h + 15) >> 4, nmcu = mcux * mcuy;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= 6 * nmcu) return;
-  const uint8_t* img = rgb + (size_t)frame * rgb_stride;
+  const uint8_t* fp = planes + (size_t)frame * plane_stride;
+  const int yw = 16 * mcux, cw = 8 * mcux;
   int comp, bx, by, mcu, blk;
   if (t < 4 * nmcu) {
     comp = 0, by = t / (2 * mcux), bx = t - by * 2 * mcux;
@@ -166,47 +238,28 @@ __global__ __launch_bounds__(256) void k_enc_fdct(const JpegFrameDesc* __restric
   }
   int16_t* out = coef + (size_t)frame * coef_stride + ((size_t)mcu * 6 + blk) * 64;
   const int tq = comp ? 1 : 0;
-  int ws[64];
   bool dummy = false;
+  const uint8_t* src;
+  int pitch;
   if (comp == 0) {
+    // jccoefct.c: blocks beyond the component's own block grid (odd block counts) are dummies -- AC 0, DC = the DC of
+    // the block before: the block to the left, or for a whole dummy row block 1 of the MCU (itself a dummy of block 0
+    // when that column is one)
     const int ybw = (w + 7) >> 3, ybh = (h + 7) >> 3;
     int sbx = bx, sby = by;
-    if (by >= ybh) {  // a row of dummy blocks: DC of block 1 of the MCU (itself a dummy of block 0 when that column is)
-      dummy = true, sby = by - 1, sbx = (bx | 1) < ybw ? (bx | 1) : (bx & ~1);
-    } else if (bx >= ybw) {  // dummy column: DC of the block to the left
-      dummy = true, sbx = bx - 1;
-    }
-#pragma unroll
-    for (int yy = 0; yy < 8; yy++) {
-      const int y = min(sby * 8 + yy, h - 1);  // rows past the image repeat the last one (jcprepct.c)
-      const uint8_t* row = img + (size_t)y * w * 3;
-#pragma unroll
-      for (int xx = 0; xx < 8; xx++) {
-        const int x = min(sbx * 8 + xx, w - 1);  // expand_right_edge
-        ws[yy * 8 + xx] = ycc_y(row[3 * x], row[3 * x + 1], row[3 * x + 2]) - 128;
-      }
-    }
+    if (by >= ybh) dummy = true, sby = by - 1, sbx = (bx | 1) < ybw ? (bx | 1) : (bx & ~1);
+    else if (bx >= ybw) dummy = true, sbx = bx - 1;
+    src = fp + (size_t)sby * 8 * yw + sbx * 8, pitch = yw;
   } else {
-    const int groups = (h + 1) >> 1;  // chroma rows that exist; later rows repeat the last one
+    const size_t ysz = (size_t)yw * 16 * mcuy, csz = (size_t)cw * 8 * mcuy;
+    src = fp + ysz + (comp == 2 ? csz : 0) + (size_t)by * 8 * cw + bx * 8, pitch = cw;
+  }
+  int ws[64];
 #pragma unroll
-    for (int yy = 0; yy < 8; yy++) {
-      const int cy = min(by * 8 + yy, groups - 1);
-      const uint8_t* r0 = img + (size_t)(2 * cy) * w * 3;
-      const uint8_t* r1 = img + (size_t)min(2 * cy + 1, h - 1) * w * 3;
+  for (int yy = 0; yy < 8; yy++) {
+    const uint2 v = *reinterpret_cast<const uint2*>(src + (size_t)yy * pitch);
 #pragma unroll
-      for (int xx = 0; xx < 8; xx++) {
-        const int cx = bx * 8 + xx;
-        const int xa = min(2 * cx, w - 1), xb = min(2 * cx + 1, w - 1);
-        int s;
-        if (comp == 1)
-          s = ycc_cb(r0[3 * xa], r0[3 * xa + 1], r0[3 * xa + 2]) + ycc_cb(r0[3 * xb], r0[3 * xb + 1], r0[3 * xb + 2]) +
-              ycc_cb(r1[3 * xa], r1[3 * xa + 1], r1[3 * xa + 2]) + ycc_cb(r1[3 * xb], r1[3 * xb + 1], r1[3 * xb + 2]);
-        else
-          s = ycc_cr(r0[3 * xa], r0[3 * xa + 1], r0[3 * xa + 2]) + ycc_cr(r0[3 * xb], r0[3 * xb + 1], r0[3 * xb + 2]) +
-              ycc_cr(r1[3 * xa], r1[3 * xa + 1], r1[3 * xa + 2]) + ycc_cr(r1[3 * xb], r1[3 * xb + 1], r1[3 * xb + 2]);
-        ws[yy * 8 + xx] = ((s + ((cx & 1) ? 2 : 1)) >> 2) - 128;  // h2v2_downsample: bias 1, 2, 1, 2, ...
-      }
-    }
+    for (int xx = 0; xx < 8; xx++) ws[yy * 8 + xx] = (int)(((xx < 4 ? v.x : v.y) >> (8 * (xx & 3))) & 255) - 128;
   }
   uint4* o4 = reinterpret_cast<uint4*>(out);
   if (dummy) {
@@ -573,8 +626,11 @@ void launch_jpeg_encode(const JpegFrameDesc* d_descs, const uint8_t* d_rgb, size
     if (hook) (*hook)(name, begin);
   };
   stage("enc_fdct", true);
-  if (ifast) hipLaunchKernelGGL(k_enc_fdct<true>, gblk, dim3(256), 0, s, d_descs, d_rgb, rgb_stride, q, e.coef, e.coef_stride);
-  else hipLaunchKernelGGL(k_enc_fdct<false>, gblk, dim3(256), 0, s, d_descs, d_rgb, rgb_stride, q, e.coef, e.coef_stride);
+  const uint32_t ycc_threads = 2 * ((max_w + 15) / 16) * 8 * ((max_h + 15) / 16);
+  hipLaunchKernelGGL(k_enc_ycc, dim3((ycc_threads + 255) / 256, count), dim3(256), 0, s, d_descs, d_rgb, rgb_stride, e.planes,
+                     e.plane_stride);
+  if (ifast) hipLaunchKernelGGL(k_enc_fdct<true>, gblk, dim3(256), 0, s, d_descs, e.planes, e.plane_stride, q, e.coef, e.coef_stride);
+  else hipLaunchKernelGGL(k_enc_fdct<false>, gblk, dim3(256), 0, s, d_descs, e.planes, e.plane_stride, q, e.coef, e.coef_stride);
   stage("enc_fdct", false);
   stage("enc_huffman", true);
   hipLaunchKernelGGL(k_enc_bits, gblk, dim3(256), 0, s, d_descs, e.coef, e.coef_stride, e.tables, e.bits, e.blk_stride);

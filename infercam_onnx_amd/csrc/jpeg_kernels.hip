@@ -356,7 +356,69 @@ __global__ __launch_bounds__(256) void k_upsample_norm_420(const JpegFrameDesc* 
   *reinterpret_cast<float4*>(o + 2 * hw + 4) = make_float4(bl[4], bl[5], bl[6], bl[7]);
 }
 
+// The same 4:2:0 fast path with interleaved RGB8 output (frames of any size whose width is a multiple of 8): what the
+// resize stage reads for frames that are not at the model size, and what N1 draws on and re-encodes.
+// Bit-identical to k_upsample_rgb.
+__global__ __launch_bounds__(256) void k_upsample_rgb_420(const JpegFrameDesc* __restrict__ descs,
+                                                          const uint8_t* __restrict__ planes, size_t plane_stride,
+                                                          uint8_t* __restrict__ rgb, size_t rgb_stride) {
+  const int frame = blockIdx.y;
+  const JpegFrameDesc& d = descs[frame];
+  const int W = d.width, H = d.height;
+  if (W <= 0) return;  // failed / skipped frame
+  const int gw = W >> 3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= gw * H) return;
+  const int y = t / gw, x0 = (t - y * gw) * 8;
+  const uint8_t* fp = planes + (size_t)frame * plane_stride;
+  const int ypitch = d.wblk[0] * 8, cpitch = d.wblk[1] * 8;
+  const int dw = d.dw[1], dh = d.dh[1];
+  const uint2 yy = *reinterpret_cast<const uint2*>(fp + d.plane_off[0] + (size_t)y * ypitch + x0);
+  const int iy = y >> 1, ny = max(0, min(dh - 1, (y & 1) ? iy + 1 : iy - 1));
+  const int c0 = x0 >> 1, cl = max(c0 - 1, 0), cr = min(c0 + 4, dw - 1);
+  int s[2][6];  // column sums 3*near + far for chroma columns c0-1 .. c0+4 (clamped)
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const uint8_t* p0 = fp + d.plane_off[1 + c] + (size_t)iy * cpitch;
+    const uint8_t* p1 = fp + d.plane_off[1 + c] + (size_t)ny * cpitch;
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(p0 + c0), b = *reinterpret_cast<const uint32_t*>(p1 + c0);
+    s[c][0] = 3 * p0[cl] + p1[cl];
+    s[c][5] = 3 * p0[cr] + p1[cr];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[c][1 + i] = 3 * (int)((a >> (8 * i)) & 255) + (int)((b >> (8 * i)) & 255);
+  }
+  uint32_t px[24];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = 1 + (j >> 1);  // chroma column of this pixel inside s[]
+    int cbv, crv;
+    if (j & 1) {
+      cbv = (s[0][i] * 3 + s[0][i + 1] + 7) >> 4;
+      crv = (s[1][i] * 3 + s[1][i + 1] + 7) >> 4;
+    } else {
+      cbv = (s[0][i] * 3 + s[0][i - 1] + 8) >> 4;
+      crv = (s[1][i] * 3 + s[1][i - 1] + 8) >> 4;
+    }
+    const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
+    const int cb = cbv - 128, crr = crv - 128;
+    px[3 * j] = (uint32_t)clamp255(yv + ((91881 * crr + 32768) >> 16));
+    px[3 * j + 1] = (uint32_t)clamp255(yv + ((-22554 * cb + 32768 - 46802 * crr) >> 16));
+    px[3 * j + 2] = (uint32_t)clamp255(yv + ((116130 * cb + 32768) >> 16));
+  }
+  // 24 bytes at a 4-byte aligned address (W % 8 == 0, rgb_stride % 4 == 0: launcher-checked)
+  uint32_t* o = reinterpret_cast<uint32_t*>(rgb + (size_t)frame * rgb_stride + ((size_t)y * W + x0) * 3);
+#pragma unroll
+  for (int q = 0; q < 6; q++) o[q] = px[4 * q] | (px[4 * q + 1] << 8) | (px[4 * q + 2] << 16) | (px[4 * q + 3] << 24);
+}
+
 }  // namespace
+
+void launch_upsample_rgb_420(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
+                             size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s) {
+  if (!count) return;
+  dim3 grid(((max_w / 8) * max_h + 255) / 256, count);
+  hipLaunchKernelGGL(k_upsample_rgb_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
+}
 
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
                  size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s) {

@@ -18,6 +18,9 @@ void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coe
 // Fancy upsampling + colour conversion -> interleaved RGB8 (pitch 3*width, frame stride rgb_stride).
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
                          size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s);
+// 4:2:0 YCbCr frames whose width is a multiple of 8 (every non-skipped frame of the batch): same pixels, 8 per thread.
+void launch_upsample_rgb_420(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
+                             size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s);
 // Same, fused with the A4 normalisation for frames that already have the model size:
 // -> f32 [count][3][H][W].  norm_lut: [3][256].
 void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
@@ -222,6 +225,8 @@ struct EncQuant {
 };
 // Device working set of the encoder for one batch (one per context, allocated on first use).
 struct EncBuffers {
+  uint8_t* planes = nullptr;     // [frame] Y [16 mcuy][16 mcux] | Cb [8 mcuy][8 mcux] | Cr: MCU-padded sample planes
+  size_t plane_stride = 0;
   int16_t* coef = nullptr;       // [frame][mcu][Y00 Y01 Y10 Y11 Cb Cr][64] quantised, zigzag order
   size_t coef_stride = 0;        // int16 per frame
   uint32_t* bits = nullptr;      // [frame][block] code length, then (in place) bit offset

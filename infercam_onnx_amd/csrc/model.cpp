@@ -1367,6 +1367,8 @@ int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart) {
     e.blk_stride = mcus * 6;
     e.word_stride = (((sb + 3) / 4 + 3) & ~(size_t)3) + 8;  // whole 16-byte groups + the padding the scan zeroes
     e.chunk_stride = (sb + 4095) / 4096 + 1;
+    e.plane_stride = mcus * 384;  // 256 luma + 2 x 64 chroma samples per MCU
+    HIPC(m, hipMalloc(&e.planes, e.plane_stride * m->B));
     HIPC(m, hipMalloc(&e.coef, sizeof(int16_t) * e.coef_stride * m->B));
     HIPC(m, hipMalloc(&e.bits, sizeof(uint32_t) * e.blk_stride * m->B));
     HIPC(m, hipMalloc(&e.total_bits, sizeof(uint32_t) * m->B));
@@ -1471,6 +1473,30 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
   return run_decoded(m, s, count, g.plan.any_ok, g.d_descs, c.d_coef_buf[buf], buf);
 }
 
+// Every decodable frame of the batch is 3-component YCbCr 4:2:0 (what the fancy-upsampling fast paths take).
+bool batch_is_420(const Slot& s, uint32_t count) {
+  for (uint32_t i = 0; i < count; i++) {
+    if (s.st[i] != UFD_OK) continue;
+    const JpegFrameDesc& d = s.h_descs[i];
+    if (!(d.ncomp == 3 && d.color == kColorYCbCr && d.h[0] == 2 && d.v[0] == 2 && d.h[1] == 1 && d.v[1] == 1 && d.h[2] == 1 &&
+          d.v[2] == 1 && d.dw[1] > 2))
+      return false;
+  }
+  return true;
+}
+
+// Decoded sample planes -> interleaved RGB8 frames in the context's d_rgb (tight pitch).
+void enqueue_upsample_rgb(ufd_model* m, const Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count) {
+  bool fast = batch_is_420(s, count) && (m->rgb_stride % 4) == 0;
+  for (uint32_t i = 0; i < count && fast; i++)
+    if (s.st[i] == UFD_OK && (s.h_descs[i].width % 8) != 0) fast = false;
+  ProfScope ps(m, fast ? "upsample_rgb_420" : "upsample_rgb", 0, 0);
+  if (fast)
+    launch_upsample_rgb_420(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
+  else
+    launch_upsample_rgb(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
+}
+
 // Coefficient slabs -> detections: IDCT, upsampling + colour + normalisation (+ resize), the
 // network, head decode, NMS and the result copy, all on the context's stream.
 int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFrameDesc* d_descs_in, int16_t* d_coef_in, int buf) {
@@ -1493,20 +1519,12 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       ProfScope ps(m, "idct", 0, 0);
       launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream);
     }
-    if (all_model_size && s.annot) {  // N1 encodes the decoded frame: the RGB image the fused paths never make
-      ProfScope ps(m, "upsample_rgb", 0, 0);
-      launch_upsample_rgb(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
-    }
+    if (all_model_size && s.annot)  // N1 encodes the decoded frame: the RGB image the fused paths never make
+      enqueue_upsample_rgb(m, s, d_descs, mw, mh, count);
     if (all_model_size) {
       // failed frames keep stale input; their results are never reported
       // camera streams are 4:2:0 YCbCr: specialised kernel when every decoded frame qualifies
-      bool all_420 = (m->W % 8) == 0;
-      for (uint32_t i = 0; i < count && all_420; i++) {
-        if (s.st[i] != UFD_OK) continue;
-        const JpegFrameDesc& d = s.h_descs[i];
-        all_420 = d.ncomp == 3 && d.color == kColorYCbCr && d.h[0] == 2 && d.v[0] == 2 && d.h[1] == 1 && d.v[1] == 1 &&
-                  d.h[2] == 1 && d.v[2] == 1 && d.dw[1] > 2;
-      }
+      const bool all_420 = (m->W % 8) == 0 && batch_is_420(s, count);
       // 4:2:0 frames at the model size: the stem conv reads the sample planes itself (no f32 input
       // tensor); UFD_NO_STEM_FUSE=1 at ufd_create keeps the two-kernel path
       if (all_420 && m->stem_fusable) {
@@ -1523,10 +1541,7 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
         tl_cur->consumed_valid[buf] = true;
       }
     } else {
-      {
-        ProfScope ps(m, "upsample_rgb", 0, 0);
-        launch_upsample_rgb(d_descs, tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, mw, mh, count, tl_cur->stream);
-      }
+      enqueue_upsample_rgb(m, s, d_descs, mw, mh, count);
       HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
       tl_cur->consumed_valid[buf] = true;
       // one camera stream = one frame size: the whole batch in one launch (failed frames resample
@@ -1707,7 +1722,7 @@ void destroy(ufd_model* m) {
     dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_ndet);
     dfree(c.d_spill);
     dfree(c.d_nms_mat);
-    dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
+    dfree(c.enc.planes), dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
     dfree(c.d_enc_tables), dfree(c.d_enc_header), dfree(c.d_enc_descs);
   }
   for (float* t : m->tap_buf) dfree(t);
