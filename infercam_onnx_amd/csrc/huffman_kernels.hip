@@ -39,7 +39,7 @@ namespace {
 //                   gives every subsequence its first MCU;
 //   k_huff_write    one lane per subsequence decodes it a last time from its true entry state and
 //                   stores the coefficients, DC as differences;
-//   k_dc_prefix     DC differences -> DC values.
+//   k_dc_prefix     DC differences -> DC values, on a compact side array (one int16 per block) that k_idct reads.
 // Integer, latency-bound work spread over the whole chip in short launches.
 constexpr int kSyncThreads = 1024;
 constexpr int kSyncMinBytes = 64;  // shortest subsequence
@@ -151,10 +151,10 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
 }
 
 // Same walk from the true entry state, storing the coefficients: AC in ZIGZAG order (the IDCT
-// kernel undoes it), DC as differences (k_dc_prefix sums them).  Zero coefficients are not stored
+// kernel undoes it), DC differences into the compact side array (k_dc_prefix sums them).  Zero coefficients are not stored
 // (the slab is pre-zeroed).
 __device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, uint32_t limit, const WriteTables& T, int bpm,
-                                           int16_t* fcoef, int mcu, int total_mcus, bool* bad) {
+                                           int16_t* fcoef, int16_t* fdc, int mcu, int total_mcus, bool* bad) {
   uint32_t pos = st.p;
   int c = (int)(st.cz & 0xFF), z = (int)(st.cz >> 8);
   if (mcu >= total_mcus) return;  // trailing pad bits only
@@ -180,7 +180,7 @@ __device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, 
     bw.skip(adv);
     pos += (uint32_t)adv;
     if (z == 0) {
-      if (val) blk[0] = (int16_t)val;
+      fdc[(blk - fcoef) >> 6] = (int16_t)val;  // DC difference of the block, in the compact side array (k_dc_prefix sums it)
       if ((e & 0xFF) > 15) *bad = true;
       z = 1;
     } else if (sz) {
@@ -716,27 +716,29 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
   const uint32_t limit = sb.lim[fbase + i] & 0x7FFFFFFFu;
   const HuffInterval& sg = ivs[sc.seg_base + sb.seg[fbase + i]];
   const int mcu_end = (int)(sg.mcu0 + sg.nmcu);  // (a segment never writes into the next one's MCUs)
+  int16_t* fdc = sb.dc + (size_t)frame * sb.dc_stride;
   if (staged)
-    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i], mcu_end,
+    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, sb.mcu0[fbase + i], mcu_end,
                &bad);
   else
-    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, sb.mcu0[fbase + i], mcu_end,
+    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, sb.mcu0[fbase + i], mcu_end,
                &bad);
   if (bad) atomicOr(&status[frame], 1u);
 }
 
 // DC differences -> DC values: per component a running sum over the blocks in scan order, restarted
 // at every restart interval (jdhuff.c last_dc_val / process_restart).  One workgroup per frame,
-// one MCU per thread and pass.
+// one MCU per thread and pass, on the compact side array of DC terms (one int16 per block, in the slab's block order:
+// 14 KB per 640x480 frame instead of a 128-byte-strided walk over the 0.9 MB slab); k_idct takes the DC from there.
 __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __restrict__ scans,
                                                             const JpegFrameDesc* __restrict__ descs,
-                                                            int16_t* __restrict__ coef, size_t coef_stride) {
+                                                            int16_t* __restrict__ dc, size_t dc_stride) {
   __shared__ int s_wave[kSyncThreads / 64];
   __shared__ int s_pre[3][kSyncThreads];  // exclusive prefix of this pass (without the carry)
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (scans[frame].nseg == 0) return;
   const JpegFrameDesc& d = descs[frame];
-  int16_t* fcoef = coef + (size_t)frame * coef_stride;
+  int16_t* fdc = dc + (size_t)frame * dc_stride;
   const int total = d.mcux * d.mcuy;
   const int ri = d.restart_interval > 0 ? d.restart_interval : total;
   int carry[3] = {0, 0, 0};      // sum over all MCUs in front of this pass
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
       for (int c = 0; c < d.ncomp; c++)
         for (int by = 0; by < d.v[c]; by++)
           for (int bx = 0; bx < d.h[c]; bx++)
-            sums[c] += fcoef[d.coef_off[c] + ((size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx) * 64];
+            sums[c] += fdc[(d.coef_off[c] >> 6) + (size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx];
     int pre[3], tot[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
       for (int c = 0; c < d.ncomp; c++)
         for (int by = 0; by < d.v[c]; by++)
           for (int bx = 0; bx < d.h[c]; bx++) {
-            int16_t* p = fcoef + d.coef_off[c] + ((size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx) * 64;
+            int16_t* p = fdc + (d.coef_off[c] >> 6) + (size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx;
             pred[c] += *p;
             *p = (int16_t)pred[c];
           }
@@ -802,7 +804,7 @@ void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, ui
   hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs);
 }
 
-size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers* layout) {
+size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride, SyncBuffers* layout) {
   // carve one allocation: returns the size; with layout != nullptr fills offsets relative to layout->stream
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -822,6 +824,7 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
   const size_t o_map = take(subs * sizeof(unsigned long long));
   const size_t o_lim = take(subs * sizeof(uint32_t));
   const size_t o_seg = take(subs * sizeof(uint16_t));
+  const size_t o_dc = take(dc_stride * sizeof(int16_t) * max_frames);
   if (layout) {
     uint8_t* base = layout->stream;
     layout->stream = base + o_stream;
@@ -836,6 +839,8 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers
     layout->map = reinterpret_cast<unsigned long long*>(base + o_map);
     layout->lim = reinterpret_cast<uint32_t*>(base + o_lim);
     layout->seg = reinterpret_cast<uint16_t*>(base + o_seg);
+    layout->dc = reinterpret_cast<int16_t*>(base + o_dc);
+    layout->dc_stride = dc_stride;
     layout->max_frames = max_frames;
   }
   return off;
@@ -872,7 +877,7 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
     hipLaunchKernelGGL(k_huff_write, dim3((nsub + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
                        d_luts, d_descs, sb, d_coef, coef_stride, d_status);
   });
-  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, d_coef, coef_stride); });
+  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, sb.dc, sb.dc_stride); });
 }
 
 }  // namespace ufd

@@ -83,7 +83,8 @@ __constant__ uint8_t c_nat_to_zig[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4, 
 // markers) instead of natural order.
 template <bool ZZ>
 __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ descs, const int16_t* __restrict__ coef,
-                                              size_t coef_stride, uint8_t* __restrict__ planes, size_t plane_stride) {
+                                              size_t coef_stride, uint8_t* __restrict__ planes, size_t plane_stride,
+                                              const int16_t* __restrict__ dc, size_t dc_stride) {
   __shared__ __attribute__((aligned(16))) int16_t s_in[kBlocksPerWG * 64];
   __shared__ int s_ws[kBlocksPerWG * kWsStride];
   const int frame = blockIdx.y;
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ 
   const int tid = threadIdx.x;
   const int16_t* src = coef + (size_t)frame * coef_stride + (size_t)g0 * 64;
   if (tid * 8 < nblk * 64) {
-    *reinterpret_cast<uint4*>(&s_in[tid * 8]) = *reinterpret_cast<const uint4*>(src + tid * 8);
+    uint4 v = *reinterpret_cast<const uint4*>(src + tid * 8);
+    // the device entropy decoder keeps the DC terms in a compact side array (the thread that loads a block's head patches it in)
+    if (dc && (tid & 7) == 0) v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)dc[(size_t)frame * dc_stride + g0 + (tid >> 3)];
+    *reinterpret_cast<uint4*>(&s_in[tid * 8]) = v;
   }
   __syncthreads();
   // pass 1: columns.  thread -> (local block, column)
@@ -421,13 +425,14 @@ void launch_upsample_rgb_420(const JpegFrameDesc* d_descs, const uint8_t* d_plan
 }
 
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
-                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s) {
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s, const int16_t* d_dc,
+                 size_t dc_stride) {
   if (!count || !max_blocks) return;
   dim3 grid((max_blocks + kBlocksPerWG - 1) / kBlocksPerWG, count);
   if (zigzag)
-    hipLaunchKernelGGL(k_idct<true>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
+    hipLaunchKernelGGL(k_idct<true>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
   else
-    hipLaunchKernelGGL(k_idct<false>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride);
+    hipLaunchKernelGGL(k_idct<false>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
 }
 
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,

@@ -13,8 +13,10 @@ namespace ufd {
 
 // ---------------- A1: JPEG reconstruction (jpeg_kernels.hip) ----------------
 // Dequantise + ISLOW IDCT of every 8x8 block of `count` frames into u8 sample planes.
+// d_dc (device entropy decoder): DC term of block g of frame f at d_dc[f * dc_stride + g], overriding the slab's; or null.
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
-                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s);
+                 size_t plane_stride, uint32_t max_blocks, uint32_t count, bool zigzag, hipStream_t s,
+                 const int16_t* d_dc = nullptr, size_t dc_stride = 0);
 // Fancy upsampling + colour conversion -> interleaved RGB8 (pitch 3*width, frame stride rgb_stride).
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
                          size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s);
@@ -86,12 +88,14 @@ struct SyncBuffers {
   uint32_t* lim = nullptr; // [frame][subsequence] end of the slot's data in bits (min(slot end, segment end)) | first-of-segment << 31
   uint16_t* seg = nullptr; // [frame][subsequence] segment of the slot
   unsigned long long* map = nullptr;  // [frame][subsequence] slot -> slot of the next subsequence, 16 nibbles
+  int16_t* dc = nullptr;   // [frame][block] DC term of every block (differences from k_huff_write, values after k_dc_prefix)
+  size_t dc_stride = 0;
   uint32_t max_frames = 0;
 };
 // Called before (true) and after (false) each kernel of the pipeline with its short name (profiling).
 using HuffStageHook = std::function<void(const char* kernel, bool begin)>;
 // Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
-size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, SyncBuffers* layout);
+size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride /* blocks per frame */, SyncBuffers* layout);
 // Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
 void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, hipStream_t s);
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,

@@ -1517,7 +1517,8 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
     int16_t* d_coef = d_coef_in;
     {
       ProfScope ps(m, "idct", 0, 0);
-      launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream);
+      launch_idct(d_descs, d_coef, m->coef_stride, tl_cur->d_planes, m->plane_stride, max_blocks, count, s.coef_zigzag, tl_cur->stream,
+                  s.gpu_entropy ? tl_cur->sync.dc : nullptr, tl_cur->sync.dc_stride);
     }
     if (all_model_size && s.annot)  // N1 encodes the decoded frame: the RGB image the fused paths never make
       enqueue_upsample_rgb(m, s, d_descs, mw, mh, count);
@@ -1913,9 +1914,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
       HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
     }
     if (m->gpu_entropy_enabled) {
-      HIPB(hipMalloc(&c.d_sync, sync_buffers_bytes((uint32_t)B, m->blob_stride, nullptr)));
+      HIPB(hipMalloc(&c.d_sync, sync_buffers_bytes((uint32_t)B, m->blob_stride, m->coef_stride / 64, nullptr)));
       c.sync.stream = c.d_sync;
-      sync_buffers_bytes((uint32_t)B, m->blob_stride, &c.sync);
+      sync_buffers_bytes((uint32_t)B, m->blob_stride, m->coef_stride / 64, &c.sync);
     }
     HIPB(hipMalloc(&c.d_planes, m->plane_stride * B));
     HIPB(hipMalloc(&c.d_rgb, m->rgb_stride * B));
@@ -2326,7 +2327,8 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
     const size_t bytes = (size_t)d->width * d->height * 3;
     if (cap_bytes < bytes) return m->fail(UFD_E_ARG, "rgb buffer too small");
     launch_idct(tl_cur->d_descs_buf[buf], tl_cur->d_coef_buf[buf], m->coef_stride, tl_cur->d_planes, m->plane_stride,
-                d->total_blocks, 1, s->coef_zigzag, tl_cur->stream);
+                d->total_blocks, 1, s->coef_zigzag, tl_cur->stream, s->gpu_entropy ? tl_cur->sync.dc : nullptr,
+                tl_cur->sync.dc_stride);
     launch_upsample_rgb(tl_cur->d_descs_buf[buf], tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, d->width,
                         d->height, 1, tl_cur->stream);
     HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
