@@ -13,3 +13,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --depth 1 --no-cpu-baseline --no-variants --pool 64 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --depth 1 --no-cpu-baseline --no-variants --pool 64 > /dev/null 2>&1
 find $out -name "*.csv" < /dev/null | head -20
+# then, back in the build container: python tools/finish_profiles.py <name>
