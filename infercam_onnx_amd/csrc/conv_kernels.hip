@@ -610,7 +610,12 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
 // a[0]: first block (in, w2 = dw [C1][12], w = packed pw, bias, relu); a[1]: second block
 // (w2 = dw [32][12], w = packed pw, bias, relu, out...).  Needs a[0].iw % 8 == 0, a[1].ow % 4 == 0,
 // a[1].oh % a[1].band == 0.
-template <int C1, int CT2>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
+// ROW RING (RING = true, the 16-channel instance): consecutive X1 rows of a band share two of their three input
+// rows.  Each wave keeps those two rows of its strip in LDS for all channels (2 x C1/2 k-steps x 64 lanes x 16 B =
+// 16 KB per wave; a lane only ever reads back what it wrote itself, so there is no barrier), and per k-step loads
+// only the NEW bottom row from global memory: one 16-byte global load and two LDS reads instead of three global
+// loads, and every input row crosses the memory system once per band instead of three times.
+template <int C1, int CT2, bool RING>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
   const ConvArgs& a2 = p3.a[1];
@@ -623,6 +628,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* s_b1 = s_w2 + CT2 * KS2 * 64; // [32] bias of the first pointwise conv
   float* s_b2 = s_b1 + 32;             // [32 * CT2] bias of the second (0 beyond cout)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // RING: [wave][2 row slots][KS1][64 lanes] float4 behind the tables (a multiple of 16 bytes in)
+  float4* const s_ring = reinterpret_cast<float4*>(s_b2 + 32 * CT2) + (size_t)wave * 2 * KS1 * 64 + lane;
   // Workgroup ids are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of
   // tiles, so that neighbouring tiles (which share input rows) meet in the same L2 close in time.
   const int per_xcd = (int)gridDim.x >> 3;  // the grid is a multiple of 8
@@ -689,10 +696,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < 3; k++) ro[k] = 4u * (lane_base + (uint32_t)(min(max(y1 - 1 + k, 0), H1 - 1) * W1));
   };
-  auto load_window = [&](const uint32_t (&ro)[3], int ks, float4 (&m)[3]) {
+  // RING: input row y of k-step ks sits in slot (y & 1) once it has been the bottom row of an X1 row
+  auto ring_at = [&](int y, int ks) -> float4& { return s_ring[(((y + 2) & 1) * KS1 + ks) * 64]; };
+  auto load_window = [&](const uint32_t (&ro)[3], int y1, int ks, float4 (&m)[3]) {
     const char* base = in + (size_t)ks * chan_step;
+    if (RING) {
+      m[0] = ring_at(y1 - 1, ks), m[1] = ring_at(y1, ks);
+      m[2] = *reinterpret_cast<const float4*>(base + ro[2]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(base + ro[k]);
+      for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(base + ro[k]);
+    }
   };
   // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
   // zero padding: `wl` points into the copy of the LDS table that has those taps zeroed.
@@ -815,8 +829,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     uint32_t ro[3];
     row_offsets(2 * oy0 - 1, ro);
-    load_window(ro, 0, win[0]);
-    load_window(ro, 1, win[1]);
+    if (RING) {  // the two upper input rows of the band's first X1 row, all channels
+#pragma unroll
+      for (int ks = 0; ks < KS1; ks++) {
+        const char* base = in + (size_t)ks * chan_step;
+        ring_at(2 * oy0 - 2, ks) = *reinterpret_cast<const float4*>(base + ro[0]);
+        ring_at(2 * oy0 - 1, ks) = *reinterpret_cast<const float4*>(base + ro[1]);
+      }
+    }
+    load_window(ro, 2 * oy0 - 1, 0, win[0]);
+    load_window(ro, 2 * oy0 - 1, 1, win[1]);
   }
 #pragma unroll 1
   for (int row = 0; row < nrows; row++) {
@@ -849,10 +871,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ks = ks0 + d;
         // slot d held step ks (already consumed into tcur): refill it with step ks + 2 -- of the
         // next X1 row once this one runs out (the last row re-reads its own last window)
+        if (RING) ring_at(y1 + 1, ks) = win[d][2];  // this step's bottom row: the middle / top row of the next two X1 rows
         if (ks + 2 < KS1)
-          load_window(ro, ks + 2, win[d]);
+          load_window(ro, y1, ks + 2, win[d]);
         else
-          load_window(ro_next, last ? KS1 - 1 : ks + 2 - KS1, win[d]);
+          load_window(ro_next, last ? y1 : y1 + 1, last ? KS1 - 1 : ks + 2 - KS1, win[d]);
         const float w = s_w1[ks * 64 + lane];
         float tnext[4];
         dw_compute(wl, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
@@ -1548,12 +1571,18 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   p.a[1].cts = 1;
   p.a[1].band = band;
   const int ct2 = (second.cout + 31) / 32;
-  const size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64 + 32 + 32 * ct2) * sizeof(float);
+  size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64 + 32 + 32 * ct2) * sizeof(float);
   const dim3 grid((unsigned)((p.a[1].tiles + 7) / 8 * 8));
-  if (first.cin == 16 && ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<16, 1>), grid, dim3(256), lds, s, p);
-  else if (first.cin == 16) hipLaunchKernelGGL((k_dwpw2_mfma<16, 2>), grid, dim3(256), lds, s, p);
-  else if (ct2 == 1) hipLaunchKernelGGL((k_dwpw2_mfma<32, 1>), grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((k_dwpw2_mfma<32, 2>), grid, dim3(256), lds, s, p);
+  // the 16-channel instances keep a two-row ring per wave in LDS: 64 KB per block, two blocks per CU
+  auto launch = [&](void (*kernel)(ConvArgs3), bool ring) {
+    if (ring) lds += (size_t)4 * 2 * (first.cin / 2) * 64 * sizeof(float4);
+    if (lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, p);
+  };
+  if (first.cin == 16 && ct2 == 1) launch(k_dwpw2_mfma<16, 1, true>, true);
+  else if (first.cin == 16) launch(k_dwpw2_mfma<16, 2, true>, true);
+  else if (ct2 == 1) launch(k_dwpw2_mfma<32, 1, false>, false);
+  else launch(k_dwpw2_mfma<32, 2, false>, false);
 }
 
 void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {
