@@ -230,8 +230,18 @@ struct ufd_model {
   size_t key_stride = 0;
 
   // device entropy decoding: table sets seen so far (append-only, shared by the contexts)
-  static constexpr int kMaxLutSets = 16;
+  // Huffman table sets seen so far (per-camera optimised tables make new ones).  A full cache evicts the set that has
+  // gone unused the longest, provided no batch that could still be in flight or staged refers to it.
+  static constexpr int kMaxLutSets = 64;
   std::vector<std::array<HuffLut, 4>> lut_sets;
+  struct LutMeta {
+    uint64_t hash = 0, last_use = 0;  // content hash; plan sequence number of the last batch that used the set
+    uint32_t pins = 0;                // staged batches holding the set
+  };
+  std::vector<LutMeta> lut_meta;
+  uint64_t plan_seq = 0;
+  static constexpr size_t kMaxTapSets = 32;  // resize-tap tables kept (one per distinct source size)
+  std::map<std::pair<int, int>, uint64_t> taps_used;
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   size_t scans_off = 0, ivs_off = 0, stage_cap = 0;  // layout of the staging block (descriptors at 0)
@@ -278,6 +288,7 @@ struct ufd_staged {
   uint32_t count = 0;
   DevicePlan plan;
   std::vector<JpegFrameDesc> h_descs;
+  std::vector<HuffScan> h_scans;  // (which Huffman table sets the batch keeps pinned)
   std::vector<int32_t> st;
   uint8_t* d_stage = nullptr;  // device image of the staging block
   uint8_t* d_blob = nullptr;
@@ -836,7 +847,22 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
   std::lock_guard<std::mutex> lk(m->shared_mu);
   auto key = std::make_pair(sw, sh);
   auto it = m->taps.find(key);
+  m->taps_used[key] = ++m->plan_seq;
   if (it == m->taps.end()) {
+    if (m->taps.size() >= ufd_model::kMaxTapSets) {
+      // a stream that sweeps frame sizes must not grow the cache without bound: drop the table set unused the longest.
+      // Kernels already enqueued may still read it, so every context drains first (rare: a new size beyond the cap).
+      for (int c = 0; c < m->num_ctx; c++)
+        if (m->ctx[c].stream) (void)hipStreamSynchronize(m->ctx[c].stream);
+      auto victim = m->taps.begin();
+      for (auto jt = m->taps.begin(); jt != m->taps.end(); ++jt)
+        if (m->taps_used[jt->first] < m->taps_used[victim->first]) victim = jt;
+      for (TapsDev* t : {&victim->second.first, &victim->second.second}) {
+        (void)hipFree(t->left), (void)hipFree(t->cnt), (void)hipFree(t->w);
+      }
+      m->taps_used.erase(victim->first);
+      m->taps.erase(victim);
+    }
     std::pair<TapsDev, TapsDev> e;
     int rc = build_axis_taps(m, sh, m->H, &e.first);
     if (rc) return rc;
@@ -1159,22 +1185,63 @@ int status_from_jpeg(int st) {
 }
 
 // Index of this frame's Huffman table set in d_sync_luts (uploading it first if it is new), or -1.
-int lut_set_for(ufd_model* m, const HuffLut (&luts)[4]) {
+int lut_set_for(ufd_model* m, const HuffLut (&luts)[4], uint64_t seq) {
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over the four tables: one compare per cached set instead of a 40 KB memcmp
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(luts);
+  for (size_t i = 0; i < sizeof(HuffLut) * 4; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, bytes + i, 8);
+    h = (h ^ w) * 1099511628211ull;
+  }
   std::lock_guard<std::mutex> lk(m->shared_mu);
   for (size_t i = 0; i < m->lut_sets.size(); i++)
-    if (!std::memcmp(m->lut_sets[i].data(), luts, sizeof(HuffLut) * 4)) return (int)i;
-  if ((int)m->lut_sets.size() >= ufd_model::kMaxLutSets) return -1;
+    if (m->lut_meta[i].hash == h && !std::memcmp(m->lut_sets[i].data(), luts, sizeof(HuffLut) * 4)) {
+      m->lut_meta[i].last_use = seq;
+      return (int)i;
+    }
+  size_t idx = m->lut_sets.size();
+  if ((int)idx >= ufd_model::kMaxLutSets) {
+    // evict the least recently used set no in-flight batch can refer to: at most UFD_MAX_SLOTS batches are in flight, each
+    // planned after the one before, so a set last used more than 2 * UFD_MAX_SLOTS plans ago is idle; staged batches pin theirs
+    idx = SIZE_MAX;
+    for (size_t i = 0; i < m->lut_sets.size(); i++) {
+      const auto& q = m->lut_meta[i];
+      if (q.pins || seq < q.last_use + 2 * UFD_MAX_SLOTS + 1) continue;
+      if (idx == SIZE_MAX || q.last_use < m->lut_meta[idx].last_use) idx = i;
+    }
+    if (idx == SIZE_MAX) return -1;  // every set is busy: this batch decodes on the host workers
+    // (batches enqueued long ago may still be running on the GPU: drain the contexts before their table goes away)
+    for (int c = 0; c < m->num_ctx; c++)
+      if (m->ctx[c].stream) (void)hipStreamSynchronize(m->ctx[c].stream);
+  }
   std::array<HuffLut, 4> set;
   std::memcpy(set.data(), luts, sizeof(HuffLut) * 4);
-  const size_t idx = m->lut_sets.size();
-  // rare (once per camera stream): blocking copy into an unused slot of the shared table array
+  // rare (once per camera stream): blocking copy into the slot of the shared table array
   {
     std::unique_ptr<SyncLutImage> img(new SyncLutImage);
     build_sync_lut_image(set.data(), img.get());
     if (hipMemcpy(m->d_sync_luts + idx, img.get(), sizeof(SyncLutImage), hipMemcpyHostToDevice) != hipSuccess) return -1;
   }
-  m->lut_sets.push_back(set);
+  ufd_model::LutMeta meta;
+  meta.hash = h, meta.last_use = seq;
+  if (idx == m->lut_sets.size()) {
+    m->lut_sets.push_back(set);
+    m->lut_meta.push_back(meta);
+  } else {
+    m->lut_sets[idx] = set;
+    m->lut_meta[idx] = meta;
+  }
   return (int)idx;
+}
+
+// staged batches keep their table sets resident (ufd_stage_jpeg_batch / ufd_staged_free)
+void pin_lut_sets(ufd_model* m, const HuffScan* scans, uint32_t count, int delta) {
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  for (uint32_t i = 0; i < count; i++) {
+    if (!scans[i].nseg) continue;
+    const size_t set = scans[i].lut_base / 4;
+    if (set < m->lut_meta.size()) m->lut_meta[set].pins += delta;
+  }
 }
 
 // Host half of the device entropy path: header / marker scan of every frame (no bit is decoded),
@@ -1189,6 +1256,11 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
     s.st[i] = st;
   });
+  uint64_t seq;
+  {
+    std::lock_guard<std::mutex> lk(m->shared_mu);
+    seq = ++m->plan_seq;
+  }
   uint32_t n_iv = 0;
   for (uint32_t i = 0; i < count; i++) {
     if (s.st[i] == kJpegNotEligible) return p;
@@ -1204,7 +1276,7 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   for (uint32_t i = 0; i < count; i++) {
     std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
     if (s.st[i] != kJpegOk) continue;
-    const int set = lut_set_for(m, s.plans[i].luts);
+    const int set = lut_set_for(m, s.plans[i].luts, seq);
     if (set < 0) return p;
     HuffScan sc = s.plans[i].scan;
     sc.lut_base = (uint32_t)set * 4;
@@ -2154,6 +2226,8 @@ int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t
       (void)hipFree(g->d_stage);
       return m->fail(UFD_E_DEVICE, "staging a batch in device memory failed");
     }
+    g->h_scans.assign(tmp.h_scans, tmp.h_scans + count);
+    pin_lut_sets(m, g->h_scans.data(), count, +1);
     g->d_descs = reinterpret_cast<JpegFrameDesc*>(g->d_stage);
     g->d_scans = reinterpret_cast<HuffScan*>(g->d_stage + m->scans_off);
     g->d_ivs = reinterpret_cast<HuffInterval*>(g->d_stage + m->ivs_off);
@@ -2172,6 +2246,7 @@ int ufd_submit_staged(ufd_model* m, const ufd_staged* staged, ufd_det* out, uint
 void ufd_staged_free(ufd_model* m, ufd_staged* staged) {
   if (!staged) return;
   if (m) (void)hipSetDevice(m->cfg.device_id);
+  if (m) pin_lut_sets(m, staged->h_scans.data(), (uint32_t)staged->h_scans.size(), -1);
   (void)hipFree(staged->d_stage);
   delete staged;
 }

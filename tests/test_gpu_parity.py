@@ -647,3 +647,27 @@ def test_unusual_restart_layouts(model320_auto, oracle_lib):
         assert b"\xff\xdd" in jpeg
         got = model320_auto.debug_decode_jpeg(jpeg)
         assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (mode, kw)
+
+
+def test_table_set_and_tap_caches_evict(weights, oracle_lib):
+    """More distinct Huffman table sets (per-frame optimised tables) than the handle caches (64), and more distinct
+    frame sizes than it keeps resize taps for (32): old entries are evicted, every frame still decodes bit-exactly on
+    the device path and detections still match the oracle."""
+    from infercam_onnx_amd import synth
+
+    model = make_model(320, weights, max_batch=4, profile=True)
+    try:
+        rng = np.random.default_rng(8)
+        for k in range(80):  # optimize=True: Huffman tables fitted to each frame
+            w, h = 64 + 8 * (k % 40), 48 + 8 * ((k * 7) % 23)
+            rgb = synth.synth_frame(500 + k, k, w, h)
+            rgb = np.clip(rgb.astype(np.int16) + rng.integers(-40, 40, rgb.shape), 0, 255).astype(np.uint8)
+            j = synth.encode_jpeg(rgb, quality=60 + k % 35, optimize=True)
+            assert np.array_equal(model.debug_decode_jpeg(j), oracle_lib.jpeg_decode_rgb(j)), k
+            if k % 8 == 0:
+                got = dets_array(model.infer_jpeg(j))
+                assert_dets_match(got, oracle_lib.infer_jpeg(j, 320, 240, weights, synth.gen_priors(320, 240)), what="evict %d" % k)
+        names = {p["name"] for p in model.profile_read() if p["launches"]}
+        assert any(n.startswith("huff_write") for n in names), names  # the device entropy path stayed in use
+    finally:
+        model.close()
