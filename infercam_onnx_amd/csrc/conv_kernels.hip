@@ -1235,14 +1235,19 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
   for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = sa.lut[i];
   __syncthreads();
-  const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long total = (long)a.B * gpf;
+  // Row rolling: a wave owns a band of a.band output rows of its 14 column groups.  Output row oy reads input rows
+  // 2oy-1 .. 2oy+1, so consecutive output rows share one input row: its 8 upsampled, colour-converted, normalised
+  // pixels stay in registers (2 * band + 1 input rows converted per band instead of 3 * band), and the tables above
+  // are loaded once per band.  Groups are numbered over (frame, band, column group).
+  const int R = a.band, bands = a.oh / R;
+  const int ohw = a.oh * a.ow, gpr = a.ow >> 2, gpb = bands * gpr;
+  const long total = (long)a.B * gpb;
   const long g = ((long)blockIdx.x * 4 + wave) * NG + j16 - HL;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j16 >= HL && j16 < 16 - HL;
-  const size_t frame = inrange ? g / gpf : 0;
-  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
-  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+  const size_t frame = inrange ? g / gpb : 0;
+  const int rem = inrange ? (int)(g - (long)frame * gpb) : 0;
+  const int band = rem / gpr, ox = (rem - band * gpr) * 4, oy0 = band * R;
   const JpegFrameDesc& d = sa.descs[frame];
   const bool frame_ok = d.width == a.iw && d.height == a.ih;  // failed frames: zero input
   const uint8_t* fp = sa.planes + frame * sa.plane_stride;
@@ -1254,46 +1259,39 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const int ku = q == 1 ? -22554 : (q == 2 ? 116130 : 0);
   const int kv = q == 0 ? 91881 : (q == 1 ? -46802 : 0);
   const float* lutq = s_lut + min(q, 2) * 256;
+  // every lane upsamples ONE chroma plane for its 8 pixels (R: Cr, G and B: Cb); the G lanes
+  // fetch Cr from the R lane of the same pixels (16 lanes down)
+  const int plane = q == 0 || q == 3 ? 2 : 1;
+  const uint8_t* yplane = fp + d.plane_off[0] + ix0;
+  const uint8_t* cplane = fp + d.plane_off[plane] + c0;
 
-  floatx4 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int co = 4 * q + r;
-      acc[j][r] = co < a.cout ? a.bias[co] : 0.0f;
-    }
-
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    const int iy = oy * 2 + r - 1;
+  // input row iy of the lane's channel: v[0..7] = columns ix0 .. ix0+7, v[8] = column ix0 - 1 (0 at the row start);
+  // a row outside the image is zero padding
+  auto convert_row = [&](int iy, float (&v)[9]) {
     const bool ok = frame_ok && iy >= 0 && iy < a.ih && q < 3;
     const int yc = min(max(iy, 0), a.ih - 1);
-    // luma: 8 bytes; chroma: the row pair of h2v2 fancy upsampling, 4 columns of each plane
-    const uint2 yy = frame_ok ? *reinterpret_cast<const uint2*>(fp + d.plane_off[0] + (size_t)yc * ypitch + ix0) : make_uint2(0, 0);
+    // luma: 8 bytes; chroma: the row pair of h2v2 fancy upsampling, 4 columns of the lane's plane
     const int cy = yc >> 1, ny = max(0, min(dh - 1, (yc & 1) ? cy + 1 : cy - 1));
-    // every lane upsamples ONE chroma plane for its 8 pixels (R: Cr, G and B: Cb); the G lanes
-    // fetch Cr from the R lane of the same pixels (16 lanes down)
-    const int plane = q == 0 || q == 3 ? 2 : 1;
+    uint2 yy = make_uint2(0, 0);
     uint32_t wa = 0, wb = 0;
     if (frame_ok) {
-      wa = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[plane] + (size_t)cy * cpitch + c0);
-      wb = *reinterpret_cast<const uint32_t*>(fp + d.plane_off[plane] + (size_t)ny * cpitch + c0);
+      yy = *reinterpret_cast<const uint2*>(yplane + (size_t)yc * ypitch);
+      wa = *reinterpret_cast<const uint32_t*>(cplane + (size_t)cy * cpitch);
+      wb = *reinterpret_cast<const uint32_t*>(cplane + (size_t)ny * cpitch);
     }
-    int s[6];
+    int sc[6];
 #pragma unroll
-    for (int i = 0; i < 4; i++) s[1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
+    for (int i = 0; i < 4; i++) sc[1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
     {
       // neighbour columns c0-1 / c0+4 from the adjacent lanes (same input row when they exist)
-      const int from_prev = __shfl(s[4], lane - 1), from_next = __shfl(s[1], lane + 1);
-      s[0] = c0 > 0 ? from_prev : s[1];
-      s[5] = c0 + 4 <= dw - 1 ? from_next : s[4];
+      const int from_prev = __shfl(sc[4], lane - 1), from_next = __shfl(sc[1], lane + 1);
+      sc[0] = c0 > 0 ? from_prev : sc[1];
+      sc[5] = c0 + 4 <= dw - 1 ? from_next : sc[4];
     }
-    float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int i = 1 + (j >> 1);
-      const int mine = (j & 1) ? (s[i] * 3 + s[i + 1] + 7) >> 4 : (s[i] * 3 + s[i - 1] + 8) >> 4;
+      const int mine = (j & 1) ? (sc[i] * 3 + sc[i + 1] + 7) >> 4 : (sc[i] * 3 + sc[i - 1] + 8) >> 4;
       const int peer = __shfl(mine, lane - 16);  // the R lane's Cr for the G lane
       const int cbv = mine, crv = q == 1 ? peer : mine;
       const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
@@ -1301,28 +1299,51 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
       v[j] = ok ? lutq[px] : 0.0f;
     }
     const float left_raw = __shfl(v[7], lane - 1);
-    const float left = (j16 > 0 && ix0 > 0) ? left_raw : 0.0f;  // column ix0 - 1 (zero padding at the row start)
-    float x[3][4];  // [kx][pixel]: output pixel j reads columns 2j-1, 2j, 2j+1
-    x[0][0] = left, x[0][1] = v[1], x[0][2] = v[3], x[0][3] = v[5];
-    x[1][0] = v[0], x[1][1] = v[2], x[1][2] = v[4], x[1][3] = v[6];
-    x[2][0] = v[1], x[2][1] = v[3], x[2][2] = v[5], x[2][3] = v[7];
+    v[8] = (j16 > 0 && ix0 > 0) ? left_raw : 0.0f;  // column ix0 - 1 (zero padding at the row start)
+  };
+  floatx4 acc[4];
+  // tap row r of the 3x3 kernel applied to a converted input row: output pixel j reads columns 2j-1, 2j, 2j+1
+  auto mac_row = [&](int r, const float (&v)[9]) {
+    const float x[3][4] = {{v[8], v[1], v[3], v[5]}, {v[0], v[2], v[4], v[6]}, {v[1], v[3], v[5], v[7]}};
 #pragma unroll
     for (int kx = 0; kx < 3; kx++) {
       const float w = s_w[(r * 3 + kx) * 64 + lane];
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
     }
-  }
-  if (!live) return;
-  const int pix = oy * a.ow + ox;
+  };
+  float bias[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int co = 4 * q + r;
-    if (co < a.cout) {
-      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-      if (a.relu) o = relu4(o);
-      *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = o;
+  for (int r = 0; r < 4; r++) bias[r] = 4 * q + r < a.cout ? a.bias[4 * q + r] : 0.0f;
+
+  float top[9], mid[9], bot[9];
+  convert_row(2 * oy0 - 1, top);
+#pragma unroll 1
+  for (int i = 0; i < R; i++) {
+    const int oy = oy0 + i;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[j][r] = bias[r];
+    mac_row(0, top);
+    convert_row(2 * oy, mid);
+    mac_row(1, mid);
+    convert_row(2 * oy + 1, bot);
+    mac_row(2, bot);
+    if (live) {
+      const int pix = oy * a.ow + ox;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int co = 4 * q + r;
+        if (co < a.cout) {
+          float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+          if (a.relu) o = relu4(o);
+          *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = o;
+        }
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 9; k++) top[k] = bot[k];  // input row 2oy + 1 = 2(oy + 1) - 1
   }
 }
 
@@ -1386,9 +1407,16 @@ bool stem_planes_supported(const ConvArgs& a) {
          a.iw == 2 * a.ow && a.ih == 2 * a.oh && (a.ow & 3) == 0 && (a.iw & 7) == 0;
 }
 
-void launch_stem_planes_mfma(const StemArgs& sa, hipStream_t s) {
-  const ConvArgs& a = sa.a;
-  const long groups = (long)a.B * (a.oh * a.ow / 4);
+void launch_stem_planes_mfma(const StemArgs& sa0, hipStream_t s) {
+  StemArgs sa = sa0;
+  ConvArgs& a = sa.a;
+  // rows per band: the largest divisor of the output height <= 8 that still gives the GPU a full round of waves (8 per
+  // SIMD).  Measured at batch 32 of the 640 model (rocprofv3, alone): band 1 85 us, 2 72, 3 69, 4 67, 6 68, 8 73, 12 68.
+  int band = 1;
+  for (int r = 2; r <= 8; r++)
+    if (a.oh % r == 0 && (long)a.B * (a.oh / r) * (a.ow / 4) / 14 >= 8192) band = r;
+  a.band = band;
+  const long groups = (long)a.B * ((a.oh / band) * a.ow / 4);
   const size_t shmem = (9 * 64 + 768) * sizeof(float);
   hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
