@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float* wd2 = wl2 + ((r & 3) + 8 * (r >> 2)) * 12;
       float x[4];
 #pragma unroll
-      for (int p = 0; p < 4; p++) x[p] = a1.relu ? relu_acc(acc[p][r]) : acc[p][r];
+      for (int p = 0; p < 4; p++) x[p] = relu_acc(acc[p][r]);  // (the first block always ends in a ReLU: dwpw2_supported)
       const float from_prev = lane_prev(x[3]);
       const float l = leftok ? from_prev : 0.f;
       if (mode == 0) {
@@ -1563,7 +1563,7 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
 }
 
 bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
-  return (first.cin == 16 || first.cin == 32) && first.cout == 32 && second.cin == 32 && second.cout <= 64 &&
+  return (first.cin == 16 || first.cin == 32) && first.cout == 32 && second.cin == 32 && second.cout <= 64 && first.relu &&
          first.iw % 8 == 0 && first.iw == first.ow && first.ih == first.oh && second.ow % 4 == 0 && first.ow == 2 * second.ow &&
          first.oh == 2 * second.oh && first.res == nullptr && second.res == nullptr;
 }

@@ -505,7 +505,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         if (kHeadCls[h] == p1 || kHeadReg[h] == p1) only_reader = false;
       if (!only_reader || D1.spec.stride != 1 || D2.spec.stride != 2) continue;
       ConvArgs f{}, g{};
-      f.cin = P1.spec.cin, f.cout = P1.spec.cout, f.ih = D1.ih, f.iw = D1.iw, f.oh = P1.oh, f.ow = P1.ow;
+      f.cin = P1.spec.cin, f.cout = P1.spec.cout, f.ih = D1.ih, f.iw = D1.iw, f.oh = P1.oh, f.ow = P1.ow, f.relu = P1.spec.relu;
       g.cin = P2.spec.cin, g.cout = P2.spec.cout, g.ih = D2.ih, g.iw = D2.iw, g.oh = P2.oh, g.ow = P2.ow;
       if (!dwpw2_supported(f, g)) continue;
       P2.kind = kKindDwPw2;
