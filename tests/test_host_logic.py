@@ -186,3 +186,16 @@ def test_inferer_loop_pipelining_and_ordering():
     rx.put(None)
     t.join(5.0)
     assert not t.is_alive()
+
+
+def test_host_parsers_clean_under_asan_ubsan():
+    """tools/fuzz/run_host_fuzz.sh: the JPEG header/marker scanner + entropy decoder and the ONNX reader, built with
+    -fsanitize=address,undefined, on mutated seeds of every stream flavour (a short campaign here; run the script with
+    more rounds for a long one).  Any memory error or undefined behaviour aborts it."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    r = subprocess.run([os.path.join(ROOT, "tools", "fuzz", "run_host_fuzz.sh"), "30", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
