@@ -147,8 +147,11 @@ void ufd_staged_free(ufd_model* m, ufd_staged* staged);
  * bbox * (label_width, label_height) with the reference's `as i32` / `as u32` casts, colour (0, 255, 0), clipped
  * to the decoded frame.  NOTE: label_width / label_height are the slot's StaticImage.0 / .1, which the router stamps
  * with 1280 x 720 whatever the JPEG's own size is (router.rs:66-67).  A rectangle narrower or lower than one pixel
- * (imageproc's Rect::of_size would assert and the reference task panic) is skipped.  The confidence text
- * (draw_text, inferer.rs:80-88) is NOT drawn: rusttype glyph rasterisation is deferred.
+ * (imageproc's Rect::of_size would assert and the reference task panic) is skipped, label included.  Then the
+ * confidence label of that detection, draw_text(.., x as i32, y as i32, Scale 16, DejaVuSansMono, "{:.2}%")
+ * (inferer.rs:80-88): glyph coverage from a table restated from rusttype 0.9.3 / ab_glyph_rasterizer (parity with the
+ * crates unpinned: DESIGN.md section 2), blended with imageproc's f32 weighted_sum; detections are drawn in order, so
+ * later rectangles and labels go over earlier ones exactly as in the reference.  UFD_ANNOT_NO_TEXT: rectangles only.
  * turbojpeg::compress_image(&frame, quality, Subsamp::Sub2x2) (inferer.rs:39, quality 95): baseline 4:2:0 stream
  * byte-identical to libjpeg-turbo's (fast integer DCT below quality 96 as tjCompress2 selects, accurate from 96).
  * UFD_ANNOT_MULTIPART wraps every stream as as_jpeg_stream_item does (lib.rs:48-57).
@@ -158,6 +161,7 @@ void ufd_staged_free(ufd_model* m, ufd_staged* staged);
  * whose stream does not fit in jpeg_cap gets status UFD_E_TRUNCATED (its detections are still valid) and length 0.
  * ufd_encode_bound(w, h) bytes per frame always suffice.  Detections, n[] and status[] as ufd_submit_jpeg_batch. */
 #define UFD_ANNOT_MULTIPART 1u
+#define UFD_ANNOT_NO_TEXT 2u
 typedef struct ufd_annotate {
   uint32_t struct_size;   /* = sizeof(ufd_annotate) */
   float label_width;      /* inferer.rs:32-33: recv_ref.0 / .1 (1280 / 720 in the reference's router) */
@@ -253,9 +257,10 @@ int ufd_sched_get_stats(ufd_sched* s, ufd_sched_stats* out);
 uint32_t ufd_sched_debug_plan(const uint32_t* queued, uint32_t n_streams, uint32_t last, uint32_t max_batch, uint32_t* take);
 
 /* ---- stage taps (parity tests call the path stage by stage through these) ---- */
-/* N1 stages alone: the rectangles of `n` detections on an RGB8 frame (in place), and the encoder on an RGB8 frame. */
-int ufd_debug_draw_rects(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
-                         float label_width, float label_height);
+/* N1 stages alone: the rectangles (and, text != 0, labels) of `n` detections on an RGB8 frame (in place), and the encoder
+ * on an RGB8 frame. */
+int ufd_debug_draw_labels(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
+                          float label_width, float label_height, uint32_t text);
 int ufd_debug_encode_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, uint32_t quality,
                          uint32_t flags, uint8_t* out, size_t cap, size_t* len);
 /* A1 only: decode on the GPU and copy the interleaved RGB8 frame back (cap_bytes >= h*w*3). */

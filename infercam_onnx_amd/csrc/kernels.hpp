@@ -249,8 +249,15 @@ struct EncBuffers {
   uint8_t* out = nullptr;        // finished streams, packed
 };
 using EncStageHook = std::function<void(const char* stage, bool begin)>;
-void launch_draw_rects(const JpegFrameDesc* d_descs, const Det* d_dets, uint32_t det_stride, const uint32_t* d_ndet, uint8_t* d_rgb,
-                       size_t rgb_stride, float label_w, float label_h, uint32_t count, hipStream_t s);
+// Rectangles and (text) confidence labels of the detections, in detection order, into the RGB frames.  d_ops: scratch of
+// label_ops_bytes(frames, det_stride); d_glyphs / d_coverage: the atlas of glyph_atlas.inc (label_atlas) on the device.
+size_t label_ops_bytes(uint32_t frames, uint32_t det_stride);
+void launch_draw_labels(const JpegFrameDesc* d_descs, const Det* d_dets, uint32_t det_stride, const uint32_t* d_ndet,
+                        uint32_t max_dets, void* d_ops, const int* d_glyphs, const float* d_coverage, bool text, uint8_t* d_rgb,
+                        size_t rgb_stride, uint32_t max_w, uint32_t max_h, float label_w, float label_h, uint32_t count,
+                        hipStream_t s);
+// the atlas as host arrays: glyph records {x, y, w, h, offset} for [position][character], coverage floats
+void label_atlas(const int** glyphs, size_t* glyph_ints, const float** coverage, size_t* coverage_floats);
 void launch_jpeg_encode(const JpegFrameDesc* d_descs, const uint8_t* d_rgb, size_t rgb_stride, uint32_t max_w, uint32_t max_h,
                         uint32_t count, const EncQuant& q, bool ifast, const EncBuffers& e, hipStream_t s,
                         const EncStageHook* hook = nullptr);

@@ -181,6 +181,9 @@ struct Ctx {
   uint32_t* d_enc_tables = nullptr;
   uint8_t* d_enc_header = nullptr;
   JpegFrameDesc* d_enc_descs = nullptr;  // descriptors of frames that did not come out of the decoder (debug taps)
+  void* d_label_ops = nullptr;           // one drawing operation per detection of the batch
+  int* d_glyphs = nullptr;               // label glyph atlas (glyph_atlas.inc)
+  float* d_coverage = nullptr;
 };
 constexpr int kMaxCtx = 8;
 
@@ -1449,6 +1452,17 @@ int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart) {
     HIPC(m, hipMalloc(&c.d_enc_tables, sizeof(uint32_t) * 2 * 272));
     HIPC(m, hipMalloc(&c.d_enc_header, 1024));
     HIPC(m, hipMalloc(&c.d_enc_descs, sizeof(JpegFrameDesc) * m->B));
+    HIPC(m, hipMalloc(&c.d_label_ops, label_ops_bytes(m->B, (uint32_t)m->K)));
+    {
+      const int* g;
+      const float* cov;
+      size_t ng, nc;
+      label_atlas(&g, &ng, &cov, &nc);
+      HIPC(m, hipMalloc(&c.d_glyphs, ng * sizeof(int)));
+      HIPC(m, hipMalloc(&c.d_coverage, nc * sizeof(float)));
+      HIPC(m, hipMemcpy(c.d_glyphs, g, ng * sizeof(int), hipMemcpyHostToDevice));
+      HIPC(m, hipMemcpy(c.d_coverage, cov, nc * sizeof(float), hipMemcpyHostToDevice));
+    }
     uint32_t tabs[2 * 272];
     enc_make_code_tables(tabs);
     HIPC(m, hipMemcpy(c.d_enc_tables, tabs, sizeof(tabs), hipMemcpyHostToDevice));
@@ -1489,9 +1503,10 @@ int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32
   rc = ensure_slot_encoder(m, s);
   if (rc) return rc;
   {
-    ProfScope ps(m, "draw_rects", 0, 0);
-    launch_draw_rects(d_descs, s.d_dets, (uint32_t)m->K, c.d_ndet, c.d_rgb, m->rgb_stride, s.annot_args.label_width,
-                      s.annot_args.label_height, count, c.stream);
+    ProfScope ps(m, "draw_labels", 0, 0);
+    launch_draw_labels(d_descs, s.d_dets, (uint32_t)m->K, c.d_ndet, (uint32_t)m->K, c.d_label_ops, c.d_glyphs, c.d_coverage,
+                       !(s.annot_args.flags & UFD_ANNOT_NO_TEXT), c.d_rgb, m->rgb_stride, mw, mh, s.annot_args.label_width,
+                       s.annot_args.label_height, count, c.stream);
   }
   EncBuffers e = c.enc;
   e.out = s.d_enc_out;
@@ -1797,6 +1812,7 @@ void destroy(ufd_model* m) {
     dfree(c.d_nms_mat);
     dfree(c.enc.planes), dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
     dfree(c.d_enc_tables), dfree(c.d_enc_header), dfree(c.d_enc_descs);
+    dfree(c.d_label_ops), dfree(c.d_glyphs), dfree(c.d_coverage);
   }
   for (float* t : m->tap_buf) dfree(t);
   for (auto& kv : m->taps)
@@ -2326,8 +2342,8 @@ static int upload_plain_frame(ufd_model* m, const uint8_t* rgb, uint32_t w, uint
   return UFD_OK;
 }
 
-int ufd_debug_draw_rects(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
-                         float label_width, float label_height) {
+int ufd_debug_draw_labels(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uint32_t pitch, const ufd_det* dets, uint32_t n,
+                          float label_width, float label_height, uint32_t text) {
   return guarded(m, [&]() -> int {
     drain_worker0(m);
     if (!rgb || (!dets && n)) return m->fail(UFD_E_ARG, "null argument");
@@ -2342,8 +2358,9 @@ int ufd_debug_draw_rects(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, uin
     if (rc) return rc;
     if (n) HIPC(m, hipMemcpyAsync(s->d_dets, dets, sizeof(Det) * n, hipMemcpyHostToDevice, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(tl_cur->d_ndet, &n, sizeof(uint32_t), hipMemcpyHostToDevice, tl_cur->stream));
-    launch_draw_rects(tl_cur->d_enc_descs, s->d_dets, (uint32_t)m->K, tl_cur->d_ndet, tl_cur->d_rgb, m->rgb_stride, label_width,
-                      label_height, 1, tl_cur->stream);
+    launch_draw_labels(tl_cur->d_enc_descs, s->d_dets, (uint32_t)m->K, tl_cur->d_ndet, std::max(n, 1u), tl_cur->d_label_ops,
+                       tl_cur->d_glyphs, tl_cur->d_coverage, text != 0, tl_cur->d_rgb, m->rgb_stride, w, h, label_width, label_height,
+                       1, tl_cur->stream);
     HIPC(m, hipMemcpy2DAsync(rgb, pitch, tl_cur->d_rgb, (size_t)w * 3, (size_t)w * 3, h, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipStreamSynchronize(tl_cur->stream));
     return UFD_OK;

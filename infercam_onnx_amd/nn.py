@@ -22,6 +22,7 @@ UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_E
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_MAX_SLOTS = 8
 UFD_ANNOT_MULTIPART = 1
+UFD_ANNOT_NO_TEXT = 2
 UFD_E_FULL = -9
 
 _STATUS_NAMES = {0: "UFD_OK", -1: "UFD_E_ARG", -2: "UFD_E_DECODE", -3: "UFD_E_UNSUPPORTED", -4: "UFD_E_TRUNCATED",
@@ -89,7 +90,7 @@ ABI_SYMBOLS = (
     "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
     "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
     "ufd_submit_annotate_batch", "ufd_annotate_jpeg_batch", "ufd_encode_bound", "ufd_host_alloc", "ufd_host_free",
-    "ufd_debug_draw_rects", "ufd_debug_encode_rgb", "ufd_model_limits",
+    "ufd_debug_draw_labels", "ufd_debug_encode_rgb", "ufd_model_limits",
     "ufd_sched_create", "ufd_sched_destroy", "ufd_sched_add_stream", "ufd_sched_remove_stream", "ufd_sched_push",
     "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
 )
@@ -145,7 +146,7 @@ def load_library():
     L.ufd_host_alloc.restype = vp
     L.ufd_host_free.argtypes = [vp]
     L.ufd_host_free.restype = None
-    L.ufd_debug_draw_rects.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_float, ctypes.c_float]
+    L.ufd_debug_draw_labels.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_float, ctypes.c_float, u32]
     L.ufd_debug_encode_rgb.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, sz, ctypes.POINTER(sz)]
     L.ufd_model_limits.argtypes = [vp, pu32, pu32, pu32]
     L.ufd_sched_create.argtypes = [ctypes.POINTER(UfdSchedConfig), ctypes.POINTER(vp)]
@@ -404,7 +405,7 @@ class UltrafaceModel(InferModel):
                 owner.ufd_host_free(mem)
                 self.jpeg_mem = None
 
-    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None):
+    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True):
         """Buffers of one annotate batch (reusable): pinned output memory from ufd_host_alloc.  label_size = the
         slot's (width, height) -- 1280 x 720 in the reference's router, whatever the JPEG's size (router.rs:66-67)."""
         base = self._prep_batch(jpegs)
@@ -431,7 +432,7 @@ class UltrafaceModel(InferModel):
         a = UfdAnnotate()
         a.struct_size = ctypes.sizeof(UfdAnnotate)
         a.label_width, a.label_height = float(label_size[0]), float(label_size[1])
-        a.quality, a.flags = int(quality), (UFD_ANNOT_MULTIPART if multipart else 0)
+        a.quality, a.flags = int(quality), (UFD_ANNOT_MULTIPART if multipart else 0) | (0 if text else UFD_ANNOT_NO_TEXT)
         a.jpeg_out, a.jpeg_cap = b.jpeg_mem, cap
         a.jpeg_off, a.jpeg_len = ctypes.addressof(b.jpeg_off), ctypes.addressof(b.jpeg_len)
         b.annot = a
@@ -451,26 +452,26 @@ class UltrafaceModel(InferModel):
         streams = [bytes(view[b.jpeg_off[i]:b.jpeg_off[i] + b.jpeg_len[i]]) if b.jpeg_len[i] else None for i in range(b.count)]
         return dets, status, streams
 
-    def annotate_jpeg_batch(self, jpegs, label_size, quality=95, multipart=False):
-        """decode -> infer -> rectangles -> re-encode for a batch: ([detections], [status], [annotated JPEG bytes or None])."""
-        b = self.prep_annotate_batch(jpegs, label_size, quality, multipart)
+    def annotate_jpeg_batch(self, jpegs, label_size, quality=95, multipart=False, text=True):
+        """decode -> infer -> rectangles + labels -> re-encode for a batch: ([detections], [status], [annotated JPEG bytes or None])."""
+        b = self.prep_annotate_batch(jpegs, label_size, quality, multipart, text=text)
         return self.wait(self.submit_annotate_batch(b))
 
-    def annotate_jpeg(self, jpeg, label_size, quality=95, multipart=False):
-        dets, status, streams = self.annotate_jpeg_batch([jpeg], label_size, quality, multipart)
+    def annotate_jpeg(self, jpeg, label_size, quality=95, multipart=False, text=True):
+        dets, status, streams = self.annotate_jpeg_batch([jpeg], label_size, quality, multipart, text=text)
         if status[0] not in (UFD_OK, UFD_E_TRUNCATED):
             raise UfdError(status[0], "frame skipped")
         return dets[0], streams[0]
 
-    def debug_draw_rects(self, rgb, dets, label_size):
-        """N1 drawing stage alone on the GPU: HxWx3 uint8 + [(bbox, conf)] or [n,5] -> annotated copy."""
+    def debug_draw_labels(self, rgb, dets, label_size, text=True):
+        """N1 drawing stage alone on the GPU: HxWx3 uint8 + [(bbox, conf)] or [n,5] -> copy with rectangles (+ labels)."""
         out = np.ascontiguousarray(rgb, np.uint8).copy()
         h, w, _ = out.shape
         if not isinstance(dets, np.ndarray):
             dets = [list(b) + [c] for b, c in dets]
         d = np.ascontiguousarray(np.asarray(dets, np.float32).reshape(-1, 5))
-        self._check(self._lib.ufd_debug_draw_rects(self._h, out.ctypes.data, w, h, w * 3, d.ctypes.data, len(d),
-                                                   float(label_size[0]), float(label_size[1])))
+        self._check(self._lib.ufd_debug_draw_labels(self._h, out.ctypes.data, w, h, w * 3, d.ctypes.data, len(d),
+                                                    float(label_size[0]), float(label_size[1]), int(bool(text))))
         return out
 
     def debug_encode_rgb(self, rgb, quality=95, multipart=False):

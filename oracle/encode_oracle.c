@@ -10,8 +10,12 @@
  * `as u32` casts) is restated line by line; draw_hollow_rect is imageproc 0.23 (Cargo.lock, not under
  * /root/reference): four Bresenham segments (left,top)-(right,top), (left,bottom)-(right,bottom),
  * (left,top)-(left,bottom), (right,top)-(right,bottom) with right = left + w - 1, bottom = top + h - 1,
- * every point clipped against the image.  The confidence text (draw_text, rusttype 0.9.3 glyph
- * rasterisation of DejaVuSansMono at 16 px) is NOT restated: deferred, see DESIGN.md.
+ * every point clipped against the image.  The confidence text (draw_text, inferer.rs:80-88): imageproc 0.23
+ * draw_text_mut blends, per glyph pixel, pixel * (1 - v) + colour * v in f32 and casts back with its Clamp (truncation);
+ * the coverage v comes from glyph_atlas.inc, a DATA table made by tools/make_glyph_atlas.py, which restates rusttype
+ * 0.9.3's layout (caret advance, pixel bounding boxes) and ab_glyph_rasterizer's accumulation for DejaVuSansMono at
+ * Scale 16 -- "parity unpinned": none of those crates can be run here (FreeType agrees on the shapes, not bit for bit).
+ * The label is format!("{:.2}%", confidence * 100.0): the f32 product, correctly rounded to two decimals.
  *
  * Encoding: turbojpeg 0.5.2 / turbojpeg-sys 0.2.2 (Cargo.lock:2617-2640) = libjpeg-turbo 2.1.x through
  * tjCompress2(flags = 0): jpeg_set_defaults, jpeg_set_quality(q, TRUE), YCbCr 4:2:0, Annex-K Huffman
@@ -68,6 +72,61 @@ void ufo_draw_hollow_rects(uint8_t* rgb, int w, int h, const ufo_det* dets, int 
       if (l >= 0 && l < w) rgb[((size_t)y * w + l) * 3] = 0, rgb[((size_t)y * w + l) * 3 + 1] = 255, rgb[((size_t)y * w + l) * 3 + 2] = 0;
       if (r >= 0 && r < w) rgb[((size_t)y * w + r) * 3] = 0, rgb[((size_t)y * w + r) * 3 + 1] = 255, rgb[((size_t)y * w + r) * 3 + 2] = 0;
     }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * draw_text(&frame, color, x_tl as i32, y_tl as i32, Scale 16, DejaVuSansMono, "{:.2}%") (inferer.rs:80-88) */
+#include <math.h>
+#include <stdio.h>
+
+#include "glyph_atlas.inc"
+
+/* format!("{:.2}%", confidence * 100.0): characters as indices into "0123456789.%"; returns the length (<= 8) or 0 when
+ * the value has no such representation (negative, NaN, >= 1000: never a confidence) */
+int ufo_label_chars(float confidence, uint8_t chars[8]) {
+  const float v = confidence * 100.0f; /* f32 product, as in the reference */
+  if (!(v >= 0.0f) || v >= 1000.0f) return 0;
+  /* v * 100 is exact in double (24 + 7 significant bits); nearbyint rounds half to even like Rust's exact formatting */
+  const long r = (long)nearbyint((double)v * 100.0);
+  char buf[16];
+  const int n = snprintf(buf, sizeof(buf), "%ld.%02ld%%", r / 100, r % 100);
+  if (n < 1 || n > UFD_GLYPH_POSITIONS) return 0;
+  for (int i = 0; i < n; i++) chars[i] = (uint8_t)(buf[i] == '.' ? 10 : (buf[i] == '%' ? 11 : buf[i] - '0'));
+  return n;
+}
+
+/* imageproc pixelops::weighted_sum + Clamp<f32> for u8 */
+static uint8_t blend_channel(uint8_t p, float color, float v) {
+  const float lw = 1.0f - v;
+  const float t = (float)p * lw + color * v;
+  return t < 255.0f ? (t > 0.0f ? (uint8_t)t : 0) : 255;
+}
+
+static void draw_label(uint8_t* rgb, int w, int h, int64_t x, int64_t y, const uint8_t* chars, int n) {
+  for (int k = 0; k < n; k++) { /* glyph by glyph in layout order: neighbouring boxes may share a pixel column */
+    const UfdGlyph* g = &kUfdGlyphs[k][chars[k]];
+    const float* cov = kUfdGlyphCoverage + g->off;
+    for (int gy = 0; gy < g->h; gy++)
+      for (int gx = 0; gx < g->w; gx++) {
+        const int64_t ix = gx + g->x + x, iy = gy + g->y + y;
+        if (ix < 0 || ix >= w || iy < 0 || iy >= h) continue;
+        uint8_t* p = rgb + ((size_t)iy * w + (size_t)ix) * 3;
+        const float v = cov[gy * g->w + gx];
+        p[0] = blend_channel(p[0], 0.0f, v), p[1] = blend_channel(p[1], 255.0f, v), p[2] = blend_channel(p[2], 0.0f, v);
+      }
+  }
+}
+
+/* draw_bboxes_on_image (inferer.rs:58-92): per detection, in order, the hollow rectangle then its label */
+void ufo_draw_labels(uint8_t* rgb, int w, int h, const ufo_det* dets, int n, float label_w, float label_h) {
+  for (int i = 0; i < n; i++) {
+    int64_t l, t, r, b;
+    if (!ufo_rect_of_det(&dets[i], label_w, label_h, &l, &t, &r, &b)) continue; /* (the reference would have panicked) */
+    ufo_draw_hollow_rects(rgb, w, h, &dets[i], 1, label_w, label_h);
+    uint8_t chars[8];
+    const int len = ufo_label_chars(dets[i].conf, chars);
+    draw_label(rgb, w, h, l, t, chars, len); /* text origin = (x_tl as i32, y_tl as i32) = the rectangle's corner */
   }
 }
 
@@ -488,7 +547,7 @@ size_t ufo_stream_item(const uint8_t* jpeg, size_t len, uint8_t* out, size_t cap
   return total;
 }
 
-/* Inferer::run, inferer.rs:35-40, text excepted: decompress_image -> infer_faces -> draw_bboxes_on_image ->
+/* Inferer::run, inferer.rs:35-40: decompress_image -> infer_faces -> draw_bboxes_on_image ->
  * compress_image(95, Sub2x2).  label_w / label_h are the slot's width / height (router.rs:66-67: 1280 x 720). */
 int ufo_annotate_encode_jpeg(const uint8_t* jpeg, size_t len, int model_w, int model_h, const float* weights,
                              const float* priors, float min_confidence, float max_iou, float label_w, float label_h, int quality,
@@ -505,7 +564,7 @@ int ufo_annotate_encode_jpeg(const uint8_t* jpeg, size_t len, int model_w, int m
     if (n < 0) rc = n;
   }
   if (rc == UFO_OK) {
-    ufo_draw_hollow_rects(rgb, info.width, info.height, dets, n < cap ? n : cap, label_w, label_h);
+    ufo_draw_labels(rgb, info.width, info.height, dets, n < cap ? n : cap, label_w, label_h);
     rc = ufo_jpeg_encode_rgb(rgb, info.width, info.height, quality, -1, out, out_cap, out_len);
   }
   free(rgb);

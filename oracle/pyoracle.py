@@ -74,6 +74,9 @@ def lib():
         L.ufo_rect_of_det.argtypes = [vp, c_f, c_f, i64p, i64p, i64p, i64p]
         L.ufo_draw_hollow_rects.argtypes = [vp, c_int, c_int, vp, c_int, c_f, c_f]
         L.ufo_draw_hollow_rects.restype = None
+        L.ufo_label_chars.argtypes = [c_f, vp]
+        L.ufo_draw_labels.argtypes = [vp, c_int, c_int, vp, c_int, c_f, c_f]
+        L.ufo_draw_labels.restype = None
         L.ufo_jpeg_quant_table.argtypes = [c_int, c_int, vp]
         L.ufo_jpeg_quant_table.restype = None
         L.ufo_jpeg_encode_bound.argtypes = [c_int, c_int]
@@ -277,6 +280,21 @@ def draw_hollow_rects(rgb, dets, label_w, label_h):
     return out
 
 
+def label_text(confidence):
+    """format!("{:.2}%", confidence * 100.0) (inferer.rs:88)."""
+    buf = (ctypes.c_uint8 * 8)()
+    n = lib().ufo_label_chars(float(confidence), buf)
+    return "".join("0123456789.%"[buf[i]] for i in range(n))
+
+
+def draw_labels(rgb, dets, label_w, label_h):
+    """draw_bboxes_on_image: rectangle + confidence label per detection, in order; returns a new HxWx3 array."""
+    out = np.ascontiguousarray(rgb, np.uint8).copy()
+    arr, n = _det_array(dets)
+    lib().ufo_draw_labels(out.ctypes.data, out.shape[1], out.shape[0], arr, n, label_w, label_h)
+    return out
+
+
 def quant_table(quality, chroma):
     out = np.empty(64, np.uint8)
     lib().ufo_jpeg_quant_table(quality, int(chroma), out.ctypes.data)
@@ -313,7 +331,7 @@ def stream_item(jpeg):
 
 
 def annotate_encode_jpeg(data, model_w, model_h, weights, priors, label_w, label_h, min_confidence=0.5, max_iou=0.5, quality=95):
-    """Inferer::run, inferer.rs:35-40 (no text): returns (detections [n,5], annotated JPEG bytes)."""
+    """Inferer::run, inferer.rs:35-40: returns (detections [n,5], annotated JPEG bytes)."""
     weights = np.ascontiguousarray(weights, np.float32)
     priors = np.ascontiguousarray(priors, np.float32)
     info = jpeg_probe(data)

@@ -117,6 +117,10 @@ int ufo_infer_jpeg_mt(const uint8_t* const* jpegs, const size_t* lens, int n_fra
 int ufo_rect_of_det(const ufo_det* d, float label_w, float label_h, int64_t* left, int64_t* top, int64_t* right, int64_t* bottom);
 /* draw_hollow_rect of every detection, colour (0, 255, 0), clipped to the w x h frame (text: not restated) */
 void ufo_draw_hollow_rects(uint8_t* rgb, int w, int h, const ufo_det* dets, int n, float label_w, float label_h);
+/* the label of a detection: format!("{:.2}%", confidence * 100.0) as indices into "0123456789.%"; returns its length */
+int ufo_label_chars(float confidence, uint8_t chars[8]);
+/* draw_bboxes_on_image (inferer.rs:58-92): per detection, in order, the rectangle then the label (glyph_atlas.inc) */
+void ufo_draw_labels(uint8_t* rgb, int w, int h, const ufo_det* dets, int n, float label_w, float label_h);
 /* jpeg_set_quality(quality, TRUE) table, natural order */
 void ufo_jpeg_quant_table(int quality, int chroma, uint8_t out[64]);
 size_t ufo_jpeg_encode_bound(int w, int h);
@@ -127,7 +131,7 @@ int ufo_jpeg_encode_rgb(const uint8_t* rgb, int w, int h, int quality, int dct, 
 int ufo_jpeg_encode_coefficients(const uint8_t* rgb, int w, int h, int quality, int dct, int16_t* coef);
 /* as_jpeg_stream_item (lib.rs:48-57): returns the framed length; writes when cap suffices */
 size_t ufo_stream_item(const uint8_t* jpeg, size_t len, uint8_t* out, size_t cap);
-/* inferer.rs:35-40 without the text: decode -> infer -> rectangles -> encode; returns the detection count or < 0 */
+/* inferer.rs:35-40: decode -> infer -> rectangles + labels -> encode; returns the detection count or < 0 */
 int ufo_annotate_encode_jpeg(const uint8_t* jpeg, size_t len, int model_w, int model_h, const float* weights,
                              const float* priors, float min_confidence, float max_iou, float label_w, float label_h, int quality,
                              ufo_det* dets, int cap, uint8_t* out, size_t out_cap, size_t* out_len);

@@ -68,7 +68,7 @@ def test_encoder_multipart_framing(model320):
     assert model320.debug_encode_rgb(rgb, 95) == jpeg  # and back to the plain header
 
 
-def test_rectangles_equal_the_oracle(model320):
+def test_rectangles_and_labels_equal_the_oracle(model320):
     rng = np.random.default_rng(11)
     rgb = synth.synth_frame(1, 3, 320, 240)
     dets = np.concatenate([
@@ -76,16 +76,36 @@ def test_rectangles_equal_the_oracle(model320):
         np.array([[0.0, 0.0, 1.0, 1.0, 0.9], [0.5, 0.5, 0.5, 0.9, 0.8],           # whole frame; zero width
                   [0.25, 0.25, 0.2534, 0.75, 0.7], [np.nan, 0.1, 0.5, 0.5, 0.6],   # one pixel wide; NaN corner
                   [-5.0, -5.0, 6.0, 6.0, 0.5], [0.999, 0.999, 1.5, 1.5, 0.5]], np.float32)])
+    dets[:, 4] = np.abs(dets[:, 4]) % 1.0  # confidences in [0, 1): labels "0.00%" .. "99.99%"
+    dets[3, 4], dets[4, 4] = 1.0, 0.999999  # "100.00%" twice (seven characters)
     for label in ((320, 240), (1280, 720), (100.5, 77.25)):
-        got = model320.debug_draw_rects(rgb, dets, label)
+        got = model320.debug_draw_labels(rgb, dets, label, text=False)
         assert np.array_equal(got, oracle.draw_hollow_rects(rgb, dets, *label)), label
-    assert np.array_equal(model320.debug_draw_rects(rgb, np.zeros((0, 5), np.float32), (320, 240)), rgb)
+        # with the labels: order matters (a label blends over earlier rectangles, later rectangles cut through it)
+        got = model320.debug_draw_labels(rgb, dets, label)
+        assert np.array_equal(got, oracle.draw_labels(rgb, dets, *label)), label
+    assert np.array_equal(model320.debug_draw_labels(rgb, np.zeros((0, 5), np.float32), (320, 240)), rgb)
+
+
+def test_many_overlapping_labels_keep_the_reference_order(model320):
+    """Hundreds of detections piled on the same spot (more than one 256-operation pass of the tile kernel): every pixel
+    must see rectangles and label blends in detection order."""
+    rng = np.random.default_rng(5)
+    rgb = synth.synth_frame(1, 4, 320, 240)
+    n = 700
+    dets = np.zeros((n, 5), np.float32)
+    dets[:, 0] = 0.3 + rng.uniform(-0.05, 0.05, n)
+    dets[:, 1] = 0.3 + rng.uniform(-0.05, 0.05, n)
+    dets[:, 2] = dets[:, 0] + rng.uniform(0.05, 0.4, n)
+    dets[:, 3] = dets[:, 1] + rng.uniform(0.05, 0.4, n)
+    dets[:, 4] = rng.uniform(0.5, 1.0, n)
+    assert np.array_equal(model320.debug_draw_labels(rgb, dets, (320, 240)), oracle.draw_labels(rgb, dets, 320, 240))
 
 
 def _expected_stream(jpeg, dets, label, quality=95):
     """The oracle's draw + encode of the oracle's decode, with the detections the GPU reported (detections are
     compared with the oracle's separately: a rectangle corner may sit on an integer boundary)."""
-    frame = oracle.draw_hollow_rects(oracle.jpeg_decode_rgb(jpeg), dets_array(dets), *label)
+    frame = oracle.draw_labels(oracle.jpeg_decode_rgb(jpeg), dets_array(dets), *label)
     return oracle.jpeg_encode_rgb(frame, quality)
 
 
@@ -142,6 +162,16 @@ def test_annotate_reference_test_pictures(model320, name):
     jpeg = open(os.path.join(PICS, name), "rb").read()
     d, s = model320.annotate_jpeg(jpeg, (1280, 720))
     assert s == _expected_stream(jpeg, d, (1280, 720))
+
+
+def test_annotate_without_text_flag(weights):
+    W, H = 320, 240
+    jpegs = synth.synth_jpeg_pool(2, 2, W, H, quality=90, subsampling="4:2:0")
+    with _model(320, weights, max_batch=2, max_src=(W, H), det_cap=4420) as m:
+        dets, status, streams = m.annotate_jpeg_batch(jpegs, (W, H), text=False)
+        for j, d, s in zip(jpegs, dets, streams):
+            frame = oracle.draw_hollow_rects(oracle.jpeg_decode_rgb(j), dets_array(d), W, H)
+            assert s == oracle.jpeg_encode_rgb(frame, 95)
 
 
 def test_annotate_output_buffer_too_small(weights):

@@ -101,7 +101,7 @@ def test_streams_of_both_variants_and_output_kinds(weights):
             assert r["status"] == 0 and r["variant"] == variant
             assert_dets_match(dets_array(r["dets"]), oracle.infer_jpeg(j, w, h, weights, pri[variant]), what="sched")
             if annot:
-                frame = oracle.draw_hollow_rects(oracle.jpeg_decode_rgb(j), dets_array(r["dets"]), 1280, 720)
+                frame = oracle.draw_labels(oracle.jpeg_decode_rgb(j), dets_array(r["dets"]), 1280, 720)
                 assert r["jpeg"] == oracle.jpeg_encode_rgb(frame, 95)
             else:
                 assert r["jpeg"] is None
