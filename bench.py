@@ -98,7 +98,7 @@ def parse_args():
     ap.add_argument("--annotate", action="store_true",
                     help="time the whole Inferer::run iteration instead (decode -> infer -> rectangles -> JPEG re-encode, "
                          "ufd_submit_annotate_batch): a side workload for profiling N1, not BASELINE.json's metric")
-    ap.add_argument("--profile-every", type=int, default=8, help="record kernel events for every n-th timed step (0: never)")
+    ap.add_argument("--profile-every", type=int, default=10, help="record kernel events for every n-th timed step (0: never)")
     return ap.parse_args()
 
 
