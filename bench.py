@@ -323,7 +323,9 @@ def main():
             run_steps(3, primary_staged, depth=depth)
             model.profile_reset()
             run_steps(k, primary_staged, depth=depth)
-            for stg, ms in stage_ms(model.profile_read(), k).items():
+            st_run = model.profile_read()
+            extras["kernel_stats_" + name] = st_run
+            for stg, ms in stage_ms(st_run, k).items():
                 sb.setdefault(stg, {})[name + "_ms"] = round(ms, 4)
         extras["stages"] = sb
         model.profile_sampling(1 << 30)
@@ -425,6 +427,14 @@ def main():
             except Exception:
                 pass
             per_launch = d["bytes"] / max(d["launches"], 1)
+            alone = aggregate(extras.get("kernel_stats_alone", [])).get(dom)
+            if alone and alone["ms"] > 0:  # the same kernel with one batch in flight (nothing else on the GPU)
+                a_tfl = alone["flops"] / (alone["ms"] * 1e-3) / 1e12
+                a_gbs = alone["bytes"] / (alone["ms"] * 1e-3) / 1e9
+                roof["alone"] = {"avg_launch_us": round(alone["ms"] * 1e3 / max(alone["launches"], 1), 2), "launches": alone["launches"],
+                                 "mfma_frac": round(a_tfl / MFMA_F32_PEAK_TFLOPS, 4), "hbm_frac": round(a_gbs / HBM_PEAK_GBS, 4),
+                                 "what": "one batch in flight: the kernel has the GPU to itself; `frac` above is with six batches in "
+                                         "flight over three contexts, whose kernels share the GPU"}
             roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(per_launch),
                          "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
