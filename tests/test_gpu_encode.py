@@ -184,3 +184,23 @@ def test_annotate_output_buffer_too_small(weights):
         assert streams[0] == ref_s[0] and streams[1] == ref_s[1]
         assert status[:2] == [0, 0] and status[2:] == [nn.UFD_E_TRUNCATED] * 2 and streams[2] is None and streams[3] is None
         assert dets[2] == ref_d[2]  # detections of a truncated frame are still reported
+
+
+def test_annotate_mixed_frame_sizes_and_flavours_in_one_batch(weights):
+    """Frames of different sizes, subsamplings and coding modes in one annotate batch (the encoder kernels take every
+    frame's own dimensions; progressive and 4:4:4 frames go through the host entropy decoder and the generic upsampler):
+    every stream equals the oracle's for that frame."""
+    frames = [
+        synth.encode_jpeg(synth.synth_frame(31, 0, 320, 240)),
+        synth.encode_jpeg(synth.synth_frame(31, 1, 640, 480), subsampling="4:2:2"),
+        synth.encode_jpeg(synth.synth_frame(31, 2, 72, 56), subsampling="4:4:4"),
+        synth.encode_jpeg(synth.synth_frame(31, 3, 333, 217)),
+        synth.encode_jpeg(synth.synth_frame(31, 4, 640, 360), progressive=True),
+        synth.encode_jpeg(synth.synth_frame(31, 5, 24, 24), restart_rows=1),
+    ]
+    with _model(320, weights, max_batch=8, max_src=(640, 480), det_cap=4420) as m:
+        for label in ((1280, 720), (320, 240)):
+            dets, status, streams = m.annotate_jpeg_batch(frames, label)
+            assert status == [0] * len(frames)
+            for j, d, s in zip(frames, dets, streams):
+                assert s == _expected_stream(j, d, label)
