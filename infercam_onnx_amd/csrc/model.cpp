@@ -1048,7 +1048,7 @@ void enqueue_forward(ufd_model* m, uint32_t count) {
   tl_cur->last_forward_count = count;
 }
 
-void enqueue_heads(ufd_model* m, uint32_t count) {
+void enqueue_heads(ufd_model* m, uint32_t count, bool raw_outputs = false) {
   HeadArgs h;
   int base = 0;
   for (int i = 0; i < 4; i++) {
@@ -1062,8 +1062,8 @@ void enqueue_heads(ufd_model* m, uint32_t count) {
   }
   h.base[4] = base;
   (void)hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream);
-  ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 6 + 4) * 4, 0);
-  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, tl_cur->d_scores, tl_cur->d_boxes, tl_cur->d_keys, m->key_stride,
+  ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 4) * 4, 0);
+  launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, raw_outputs ? tl_cur->d_scores : nullptr, tl_cur->d_boxes, tl_cur->d_keys, m->key_stride,
                      tl_cur->d_counts, tl_cur->stream);
 }
 
@@ -2462,7 +2462,7 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
     const size_t in_floats = (size_t)count * 3 * m->W * m->H;
     HIPC(m, hipMemcpyAsync(tl_cur->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, tl_cur->stream));
     enqueue_forward(m, count);
-    enqueue_heads(m, count);
+    enqueue_heads(m, count, /*raw_outputs=*/true);
     HIPC(m, hipMemcpyAsync(scores, tl_cur->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(boxes, tl_cur->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipStreamSynchronize(tl_cur->stream));

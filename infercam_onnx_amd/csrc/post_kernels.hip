@@ -71,9 +71,12 @@ __global__ __launch_bounds__(256) void k_head_decode(HeadArgs h, const float* __
   bb.z = cx + bw / 2.0f;
   bb.w = cy + bh / 2.0f;
   const size_t o = (size_t)frame * K + k;
-  reinterpret_cast<float2*>(scores)[o] = make_float2(c0, c1);
-  reinterpret_cast<float4*>(boxes)[o] = bb;
-  if (c1 > min_conf) {  // strict; NaN fails
+  const bool cand = c1 > min_conf;  // strict; NaN fails
+  // the raw [K, 6] outputs exist for the stage tap only (scores != null): the product keeps the boxes of the
+  // candidates, which is all the sort / NMS kernels read
+  if (scores) reinterpret_cast<float2*>(scores)[o] = make_float2(c0, c1);
+  if (scores || cand) reinterpret_cast<float4*>(boxes)[o] = bb;
+  if (cand) {
     const uint32_t pos = atomicAdd(&counts[frame], 1u);
     keys[(size_t)frame * key_stride + pos] = make_key(c1, (uint32_t)k);
   }
