@@ -70,6 +70,36 @@ class UltrafaceModel : public InferModel {
     if (rc != UFD_OK && rc != UFD_E_TRUNCATED) throw std::runtime_error(std::string("ufd_infer_jpeg: ") + ufd_last_error(h_));
     return collect(out, n);
   }
+  // Inferer::run, the whole iteration (inferer.rs:35-40): decompress_image -> infer_faces -> draw_bboxes_on_image(image,
+  // boxes, width, height) -> compress_image(&frame, 95, Sub2x2).  width / height = the slot's labels (router.rs:66-67).
+  struct Annotated {
+    std::vector<std::pair<Bbox, float>> bboxes_with_confidences;
+    std::vector<uint8_t> jpeg;
+  };
+  Annotated annotate_jpeg(const uint8_t* jpeg, size_t len, uint32_t width, uint32_t height, uint32_t quality = 95,
+                          bool multipart = false) {
+    std::vector<ufd_det> out(kCap);
+    uint32_t n = 0;
+    int32_t st = 0;
+    uint32_t w = 0, h = 0;
+    if (ufd_debug_jpeg_coefficients(jpeg, len, nullptr, 0, &n, &w, &h) != UFD_OK) throw std::runtime_error("not a JPEG");
+    Annotated r;
+    r.jpeg.resize(ufd_encode_bound(w, h));
+    size_t off = 0, out_len = 0;
+    ufd_annotate a{};
+    a.struct_size = sizeof(a);
+    a.label_width = (float)width, a.label_height = (float)height;
+    a.quality = quality, a.flags = multipart ? UFD_ANNOT_MULTIPART : 0;
+    a.jpeg_out = r.jpeg.data(), a.jpeg_cap = r.jpeg.size(), a.jpeg_off = &off, a.jpeg_len = &out_len;
+    n = 0;
+    int rc = ufd_annotate_jpeg_batch(h_, &jpeg, &len, 1, &a, out.data(), kCap, &n, &st);
+    if (rc != UFD_OK || (st != UFD_OK && st != UFD_E_TRUNCATED))
+      throw std::runtime_error(std::string("ufd_annotate_jpeg_batch: ") + ufd_last_error(h_));
+    r.jpeg.erase(r.jpeg.begin(), r.jpeg.begin() + (long)off);
+    r.jpeg.resize(out_len);
+    r.bboxes_with_confidences = collect(out, n);
+    return r;
+  }
   ufd_model* handle() { return h_; }
 
  private:

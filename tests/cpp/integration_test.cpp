@@ -46,6 +46,15 @@ int main(int argc, char** argv) {
       if (expect && (int)bboxes_with_confidences.size() != expected_num_faces) return std::printf("face count mismatch\n"), 1;
       for (size_t i = 1; i < via_jpeg.size(); i++)
         if (via_jpeg[i].second > via_jpeg[i - 1].second) return std::printf("not in descending confidence\n"), 1;
+      // the rest of the Inferer::run iteration (inferer.rs:38-40): same detections, and a baseline JPEG of the same size back
+      auto annotated = model.annotate_jpeg(jpeg.data(), jpeg.size(), 1280, 720);
+      if (annotated.bboxes_with_confidences != via_jpeg) return std::printf("annotate and decode->infer disagree\n"), 1;
+      uint32_t aw = 0, ah = 0, ncoef = 0;
+      if (annotated.jpeg.size() < 700 || annotated.jpeg[0] != 0xFF || annotated.jpeg[1] != 0xD8 ||
+          annotated.jpeg[annotated.jpeg.size() - 2] != 0xFF || annotated.jpeg.back() != 0xD9 ||
+          ufd_debug_jpeg_coefficients(annotated.jpeg.data(), annotated.jpeg.size(), nullptr, 0, &ncoef, &aw, &ah) != UFD_OK ||
+          aw != w || ah != h)
+        return std::printf("annotated stream is not a %ux%u JPEG\n", w, h), 1;
     }
   } catch (const std::exception& e) {
     return std::printf("error: %s\n", e.what()), 1;
