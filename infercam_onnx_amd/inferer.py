@@ -3,8 +3,9 @@ the infer channel, decodes, runs the model and hands the result to the slot's se
 
 The reference processes one slot at a time on one task (inferer.rs:29-50) with UltraFace-320 and
 thresholds 0.5/0.5 (inferer.rs:23); here one GPU worker drains the queue in batches through the
-asynchronous C ABI.  Draw + JPEG re-encode (inferer.rs:38-40) are outside this path:
-the sender receives the detections.
+asynchronous C ABI.  With `annotate=True` the whole iteration runs on the GPU (N1: rectangles + labels drawn
+at the slot's width / height labels, JPEG quality 95 4:2:0 re-encode, inferer.rs:38-40) and the sender receives what the
+reference sends -- `as_jpeg_stream_item(&buf)` (inferer.rs:41-46); otherwise it receives the detections.
 """
 import collections
 import queue
@@ -19,9 +20,10 @@ class Inferer:
     (lib.rs:32); `sender` is a callable receiving `(detections or None, status)`; a `None` slot
     stops the loop (the reference loops forever)."""
 
-    def __init__(self, infer_rx, model=None, max_batch=32, depth=6, **model_kw):
+    def __init__(self, infer_rx, model=None, max_batch=32, depth=6, annotate=False, **model_kw):
         self.infer_rx = infer_rx
         self.max_batch = max_batch
+        self.annotate = annotate
         # batches in flight: the handle runs three device contexts, two batches each keep them fed
         self.depth = max(1, min(depth, 8))
         # reference default: UltrafaceModel::new(W320H240, 0.5, 0.5) (inferer.rs:23)
@@ -53,7 +55,15 @@ class Inferer:
             if slots[-1] is None:
                 stop = True
                 slots = slots[:-1]
-            if slots:
+            if slots and self.annotate:
+                # one annotate batch per label size (the reference's router stamps 1280 x 720 on every slot, router.rs:66-67)
+                by_label = collections.OrderedDict()
+                for s in slots:
+                    by_label.setdefault((s[0], s[1]), []).append(s)
+                for label, group in by_label.items():
+                    b = self.model.prep_annotate_batch([s[2] for s in group], label, quality=95, multipart=True)
+                    pending.append((self.model.submit_annotate_batch(b), group))
+            elif slots:
                 pending.append((self.model.submit_jpeg_batch([s[2] for s in slots]), slots))
             while len(pending) >= self.depth:
                 self._deliver(*pending.popleft())
@@ -61,6 +71,12 @@ class Inferer:
             self._deliver(*pending.popleft())
 
     def _deliver(self, ticket, slots):
+        if self.annotate:
+            _, status, streams = self.model.wait(ticket)
+            for slot, item, st in zip(slots, streams, status):
+                if slot[3] is not None and item is not None:  # (a frame that failed to decode sends nothing: inferer.rs:37)
+                    slot[3](item)
+            return
         results, status = self.model.wait(ticket)
         for slot, dets, st in zip(slots, results, status):
             if slot[3] is not None:

@@ -69,6 +69,35 @@ def test_inferer_loop(oracle_lib, weights):
     model.close()
 
 
+def test_inferer_loop_annotate(oracle_lib, weights):
+    """The whole Inferer::run iteration (inferer.rs:35-46): the sender receives `as_jpeg_stream_item(&buf)` of the
+    annotated frame; a frame that fails to decode sends nothing (inferer.rs:37, `if let Ok`)."""
+    from infercam_onnx_amd import nn, synth
+    from infercam_onnx_amd.inferer import Inferer
+
+    W, H = 320, 240
+    pri = synth.gen_priors(W, H)
+    model = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights, priors=pri, max_batch=4,
+                              max_src=(1280, 720), det_cap=4420)
+    rx = queue.Queue()
+    got = {}
+    jpegs = [synth.encode_jpeg(synth.synth_frame(67, i, 640, 480)) for i in range(5)]
+    labels = [(1280, 720), (1280, 720), (1280, 720), (640, 480), (1280, 720)]  # a second label size splits the batch
+    for i, j in enumerate(jpegs):
+        rx.put((labels[i][0], labels[i][1], j if i != 1 else j[:555], lambda r, i=i: got.__setitem__(i, r)))
+    rx.put(None)
+    Inferer(rx, model=model, max_batch=4, annotate=True).run()
+    assert sorted(got) == [0, 2, 3, 4]
+    for i in (0, 2, 3, 4):
+        # drawn with the detections the GPU reports (compared with the oracle's on their own: a corner may sit on a
+        # rounding boundary), then the oracle's draw + encode + multipart framing
+        dets = model.infer_jpeg(jpegs[i])
+        assert_dets_match(dets_array(dets), oracle_lib.infer_jpeg(jpegs[i], W, H, weights, pri, 0.5, 0.5), what="inferer")
+        frame = oracle_lib.draw_labels(oracle_lib.jpeg_decode_rgb(jpegs[i]), dets_array(dets), *labels[i])
+        assert got[i] == oracle_lib.stream_item(oracle_lib.jpeg_encode_rgb(frame, 95)), i
+    model.close()
+
+
 @pytest.mark.gpu
 def test_whole_file_fuzz_never_faults():
     """tools/fuzz_gpu.py: random corruptions over whole JPEG files (headers, markers, entropy data)
