@@ -17,7 +17,7 @@
  *     fixtures (tests/golden/jpeg_*.npz) -- same library, same defaults as
  *     turbojpeg::decompress_image (tjDecompress2 flags=0: ISLOW IDCT, fancy upsampling).
  *   - Resize/normalize: restated from image 0.24.5 sample.rs semantics,
- *     checked against an independent numpy twin + analytic tap tables.
+ *     checked against an independent numpy twin + analytic tap tables, and within one grey level of Pillow's BILINEAR.
  *   - CNN: checked against torch.nn.functional.conv2d (independent implementation).
  *   - Threshold / sort / NMS / IoU: first-party reference code, restated line by line
  *     from infer_server/src/nn.rs:109-140,198-260; known-answer cases in tests.

@@ -75,6 +75,26 @@ def test_constant_image_and_identity(oracle_lib):
     assert np.array_equal(oracle_lib.resize_triangle(f, 64, 48), f)
 
 
+@pytest.mark.parametrize("src,dst", [((1280, 720), (320, 240)), ((1280, 720), (640, 480)), ((640, 427), (640, 480)),
+                                     ((100, 75), (320, 240)), ((333, 517), (320, 240))])
+def test_resize_against_pillow_bilinear(oracle_lib, src, dst):
+    """A resampler nobody here wrote: Pillow's BILINEAR is the same triangle window (support widened by the downscale
+    ratio, centres at (o + 0.5) * ratio, weights normalised per output sample) with a different pass order and an
+    8-bit intermediate, so the two agree to one grey level on every sample -- a wrong support, centre or clamp of the
+    restated window would not."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    sw, sh = src
+    y, x = np.mgrid[0:sh, 0:sw]
+    img = np.stack([(128 + 100 * np.sin(x / 17.0 + c) * np.cos(y / 23.0) + rng.integers(-20, 20, (sh, sw))).clip(0, 255)
+                    for c in range(3)], -1).astype(np.uint8)
+    got = oracle_lib.resize_triangle(img, dst[0], dst[1])
+    ref = np.asarray(Image.fromarray(img).resize(dst, Image.BILINEAR))
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.3
+
+
 def test_normalize_closure(oracle_lib):
     rgb = np.arange(256 * 3, dtype=np.uint32).reshape(16, 16, 3).astype(np.uint8)
     got = oracle_lib.normalize_nchw(rgb)
