@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 script rehearsal on a one-GPU box: all ranks on cuda:0, exchanges over gloo (not a measurement)")
     ap.add_argument("--input", choices=["host", "hbm"], default="host",
                     help="host: the timed region starts from JPEG bytes in host memory (the reference's boundary, PCIe "
                          "included); hbm: the JPEG bytes of every batch are staged in HBM before the clock starts "
@@ -177,20 +179,27 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            # script rehearsal on a one-GPU box: every rank on cuda:0, the exchanges over gloo on host tensors.
+            # Not a measurement (the ranks share the GPU); the JSON line says so in config.rehearsal.
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, "RCCL formed %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = None if args.rehearse_one_gpu else dev  # where the tensors of the exchanges live
 
     from infercam_onnx_amd import nn, parallel, synth
 
     W, H, B = (640, 480, args.batch) if args.variant == 640 else (320, 240, args.batch)
     variant = nn.UltrafaceVariant.W640H480 if args.variant == 640 else nn.UltrafaceVariant.W320H240
     # ---- weights: generated on rank 0, broadcast over RCCL (the path's only collective)
-    weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist, device=dev)
+    weights = parallel.broadcast_weights(synth.synthetic_weights() if rank == 0 else None, dist, device=xdev)
     priors = synth.gen_priors(W, H)
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
@@ -267,14 +276,14 @@ def main():
     el_local = time.perf_counter() - t0
     barrier()
     el = time.perf_counter() - t0
-    el = parallel.max_over_ranks(el, dist, device=dev)
+    el = parallel.max_over_ranks(el, dist, device=xdev)
     stats = model.profile_read()
     prof_steps = max(1, (args.steps + args.profile_every - 1) // args.profile_every) if args.profile_every > 0 else 0
 
     # ---- per-rank record: which device each rank ran on and what it did alone
     props = torch.cuda.get_device_properties(local_rank)
     mine = torch.tensor([rank, local_rank, B * args.steps / el_local, getattr(props, "pci_bus_id", -1),
-                         getattr(props, "pci_device_id", -1)], dtype=torch.float64, device=dev)
+                         getattr(props, "pci_device_id", -1)], dtype=torch.float64, device=xdev if dist is not None else dev)
     if dist is not None:
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -282,7 +291,7 @@ def main():
         allr = [mine]
     ranks = [{"rank": int(t[0]), "local_rank": int(t[1]), "fps": round(float(t[2]), 1),
               "pci": "%02x:%02x" % (int(t[3]), int(t[4]))} for t in (x.cpu() for x in allr)]
-    if dist is not None:
+    if dist is not None and not args.rehearse_one_gpu:
         assert len({r["pci"] for r in ranks}) == world or ranks[0]["pci"] == "-1:-1", "two ranks share a GPU: %s" % ranks
 
     def aggregate(st):
@@ -462,6 +471,8 @@ def main():
             "whole_net_mfma_frac": round(frames / el * flops_frame / 1e12 / MFMA_F32_PEAK_TFLOPS / world, 4),
             "detections_per_frame": round(ndet / (B * args.steps), 2),
         }
+        if args.rehearse_one_gpu and world > 1:
+            out["config"]["rehearsal"] = "all %d ranks shared cuda:0 and exchanged over gloo: a run of the N>1 script path, NOT a measurement" % world
         out["config"].update({k: v for k, v in extras.items() if k.endswith("_fps")})
         if "stages" in extras:
             out["stages"] = extras["stages"]
