@@ -101,15 +101,16 @@ def test_inferer_loop_annotate(oracle_lib, weights):
 @pytest.mark.gpu
 def test_whole_file_fuzz_never_faults():
     """tools/fuzz_gpu.py: random corruptions over whole JPEG files (headers, markers, entropy data)
-    in mixed batches.  A GPU memory fault aborts the child process, so it runs as one."""
+    in mixed batches, through the detection path and the annotate + re-encode path.  A GPU memory fault aborts the child process, so it runs as one."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "40"], cwd=root, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "fuzz ok" in r.stdout
+    for extra in (["40"], ["30", "big"]):  # thumbnails through UltraFace-320; 640x480-class frames through UltraFace-640
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py")] + extra, cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "fuzz ok" in r.stdout
 
 
 @pytest.mark.gpu

@@ -1,7 +1,10 @@
 """Robustness fuzz on the GPU box: random corruptions over whole JPEG files (headers included)
-through ufd_infer_jpeg_batch in mixed batches.  Every frame must end as OK / UFD_E_DECODE /
-UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE, and a clean batch must still decode bit-exactly afterwards.
-Usage: python tools/fuzz_gpu.py [rounds]   (exits non-zero on any violation)"""
+through ufd_infer_jpeg_batch and, every other round, ufd_annotate_jpeg_batch (rectangles + labels + re-encode of
+whatever the damaged frame decodes to) in mixed batches.  Every frame must end as OK / UFD_E_TRUNCATED / UFD_E_DECODE /
+UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE, every annotated stream must be a framed JPEG, and a clean batch must still decode
+bit-exactly afterwards.
+Usage: python tools/fuzz_gpu.py [rounds] [big]   (exits non-zero on any violation; "big": 640x480-class frames through
+UltraFace-640 instead of thumbnail-sized ones through UltraFace-320)"""
 import sys
 import numpy as np
 
@@ -36,18 +39,31 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(11)
     w = synth.synthetic_weights()
-    m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=8,
-                          max_src=(640, 480), det_cap=4420)
-    base = [synth.encode_jpeg(synth.synth_frame(5, i, 96 + 8 * i, 64 + 8 * i), **kw) for i, kw in enumerate((
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"
+    if big:
+        m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=w, priors=synth.gen_priors(640, 480), max_batch=8,
+                              max_src=(704, 544), det_cap=17640)
+    else:
+        m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=8,
+                              max_src=(640, 480), det_cap=4420)
+    w0, h0 = (640, 480) if big else (96, 64)
+    base = [synth.encode_jpeg(synth.synth_frame(5, i, w0 + 8 * i, h0 + 8 * i), **kw) for i, kw in enumerate((
         {}, {"restart_rows": 1}, {"subsampling": "4:2:2"}, {"progressive": True}, {"optimize": True, "quality": 30},
         {"subsampling": "4:4:4", "restart_rows": 2}, {"quality": 100}, {"subsampling": "4:2:2", "restart_rows": 1}))]
     ref, st = m.infer_jpeg_batch(base)
     assert st == [0] * len(base), st
-    allowed = (0, nn.UFD_E_DECODE, nn.UFD_E_UNSUPPORTED, nn.UFD_E_TOO_LARGE)
+    allowed = (0, nn.UFD_E_TRUNCATED, nn.UFD_E_DECODE, nn.UFD_E_UNSUPPORTED, nn.UFD_E_TOO_LARGE)
     seen = {}
     for r in range(rounds):
         batch = [corrupt(rng, j) if rng.random() < 0.8 else j for j in base]
-        res, st = m.infer_jpeg_batch(batch)
+        if r & 1:
+            res, st, streams = m.annotate_jpeg_batch(batch, (1280, 720), quality=int(rng.integers(1, 101)))
+            for s, x in zip(st, streams):
+                if s in (0, nn.UFD_E_TRUNCATED) and not (x and x[:2] == b"\xff\xd8" and x[-2:] == b"\xff\xd9"):
+                    print("annotated stream of an OK frame is not a JPEG")
+                    sys.exit(4)
+        else:
+            res, st = m.infer_jpeg_batch(batch)
         for s in st:
             seen[s] = seen.get(s, 0) + 1
         if not all(s in allowed for s in st):
