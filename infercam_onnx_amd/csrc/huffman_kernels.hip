@@ -789,7 +789,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
   }
 }
 
-__global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, size_t coef_stride, uint32_t vec_per_frame) {
+__global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, size_t coef_stride, uint32_t vec_per_frame,
+                                                   uint32_t* __restrict__ status) {
+  // the batch's first kernel also clears the per-frame decode status (a memset launch of its own otherwise)
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[blockIdx.y] = 0;
   // 16-byte stores; coef_stride is a multiple of 8 int16
   uint4* dst = reinterpret_cast<uint4*>(coef + (size_t)blockIdx.y * coef_stride);
   for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < vec_per_frame; v += gridDim.x * 256) dst[v] = make_uint4(0, 0, 0, 0);
@@ -797,11 +800,11 @@ __global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, s
 
 }  // namespace
 
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, hipStream_t s) {
-  if (!frames || !used_int16) return;
+void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s) {
+  if (!frames) return;
   const uint32_t vecs = (uint32_t)((used_int16 + 7) / 8);
   const unsigned gx = std::min<unsigned>((vecs + 1023) / 1024, 256u);  // >= 4 stores per thread
-  hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs);
+  hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs, d_status);
 }
 
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride, SyncBuffers* layout) {

@@ -97,7 +97,7 @@ using HuffStageHook = std::function<void(const char* kernel, bool begin)>;
 // Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride /* blocks per frame */, SyncBuffers* layout);
 // Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, hipStream_t s);
+void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s);
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
@@ -212,7 +212,7 @@ struct Det {
 // Frames with more than 256 (and at most 2048) candidates are finished by two more launches: their
 // suppression matrix over the whole GPU, then one wave per frame (d_mat: nms_matrix_bytes(B) of
 // scratch; nullptr keeps everything inside the first kernel).
-void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
+void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
                      unsigned long long* d_mat, uint32_t B, hipStream_t s);
 size_t nms_matrix_bytes(uint32_t B);

@@ -1061,7 +1061,7 @@ void enqueue_heads(ufd_model* m, uint32_t count, bool raw_outputs = false) {
     base += h.plane[i] * kHeadAnchors[i];
   }
   h.base[4] = base;
-  (void)hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream);
+  // (d_counts is zero here: allocated zeroed, and k_sort_nms puts every counter back to zero once it has read it)
   ProfScope ps(m, "head_decode", (double)count * m->K * (6 + 4) * 4, 0);
   launch_head_decode(h, m->d_priors, count, m->cfg.min_confidence, raw_outputs ? tl_cur->d_scores : nullptr, tl_cur->d_boxes, tl_cur->d_keys, m->key_stride,
                      tl_cur->d_counts, tl_cur->stream);
@@ -1337,9 +1337,8 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
                            const JpegFrameDesc* d_descs, const HuffScan* d_scans, const HuffInterval* d_ivs, int16_t* d_coef) {
   {
     ProfScope ps(m, "zero_coef", (double)p.used_coef * 2 * count, 0);
-    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.stream);
+    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.d_status, c.stream);  // (also clears d_status)
   }
-  HIPC(m, hipMemsetAsync(c.d_status, 0, sizeof(uint32_t) * count, c.stream));
   {
     std::unique_ptr<ProfScope> scope;
     const double bytes = (double)p.used_blob;
@@ -2012,6 +2011,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_boxes, B * m->K * 4 * sizeof(float)));
     HIPB(hipMalloc(&c.d_keys, B * m->key_stride * sizeof(unsigned long long)));
     HIPB(hipMalloc(&c.d_counts, B * sizeof(uint32_t)));
+    HIPB(hipMemset(c.d_counts, 0, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_ndet, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
     HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B)));
@@ -2463,6 +2463,8 @@ int ufd_debug_forward(ufd_model* m, const float* input_nchw, uint32_t count, flo
     HIPC(m, hipMemcpyAsync(tl_cur->d_input, input_nchw, in_floats * sizeof(float), hipMemcpyHostToDevice, tl_cur->stream));
     enqueue_forward(m, count);
     enqueue_heads(m, count, /*raw_outputs=*/true);
+    // (no k_sort_nms follows on this tap: put the candidate counters back to zero here)
+    HIPC(m, hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(scores, tl_cur->d_scores, sizeof(float) * 2 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(boxes, tl_cur->d_boxes, sizeof(float) * 4 * m->K * count, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipStreamSynchronize(tl_cur->stream));
@@ -2505,7 +2507,6 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
     if (rc) return rc;
     HIPC(m, hipMemcpyAsync(tl_cur->d_scores, scores, sizeof(float) * 2 * m->K * count, hipMemcpyHostToDevice, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(tl_cur->d_boxes, boxes, sizeof(float) * 4 * m->K * count, hipMemcpyHostToDevice, tl_cur->stream));
-    HIPC(m, hipMemsetAsync(tl_cur->d_counts, 0, sizeof(uint32_t) * count, tl_cur->stream));
     launch_threshold(tl_cur->d_scores, m->K, count, m->cfg.min_confidence, tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->stream);
     enqueue_nms(m, *s, count);
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;

@@ -150,7 +150,7 @@ __device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const 
 //   phase 3  wave 0 resolves the block serially with bit operations: i survives iff not dead;
 //            a survivor kills row i.  Exactly the reference's greedy order (nn.rs:198-224).
 __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
-                                                  const uint32_t* __restrict__ counts, const float* __restrict__ boxes,
+                                                  uint32_t* __restrict__ counts, const float* __restrict__ boxes,
                                                   int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
                                                   uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min) {
   __shared__ unsigned long long s_keys[kSortLds];
@@ -177,6 +177,9 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   }
   if (tid == 0) s_nsel = 0;
   __syncthreads();
+  // every thread has read the frame's candidate count: leave it at zero for the next batch's k_head_decode / k_threshold
+  // (the counters are zero whenever no batch is between those kernels and this one: no memset launch per batch)
+  if (tid == 0) counts[frame] = 0;
   if (n > 1) bitonic_desc(keys, n2, tid, nthr, keys == s_keys);
   const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
   float4* fspill = spill + (size_t)frame * K;
@@ -449,7 +452,7 @@ void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_c
                      key_stride, d_counts);
 }
 
-void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, const uint32_t* d_counts, const float* d_boxes,
+void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
                      unsigned long long* d_mat, uint32_t B, hipStream_t s) {
   const int knob = kMatMin;
