@@ -53,7 +53,8 @@ typedef struct ufd_config {
   float max_iou;           /* reference passes 0.5 (inferer.rs:23) */
   float min_confidence;    /* reference passes 0.5 */
   int32_t device_id;       /* HIP device ordinal */
-  uint32_t max_batch;      /* frames per batched call (>= 1) */
+  uint32_t max_batch;      /* frames per batched call (1..1024; every activation tensor of a batch must stay below 4 GiB:
+                              at most 873 for UltraFace-640, else UFD_E_TOO_LARGE) */
   uint32_t max_src_width;  /* largest decoded frame accepted; 0 -> 1920 */
   uint32_t max_src_height; /* 0 -> 1088 */
   uint32_t host_threads;   /* host entropy-decode workers; 0 -> min(32, hardware threads) */

@@ -141,16 +141,7 @@ __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red
 // unconditional: dead lanes read a valid dummy address), so a wave does not pay one memory round
 // trip per k-step.  Needs ksteps % D == 0.
 template <int CT, int D, int SK>
-#ifndef WPE_PW
-#define WPE_PW
-#endif
-#ifndef WPE_DWPW
-#define WPE_DWPW
-#endif
-#ifndef WPE_COOP
-#define WPE_COOP
-#endif
-__global__ __launch_bounds__(256) WPE_PW void k_pw_mfma(ConvArgs3 p3) {
+__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
   const ConvArgs& a = p3.a[blockIdx.y];
   // LDS: weights of this cout tile [ksteps][64] (one vector-memory instruction per k-step is left:
   // the activation load) | split-K reduction buffer
@@ -267,7 +258,7 @@ __device__ __forceinline__ void fill_dw_variants(float* s_dw, const float* __res
 __device__ __forceinline__ int dw_variant(bool row0ok, bool row2ok) { return !row0ok ? 1 : (!row2ok ? 2 : 0); }
 
 template <int CT, int S, int D, int SK>
-__global__ __launch_bounds__(256) WPE_DWPW void k_dwpw_mfma(ConvArgs3 p3) {
+__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   const ConvArgs& a = p3.a[blockIdx.y];
   // LDS: depthwise weights [cin][12] | pointwise weights of this cout tile [ksteps][64] | split-K buffer
   extern __shared__ float s_mem[];
@@ -437,7 +428,7 @@ __global__ __launch_bounds__(256) WPE_DWPW void k_dwpw_mfma(ConvArgs3 p3) {
 // one chunk of prefetch.  fma order per output as k_dwpw_mfma.  Needs (cin/2) % 8 == 0,
 // cts % CTW == 0.
 template <int S, int CTW>
-__global__ __launch_bounds__(256) WPE_COOP void k_dwpw_coop(ConvArgs3 p3) {
+__global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   const ConvArgs& a = p3.a[blockIdx.y];
   constexpr int PT = 4 / CTW;   // pixel tiles per block
   constexpr int CH = 8;         // k-steps per chunk

@@ -1986,6 +1986,17 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->ivs_off = (m->scans_off + sizeof(HuffScan) * B + 255) & ~(size_t)255;
   m->stage_cap = ((m->ivs_off + sizeof(HuffInterval) * m->iv_cap + 255) & ~(size_t)255) + m->blob_stride * B;
   m->gpu_entropy_enabled = (cfg->flags & UFD_FLAG_HOST_ENTROPY) == 0;
+  // The convolution kernels address a tensor with a wave-uniform base and 32-bit per-lane byte offsets: every
+  // activation tensor of a batch (and the network input) must stay below 4 GiB.
+  {
+    size_t worst = (size_t)3 * m->W * m->H;
+    for (const auto& t : m->tensors) worst = std::max(worst, t.per_frame());
+    if (worst * (size_t)B * sizeof(float) >= ((size_t)1 << 32)) {
+      m->err = "max_batch " + std::to_string(B) + " is too large for this variant: an activation tensor would reach 4 GiB (limit " +
+               std::to_string((((size_t)1 << 32) - 1) / (worst * sizeof(float))) + ")";
+      return bail(UFD_E_TOO_LARGE);
+    }
+  }
   HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];

@@ -76,6 +76,16 @@ def test_corrupt_jpeg_is_an_error_not_a_crash(model320):
     assert res[1] is None and res[0] == res[2]
 
 
+def test_create_refuses_a_batch_whose_tensors_outgrow_32_bit_offsets(weights):
+    """The convolution kernels address a tensor by a wave-uniform base + 32-bit per-lane byte offsets: a max_batch whose
+    largest activation tensor (the 640 stem's 16 x 240 x 320 floats per frame) would reach 4 GiB is refused at ufd_create."""
+    from infercam_onnx_amd import nn, synth
+
+    with pytest.raises(nn.UfdError) as e:
+        nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=synth.gen_priors(640, 480), max_batch=1000)
+    assert e.value.code == nn.UFD_E_TOO_LARGE and "4 GiB" in str(e.value)
+
+
 # ---------------------------------------------------------------- A2-A4
 @pytest.mark.parametrize("src", [(1280, 720), (640, 427), (640, 960), (320, 240), (640, 480), (100, 37), (333, 500)])
 @pytest.mark.parametrize("variant", [320, 640])
