@@ -221,3 +221,41 @@ def test_reference_pictures_infer_matches_oracle(oracle_lib, weights, variant):
             assert_dets_match(dets_array(m.infer_jpeg(j)), ref, what="%s @%d single" % (n, variant))
     finally:
         m.close()
+
+
+def test_bench_script_single_and_two_rank_rehearsal():
+    """bench.py's own contract on the box: the N=1 line carries every field the driver reads (roofline, cpu_baseline,
+    verified), and the N>1 script path under torch.distributed.run (C4's launch: one process per rank, weight broadcast,
+    barrier-bracketed timing, max over ranks, per-rank records) runs end to end.  The box has one GPU: the two ranks
+    share cuda:0 and exchange over gloo (`--rehearse-one-gpu`), so the figure is not a measurement -- RCCL itself and
+    distinct devices are the driver's 8-GPU run."""
+    import socket
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-seconds", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "verified"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 1000 and line["verified"]["max_abs_err"] < 1e-3
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--rehearse-one-gpu"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line["config"]
+    assert len(line["config"]["ranks"]) == 2 and line["config"]["global_batch"] == 64
+    assert "cpu_baseline" not in line  # N = 1 only
