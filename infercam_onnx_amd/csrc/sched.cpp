@@ -52,6 +52,7 @@ struct Batch {
   uint32_t count = 0, ticket = 0;
   int why = 0;  // 0 full, 1 deadline, 2 idle
   std::vector<uint32_t> stream;
+  std::vector<uint64_t> stream_id;  // copied at dispatch: the completion thread never touches the stream table without the lock
   std::vector<Frame*> frame;
   std::vector<const uint8_t*> ptrs;
   std::vector<size_t> lens, joff, jlen;
@@ -70,7 +71,7 @@ struct ufd_sched {
   uint32_t max_batch[2] = {0, 0};
   std::mutex mu;
   std::condition_variable cv_dispatch, cv_complete, cv_flush;
-  std::deque<Stream> streams;  // (a deque: entries never move, the completion thread reads them without the lock)
+  std::deque<Stream> streams;  // (a deque: entries never move; always accessed with the lock held)
   std::vector<Klass> klasses;
   std::deque<Batch*> inflight;             // dispatch order
   std::vector<std::unique_ptr<Batch>> pool;
@@ -133,7 +134,7 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
   s->free_batches.pop_back();
   const uint32_t count = ufd_sched_debug_plan(queued.data(), (uint32_t)queued.size(), kl.last, s->max_batch[vi], take.data());
   b->klass = k, b->count = count, b->why = why;
-  b->stream.clear(), b->frame.clear(), b->ptrs.clear(), b->lens.clear();
+  b->stream.clear(), b->stream_id.clear(), b->frame.clear(), b->ptrs.clear(), b->lens.clear();
   // frames in round-robin order too, so that a stream's frames keep their order and streams share the head of the batch
   std::vector<uint32_t> left = take;
   const uint32_t start = kl.last;
@@ -150,6 +151,7 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
       st.in_batches++;
       left[i]--, any = true;
       b->stream.push_back(kl.streams[i]);
+      b->stream_id.push_back(st.cfg.stream_id);
       b->frame.push_back(f);
       b->ptrs.push_back(f->jpeg.data());
       b->lens.push_back(f->jpeg.size());
@@ -229,7 +231,10 @@ void completer_main(ufd_sched* s) {
     s->cv_complete.wait(lk, [&] { return !s->inflight.empty() || s->dispatcher_done; });
     if (s->inflight.empty()) break;  // the dispatcher has left and nothing is in flight
     Batch* b = s->inflight.front();
-    const Klass kl = s->klasses[b->klass];
+    struct {
+      ufd_model* model;
+      uint32_t variant, annotate;
+    } kl = {s->klasses[b->klass].model, s->klasses[b->klass].variant, s->klasses[b->klass].annotate};
     lk.unlock();
     if (b->ticket) {
       const int rc = ufd_wait(kl.model, b->ticket);
@@ -242,8 +247,7 @@ void completer_main(ufd_sched* s) {
       for (uint32_t i = 0; i < b->count; i++) {
         ufd_frame_result r;
         std::memset(&r, 0, sizeof(r));
-        // (stream table entries are stable: removed streams keep their slot until the scheduler is destroyed)
-        r.stream_id = s->streams[b->stream[i]].cfg.stream_id;
+        r.stream_id = b->stream_id[i];
         r.tag = b->frame[i]->tag;
         r.status = b->status[i];
         r.variant = kl.variant;
