@@ -89,12 +89,17 @@ __device__ __forceinline__ bool remap_block(const ConvArgs& a, int* tile, int* c
 
 template <int CT>
 __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half) {
+  // (pointer and bound pinned in scalar registers: left to itself the compiler re-reads them from the kernel arguments
+  // inside each of the 16 conditional blocks, a scalar-memory round trip apiece)
+  const float* bias = a.bias;
+  int cout = a.cout;
+  asm volatile("" : "+s"(bias), "+s"(cout));
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float b = co < a.cout ? a.bias[co] : 0.0f;
+      const float b = co < cout ? bias[co] : 0.0f;
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[ct][j][r] = b;
     }
@@ -1036,14 +1041,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs3 p3) {
 // the difference is fp32 rounding, ~1e-7 relative).
 // a.w: packed [ceil(cin/4)][9][64] (lane l: W[l&15][4*kc + (l>>4)][tap], zero padded).
 template <int S, int DIL>
-__global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];  // merged launches: same shapes, blockIdx.y selects the conv
+__device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   const int dil = DIL == 0 ? a.dil : DIL;
-  // DIL = 0: the dilation is a.dil (<= 8) of the selected conv -- merged launches of convs that differ
-  // in dilation only; two halo lanes and run-time tap offsets instead of compile-time ones
+  // DIL = 0: the dilation is a.dil (<= 8) at run time: two halo lanes and run-time tap offsets instead of compile-time ones
   constexpr int HL = (S == 1) ? (DIL == 0 ? 2 : (DIL + 3) / 4) : 1;  // halo lanes on each side of a quad
   constexpr int NG = 16 - 2 * HL;                   // output pixel groups per wave tile
   extern __shared__ float s_w[];                    // packed weights when they fit (a.dbg = 1)
+  // (a merged launch is sized for the widest halo among its convs: blocks past this conv's last tile leave, whole
+  // blocks and before the barrier)
+  if ((long)blockIdx.x * 4 * NG - HL >= (long)a.B * ((a.oh * a.ow) >> 2)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   const int cin4 = (a.cin + 3) >> 2;
@@ -1164,6 +1170,25 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
       if (a.relu) v = relu4(v);
       *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = v;
     }
+  }
+}
+
+// Merged launches (blockIdx.y selects the conv; same shapes, possibly different dilations -- the RFB's three dilated
+// 3x3 convs): DIL = 0 dispatches, per block, to the body compiled for the conv's dilation (compile-time tap offsets:
+// a register pick or one shuffle per tap, where the run-time form pays three selects and an LDS-pipe permute per tap).
+template <int S, int DIL>
+__global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
+  const ConvArgs& a = p3.a[blockIdx.y];
+  if (DIL != 0) {
+    conv3x3_rows_body<S, DIL>(a);
+    return;
+  }
+  switch (a.dil) {
+    case 1: conv3x3_rows_body<S, 1>(a); break;
+    case 2: conv3x3_rows_body<S, 2>(a); break;
+    case 3: conv3x3_rows_body<S, 3>(a); break;
+    case 5: conv3x3_rows_body<S, 5>(a); break;
+    default: conv3x3_rows_body<S, 0>(a); break;
   }
 }
 
