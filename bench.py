@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+ROOF_STEPS = 48             # steps of the fully sampled roofline pass (every launch of every kernel timed)
 
 # bench kernel label -> device function name (as rocprofv3 --kernel-trace --stats prints it)
 KERNEL_FUNCS = {
@@ -55,8 +56,20 @@ MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_
                 "conv3x3_rows_mfma")
 
 
+def base_label(key):
+    """'conv_dwpw2_mfma<16, 1, true>' -> 'conv_dwpw2_mfma' (the library labels a launch with its template instance)."""
+    return key.split("<")[0]
+
+
+def device_name(key):
+    """Device function name of a profiled label, template arguments included, as rocprofv3's kernel_stats.csv prints it."""
+    b = base_label(key)
+    return KERNEL_FUNCS.get(b, b) + key[len(b):]
+
+
 def stage_of(label):
     """Stage of SURVEY 8(d)'s breakdown a profiled kernel label belongs to."""
+    label = base_label(label)
     if label.startswith("h2d_"):
         return "h2d"
     if label.startswith("host_"):
@@ -314,6 +327,24 @@ def main():
     extras = {}
     if args.annotate:
         args.no_extras = True
+    if not args.no_extras:
+        # ---- steady state: the same workload, >= 200 more steps behind the timed region (a 20-step sample holds one
+        # pipeline fill and one drain in 15 ms; this figure does not)
+        k_ss = max(200, args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(k_ss, primary_staged)
+        torch.cuda.synchronize()
+        extras["steady_state"] = {"fps": round(B * k_ss / (time.perf_counter() - t1), 1), "steps": k_ss,
+                                  "what": "this rank, same submit/wait loop as the timed region, run right behind it"}
+        # ---- roofline pass: the pipeline loaded exactly as in the timed region (depth batches in flight over the
+        # contexts), EVERY launch of every kernel timed with HIP events on the library's own streams
+        model.profile_sampling(1)
+        run_steps(6, primary_staged)
+        model.profile_reset()
+        run_steps(ROOF_STEPS, primary_staged)
+        extras["kernel_stats_loaded"] = model.profile_read()
+        model.profile_sampling(1 << 30)
     if world == 1 and not args.no_extras:
         # ---- the same workload over the other boundary
         if device_entropy:
@@ -327,14 +358,14 @@ def main():
         # ---- stage breakdown: device time per batch, every kernel timed (HIP events on the library's
         # streams), with the pipeline loaded (depth batches in flight over the contexts) and alone (one batch in flight)
         sb = {}
-        for name, depth, k in (("loaded", args.depth, 24), ("alone", 1, 12)):
-            model.profile_sampling(1)
-            run_steps(3, primary_staged, depth=depth)
-            model.profile_reset()
-            run_steps(k, primary_staged, depth=depth)
-            st_run = model.profile_read()
-            extras["kernel_stats_" + name] = st_run
-            for stg, ms in stage_ms(st_run, k).items():
+        for name, depth, k in (("loaded", args.depth, ROOF_STEPS), ("alone", 1, 12)):
+            if name == "alone":
+                model.profile_sampling(1)
+                run_steps(3, primary_staged, depth=depth)
+                model.profile_reset()
+                run_steps(k, primary_staged, depth=depth)
+                extras["kernel_stats_alone"] = model.profile_read()
+            for stg, ms in stage_ms(extras["kernel_stats_" + name], k).items():
                 sb.setdefault(stg, {})[name + "_ms"] = round(ms, 4)
         extras["stages"] = sb
         model.profile_sampling(1 << 30)
@@ -410,45 +441,74 @@ def main():
 
     if rank == 0:
         frames = world * B * args.steps
-        # ---- roofline of the dominant kernel (device time from HIP events on the library's streams,
-        # sampled over the timed region)
-        agg = aggregate(stats)
+        # ---- roofline of the dominant kernel INSTANCE: device time from HIP events on the library's streams.  Source:
+        # the fully sampled loaded pass (ROOF_STEPS steps behind the timed region, same pipeline depth, every launch
+        # timed) -- the timed region itself is only sampled every --profile-every-th step so that the event packets stay
+        # out of `value`; its (few) launches are kept beside it as `timed_region_sample`.
+        loaded = extras.get("kernel_stats_loaded")
+        agg = aggregate(loaded if loaded else stats)
+        agg_timed = aggregate(stats)
         kern = {k: v for k, v in agg.items() if not k.startswith(("h2d_", "host_"))}
+        pmc, pmc_ok = {}, False
+        try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            pmc_ok = pmc.get("kernel_source_sha") == kernel_source_sha()
+        except Exception:
+            pass
+
+        def roof_of(key, d):
+            """Roofline figures of one kernel instance from its aggregated launches."""
+            sec = d["ms"] * 1e-3
+            n = max(d["launches"], 1)
+            gbs = d["bytes"] / sec / 1e9 if sec > 0 else 0.0
+            tfl = d["flops"] / sec / 1e12 if sec > 0 else 0.0
+            r = {"kernel": device_name(key), "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / n, 2),
+                 "algorithmic_bytes_per_launch": round(d["bytes"] / n), "algorithmic_flops_per_launch": round(d["flops"] / n),
+                 "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+            # (the roof the kernel sits closer to; on gfx950 fp32 MFMA and fp32 vector work share one datapath, DESIGN.md section 4)
+            if base_label(key) in MFMA_KERNELS and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+                r.update({"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)})
+            else:
+                r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            t = None
+            if pmc_ok:
+                e = pmc.get("instances", {}).get(device_name(key)) or pmc.get("kernels", {}).get(device_name(base_label(key)))
+                if e:
+                    t = round(e["hbm_bytes_per_launch"])
+            r["traffic"] = t
+            r["traffic_ratio"] = round(t / (d["bytes"] / n), 3) if t and d["bytes"] else None
+            return r
+
         roof = None
         if kern:
-            dom = max(kern, key=lambda k: kern[k]["ms"])
-            d = kern[dom]
-            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-            tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            # (the roof the kernel sits closer to; on gfx950 fp32 MFMA and fp32 vector work share one datapath)
-            if dom in MFMA_KERNELS and tfl / MFMA_F32_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
-                roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
-            else:
-                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4)}
-            traffic, traffic_src = None, "not measured for this build of the kernels (tools/collect_profiles.sh refreshes it)"
-            try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-                if pmc.get("kernel_source_sha") == kernel_source_sha():
-                    traffic = round(pmc["kernels"][KERNEL_FUNCS.get(dom, dom)]["hbm_bytes_per_launch"])
-                    traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) at commit %s, same kernel sources" % pmc.get("commit", "?")
-            except Exception:
-                pass
-            per_launch = d["bytes"] / max(d["launches"], 1)
+            # the kernel FUNCTION with the largest share of device time, then its heaviest template instance
+            fam_ms = {}
+            for k, v in kern.items():
+                fam_ms[base_label(k)] = fam_ms.get(base_label(k), 0.0) + v["ms"]
+            fam = max(fam_ms, key=fam_ms.get)
+            dom = max((k for k in kern if base_label(k) == fam), key=lambda k: kern[k]["ms"])
+            roof = roof_of(dom, kern[dom])
+            roof["source"] = ("loaded pass: %d steps behind the timed region, %d batches in flight, every launch timed (HIP events on "
+                              "the library's streams)" % (ROOF_STEPS, min(args.depth, nb))) if loaded else \
+                             "timed region, every %d-th step sampled" % args.profile_every
+            roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, FETCH x2 on gfx950) at commit %s, "
+                                      "same kernel sources, per template instance" % pmc.get("commit", "?")) if pmc_ok else \
+                                     "not measured for this build of the kernels (tools/collect_profiles.sh refreshes it)"
+            # every template instance of the same kernel function, each with its own flops / bytes / traffic
+            roof["instances"] = [roof_of(k, v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]) if base_label(k) == fam]
             alone = aggregate(extras.get("kernel_stats_alone", [])).get(dom)
-            if alone and alone["ms"] > 0:  # the same kernel with one batch in flight (nothing else on the GPU)
-                a_tfl = alone["flops"] / (alone["ms"] * 1e-3) / 1e12
-                a_gbs = alone["bytes"] / (alone["ms"] * 1e-3) / 1e9
-                roof["alone"] = {"avg_launch_us": round(alone["ms"] * 1e3 / max(alone["launches"], 1), 2), "launches": alone["launches"],
-                                 "mfma_frac": round(a_tfl / MFMA_F32_PEAK_TFLOPS, 4), "hbm_frac": round(a_gbs / HBM_PEAK_GBS, 4),
-                                 "what": "one batch in flight: the kernel has the GPU to itself; `frac` above is with six batches in "
-                                         "flight over three contexts, whose kernels share the GPU"}
-            roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(per_launch),
-                         "algorithmic_flops_per_launch": round(d["flops"] / max(d["launches"], 1)),
-                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
-                         "kernel": KERNEL_FUNCS.get(dom, dom),
-                         "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": d["launches"]})
+            if alone and alone["ms"] > 0:  # the same instance with one batch in flight (nothing else on the GPU)
+                a = roof_of(dom, alone)
+                roof["alone"] = {"avg_launch_us": a["avg_launch_us"], "launches": a["launches"], "mfma_frac": a["mfma_frac"],
+                                 "hbm_frac": a["hbm_frac"],
+                                 "what": "one batch in flight: the kernel has the GPU to itself; `frac` above is with %d batches in "
+                                         "flight over three contexts, whose kernels share the GPU" % min(args.depth, nb)}
+            tsamp = agg_timed.get(dom)
+            if loaded and tsamp and tsamp["ms"] > 0:
+                roof["timed_region_sample"] = {"launches": tsamp["launches"],
+                                               "avg_launch_us": round(tsamp["ms"] * 1e3 / max(tsamp["launches"], 1), 2)}
         flops_frame = 798315520 if args.variant == 640 else 200837120  # SURVEY 8(d): 2 x MACs of the 52 convs
         out = {
             "metric": ("frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, W, H)) if not args.annotate else
@@ -474,6 +534,9 @@ def main():
         if args.rehearse_one_gpu and world > 1:
             out["config"]["rehearsal"] = "all %d ranks shared cuda:0 and exchanged over gloo: a run of the N>1 script path, NOT a measurement" % world
         out["config"].update({k: v for k, v in extras.items() if k.endswith("_fps")})
+        if "steady_state" in extras:
+            out["steady_state_fps"] = extras["steady_state"]["fps"]
+            out["steady_state"] = extras["steady_state"]
         if "stages" in extras:
             out["stages"] = extras["stages"]
         if "latency_ms_batch1" in extras:
@@ -482,10 +545,11 @@ def main():
             out["annotate"] = extras["annotate"]
         if verified is not None:
             out["verified"] = verified
-        if prof_steps:
+        ksteps = ROOF_STEPS if loaded else prof_steps
+        if ksteps:
             gpu_ms = sum(v["ms"] for v in kern.values())
-            out["gpu_ms_per_step"] = round(gpu_ms / prof_steps, 3)
-            out["kernels_ms_per_step"] = {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+            out["gpu_ms_per_step"] = round(gpu_ms / ksteps, 3)
+            out["kernels_ms_per_step"] = {k: round(v["ms"] / ksteps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         dump = os.environ.get("UFD_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:

@@ -1529,6 +1529,18 @@ void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
     hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid, n), dim3(256), wlds, s, p);
 }
 
+// Template instance the launchers above / below pick for a launch, as rocprofv3 prints it behind the kernel name
+// (bench.py reports the roofline per instance and checks it against profiles/<round>/kernel_stats.csv).
+const char* conv_pointwise_instance(const ConvArgs* args, int n) {
+  const ConvArgs& r = args[0];
+  const long groups = (long)r.B * (r.oh * r.ow / 4);
+  const int ksteps = r.cin >> 1;
+  int max_cts = 1;
+  for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
+  if (want_splitk((groups + 31) / 32, max_cts * n, ksteps)) return "<1, 4, 4>";
+  return ksteps % 4 == 0 ? "<1, 4, 1>" : "<1, 1, 1>";
+}
+
 bool dwpw_uses_coop(const ConvArgs* args, int n) {
   // (4 cout tiles per block; the 2-tile form measured slower than k_dwpw_mfma)
   const int cts = (args[0].cout + 31) / 32, ksteps = args[0].cin >> 1;
@@ -1585,6 +1597,25 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     if (deep) launch(k_dwpw_mfma<1, 2, 2, 1>, lds);
     else launch(k_dwpw_mfma<1, 2, 1, 1>, lds);
   }
+}
+
+const char* conv_dwpw_instance(const ConvArgs* args, int n, int stride) {
+  const ConvArgs& r = args[0];
+  const long groups = (long)r.B * (r.oh * r.ow / 4);
+  const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
+  const int ksteps = r.cin >> 1;
+  int max_cts = 1;
+  for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
+  if (dwpw_uses_coop(args, n)) return stride == 1 ? (max_cts % 4 == 0 ? "<1, 4>" : "<1, 2>") : (max_cts % 4 == 0 ? "<2, 4>" : "<2, 2>");
+  if (want_splitk(wave_tiles, max_cts * n, ksteps)) return stride == 1 ? "<1, 1, 2, 4>" : "<1, 2, 2, 4>";
+  const bool deep = ksteps % 4 == 0;
+  return stride == 1 ? (deep ? "<1, 1, 2, 1>" : "<1, 1, 1, 1>") : (deep ? "<1, 2, 2, 1>" : "<1, 2, 1, 1>");
+}
+
+const char* conv_dwpw2_instance(const ConvArgs& first, const ConvArgs& second) {
+  const int ct2 = (second.cout + 31) / 32;
+  if (first.cin == 16) return ct2 == 1 ? "<16, 1, true>" : "<16, 2, true>";
+  return ct2 == 1 ? "<32, 1, false>" : "<32, 2, false>";
 }
 
 bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {

@@ -168,6 +168,10 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
 size_t depthwise_packed_floats(int c);
 void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c, float* packed /*[c][12]*/);
 void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);
+// Template arguments of the kernel instance those launchers pick, as rocprofv3 prints them ("<16, 1, true>"): profiling labels.
+const char* conv_pointwise_instance(const ConvArgs* a, int n);
+const char* conv_dwpw_instance(const ConvArgs* a, int n, int stride);
+const char* conv_dwpw2_instance(const ConvArgs& first, const ConvArgs& second);
 // Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
 void launch_conv3x3_mfma(const ConvArgs* a, int n, hipStream_t s);
 // Row variant (16-byte row loads + cross-lane shuffles instead of per-tap gathers).

@@ -992,7 +992,8 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
     const Layer& F = m->layers[L.chain_first];
     const ConvArgs first = layer_args(m, L.chain_first, f0, count, &s1);
     const ConvArgs second = layer_args(m, i, f0, count, &s2);
-    ProfScope ps(m, std::string("conv_dwpw2_mfma:") + F.spec.name + "+" + L.spec.name, L.bytes_per_frame * count + L.weight_bytes,
+    ProfScope ps(m, std::string("conv_dwpw2_mfma") + conv_dwpw2_instance(first, second) + ":" + F.spec.name + "+" + L.spec.name,
+                 L.bytes_per_frame * count + L.weight_bytes,
                  L.flops_per_frame * count, st);
     launch_conv_dwpw2_mfma(first, second, st);
     return;
@@ -1024,7 +1025,8 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
     case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
     case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
-  ProfScope ps(m, std::string(kind) + ":" + names, bytes, flops, st);
+  const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n) : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : "");
+  ProfScope ps(m, std::string(kind) + inst + ":" + names, bytes, flops, st);
   switch (L.kind) {
     case kKindPointwise: launch_conv_pointwise_mfma(args, n, st); break;
     case kKindDwPw: launch_conv_dwpw_mfma(args, n, dw_stride, st); break;

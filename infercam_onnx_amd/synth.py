@@ -106,6 +106,24 @@ def encode_jpeg(rgb, quality=90, subsampling="4:2:0", restart_rows=0, progressiv
     return bio.getvalue()
 
 
+def strip_dht(jpeg):
+    """The same stream without its DHT segments: what a UVC camera's MJPG frame looks like (the tables
+    are then the Annex-K defaults, which PIL / libjpeg-turbo also wrote into a non-optimised stream)."""
+    out, i = bytearray(jpeg[:2]), 2
+    while i + 4 <= len(jpeg):
+        if jpeg[i] != 0xFF:
+            raise ValueError("not at a marker")
+        marker = jpeg[i + 1]
+        if marker == 0xDA:  # SOS: entropy-coded data follows, copy the rest
+            out += jpeg[i:]
+            return bytes(out)
+        seg = 2 + ((jpeg[i + 2] << 8) | jpeg[i + 3])
+        if marker != 0xC4:
+            out += jpeg[i:i + seg]
+        i += seg
+    raise ValueError("no SOS marker")
+
+
 def synth_jpeg_pool(stream_id, count, width, height, quality=90, subsampling="4:2:0", restart_rows=0):
     """Pool of `count` distinct frames for one camera stream (seed 0x5EED0000 + stream_id)."""
     seed = DEFAULT_FRAME_SEED + int(stream_id)

@@ -60,6 +60,17 @@ static int max_taps(int S, int D) {
   return (int)ceilf(2.0f * sratio) + 3;
 }
 
+/* The window of output index o (tests check it against an exact-rational derivation): first source
+ * index, tap count and the normalised f32 weights exactly as the two passes below use them. */
+int ufo_axis_taps(int S, int D, int o, int* left, int* n, float* w, int cap) {
+  if (S <= 0 || D <= 0 || o < 0 || o >= D || !left || !n || !w || cap < max_taps(S, D)) return UFO_E_ARG;
+  taps_t t;
+  axis_taps(S, D, o, &t, w);
+  *left = t.left;
+  *n = t.n;
+  return UFO_OK;
+}
+
 int ufo_resize_triangle_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
   if (!src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return UFO_E_ARG;
   if (sw == dw && sh == dh) { /* image 0.24.5 resize(): same dimensions -> plain copy */

@@ -51,6 +51,7 @@ def lib():
         L.ufo_jpeg_probe.argtypes = [vp, sz, ctypes.POINTER(JpegInfo)]
         L.ufo_jpeg_decode_rgb.argtypes = [vp, sz, vp, c_int, c_int]
         L.ufo_resize_triangle_rgb.argtypes = [vp, c_int, c_int, vp, c_int, c_int]
+        L.ufo_axis_taps.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), vp, c_int]
         L.ufo_normalize_nchw.argtypes = [vp, c_int, c_int, vp]
         L.ufo_normalize_nchw.restype = None
         L.ufo_conv_specs.restype = ctypes.POINTER(ConvSpec)
@@ -128,6 +129,15 @@ def resize_triangle(rgb, dw, dh):
     out = np.empty((dh, dw, 3), np.uint8)
     _chk(lib().ufo_resize_triangle_rgb(rgb.ctypes.data, sw, sh, out.ctypes.data, dw, dh), "resize")
     return out
+
+
+def axis_taps(S, D, o):
+    """A3: (first source index, normalised f32 weights) of output index o along an axis of S -> D samples."""
+    cap = int(np.ceil(2.0 * max(S / D, 1.0))) + 8
+    w = np.zeros(cap, np.float32)
+    left, n = ctypes.c_int(), ctypes.c_int()
+    _chk(lib().ufo_axis_taps(S, D, o, ctypes.byref(left), ctypes.byref(n), w.ctypes.data, cap), "axis_taps")
+    return left.value, w[:n.value].copy()
 
 
 def normalize_nchw(rgb):

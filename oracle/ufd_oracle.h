@@ -58,6 +58,8 @@ int ufo_jpeg_coefficients(const uint8_t* data, size_t len, int16_t* coef, size_t
 /* ---- A2/A3: image::imageops::resize(.., FilterType::Triangle)  (nn.rs:74-80) ---- */
 /* src: sh x sw x 3 u8 (pitch 3*sw), dst: dh x dw x 3 u8 */
 int ufo_resize_triangle_rgb(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+/* window of output index o along an axis S -> D as the resampler uses it (cap >= ceil(2*max(S/D,1)) + 3 floats) */
+int ufo_axis_taps(int S, int D, int o, int* left, int* n, float* w, int cap);
 
 /* ---- A4: normalize closure (nn.rs:82-93): HWC u8 -> NCHW f32 [3][h][w] ---- */
 void ufo_normalize_nchw(const uint8_t* rgb, int w, int h, float* out);

@@ -34,3 +34,11 @@ def pytest_terminal_summary(terminalreporter):
         return
     terminalreporter.write_line("assert_dets_match: borderline excuse fired for %d detections in %d frames" %
                                 (EXCUSED["detections"], EXCUSED["frames"]))
+    from helpers import REFERENCE_PINS
+
+    for k, v in sorted(REFERENCE_PINS.items()):
+        # (the only results the reference's own tests pin need the zoo .onnx files, a run-time download: nn.rs:21-22,155-162)
+        terminalreporter.write_line("reference pin %s: %s" % (k, v))
+    if any(v.startswith("NOT CHECKED") for v in REFERENCE_PINS.values()):
+        terminalreporter.write_line("WARNING: the reference's face counts (integration_tests.rs:20-29: 3,6,4,3,1,1,10,0) were NOT "
+                                    "checked in this session -- parity with the reference itself stays unpinned")

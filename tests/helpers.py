@@ -62,6 +62,10 @@ def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-
 EXCUSED = {"frames": 0, "detections": 0}
 
 
+# what the reference itself pins (integration_tests.rs:20-35) and whether this session could check it (printed by conftest)
+REFERENCE_PINS = {}
+
+
 def dets_from_ctypes(out, cnt, cap, i):
     """Frame i of a UfdDet array laid out [count][cap] -> [n,5] f32 without per-element ctypes access."""
     n = min(int(cnt[i]), cap)

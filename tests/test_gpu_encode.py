@@ -87,6 +87,46 @@ def test_rectangles_and_labels_equal_the_oracle(model320):
     assert np.array_equal(model320.debug_draw_labels(rgb, np.zeros((0, 5), np.float32), (320, 240)), rgb)
 
 
+def test_product_label_glyphs_agree_with_freetype(model320):
+    """The label coverage table compiled into the PRODUCT (csrc/glyph_atlas.inc; restated from rusttype /
+    ab_glyph_rasterizer, parity with those crates unpinned -- DESIGN.md section 2) drawn by the GPU on a black frame,
+    against FreeType (PIL) rendering the same strings of inferer.rs:80-88 at the same origin and scale: ink bounding
+    box within one pixel per side, total ink within 12 %, correlation > 0.8 -- so a regenerated table cannot drift
+    silently.  (UFD_ANNOT_NO_TEXT stays the mode whose pixels are exact.)"""
+    from PIL import Image, ImageDraw, ImageFont
+
+    path = "/usr/share/fonts/truetype/dejavu/DejaVuSansMono.ttf"
+    if not os.path.exists(path):
+        pytest.skip("no DejaVuSansMono on this box")
+    font = ImageFont.truetype(path, 16 * 2048 / 2384)  # Scale 16 = ascent - descent = 2384 units of a 2048-unit em
+    W, H, x0, y0 = 160, 64, 20, 12
+    black = np.zeros((H, W, 3), np.uint8)
+    seen = set()
+    for conf in (0.1234, 0.5678, 0.9012, 0.3456, 0.7899, 1.0, 0.0705):
+        text = oracle.label_text(np.float32(conf))
+        seen |= set(text)
+        det = np.array([[x0 / W, y0 / H, 0.95, 0.95, conf]], np.float32)
+        with_text = model320.debug_draw_labels(black, det, (W, H)).astype(np.float32)
+        rect_only = model320.debug_draw_labels(black, det, (W, H), text=False).astype(np.float32)
+        cov = (with_text - rect_only)[:, :, 1] / 255.0  # colour (0, 255, 0) blended over black: green = 255 * coverage
+        assert (with_text[:, :, 0] == 0).all() and (with_text[:, :, 2] == 0).all()
+        im = Image.new("L", (W, H), 0)
+        ImageDraw.Draw(im).text((x0, y0), text, fill=255, font=font)
+        ft = np.asarray(im, np.float32) / 255.0
+        for a in (cov, ft):  # the rectangle's own top row / left column are already green: not comparable
+            a[y0, :] = 0
+            a[:, x0] = 0
+
+        def ink_box(a):
+            ys, xs = np.nonzero(a > 0.25)
+            return np.array([xs.min(), ys.min(), xs.max(), ys.max()])
+
+        assert np.abs(ink_box(cov) - ink_box(ft)).max() <= 1, (text, ink_box(cov), ink_box(ft))
+        assert abs(cov.sum() - ft.sum()) <= 0.12 * ft.sum(), (text, cov.sum(), ft.sum())
+        assert np.corrcoef(cov.ravel(), ft.ravel())[0, 1] > 0.8, text
+    assert seen == set("0123456789.%")
+
+
 def test_many_overlapping_labels_keep_the_reference_order(model320):
     """Hundreds of detections piled on the same spot (more than one 256-operation pass of the tile kernel): every pixel
     must see rectangles and label blends in detection order."""

@@ -26,20 +26,52 @@ def test_cpp_integration_test(tmp_path, weights):
     assert out.stdout.strip().endswith("ok") and out.stdout.count("faces=") == 8
 
 
+def _real_model_path(variant):
+    return os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.expanduser("~/.cache")), "infercam_onnx",
+                        "ultraface-RFB-%d.onnx" % variant)
+
+
 def test_reference_face_counts_if_real_model_present(oracle_lib):
     """integration_tests.rs:20-35 proper: only runs when the real ONNX file is in the cache path."""
     import json
     from infercam_onnx_amd import nn
+    from helpers import REFERENCE_PINS
 
-    path = os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.expanduser("~/.cache")), "infercam_onnx",
-                        "ultraface-RFB-640.onnx")
+    path = _real_model_path(640)
     if not os.path.exists(path):
+        REFERENCE_PINS["face_counts_640"] = "NOT CHECKED (%s absent)" % path
         pytest.skip("real UltraFace weights not available offline (reference downloads them, nn.rs:155-162)")
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "test_pics.json")))
     with nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights_path=path, max_src=(1280, 1024)) as m:
         for f, info in meta.items():
             jpeg = open(os.path.join(ROOT, "tests", "golden", "test_pics", f), "rb").read()
             assert len(m.infer_jpeg(jpeg)) == info["reference_face_count"], f
+    REFERENCE_PINS["face_counts_640"] = "checked: 8 pictures"
+
+
+def test_real_320_model_loads_and_agrees_with_the_oracle_if_present(oracle_lib):
+    """The server's own operating point (inferer.rs:23: W320H240, 0.5, 0.5) on the zoo file version-RFB-320.onnx: the
+    reference pins no result for it, so when the file is there the GPU path is compared with the oracle running the
+    SAME file's weights on the reference's 8 pictures.  Skipped (and reported) when the file is absent."""
+    import json
+    from infercam_onnx_amd import nn
+    from helpers import REFERENCE_PINS
+
+    path = _real_model_path(320)
+    if not os.path.exists(path):
+        REFERENCE_PINS["zoo_weights_320"] = "NOT CHECKED (%s absent)" % path
+        pytest.skip("real UltraFace-320 weights not available offline (nn.rs:21-22)")
+    from infercam_onnx_amd import synth
+
+    w, pri = nn.load_onnx(path, 320)
+    pri = pri if pri is not None else synth.gen_priors(320, 240)
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "test_pics.json")))
+    with nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights_path=path, max_src=(1280, 1024)) as m:
+        for f in meta:
+            jpeg = open(os.path.join(ROOT, "tests", "golden", "test_pics", f), "rb").read()
+            ref = oracle_lib.infer_jpeg(jpeg, 320, 240, w, pri, 0.5, 0.5)
+            assert_dets_match(dets_array(m.infer_jpeg(jpeg)), ref, what=f)
+    REFERENCE_PINS["zoo_weights_320"] = "checked against the oracle on 8 pictures"
 
 
 def test_inferer_loop(oracle_lib, weights):

@@ -52,3 +52,23 @@ def test_corrupt_streams_are_errors(oracle_lib):
     for bad in (jpeg[:200], jpeg[:-2], b"\xff\xd8\xff", b"", b"not a jpeg at all"):
         with pytest.raises(oracle_lib.OracleError):
             oracle_lib.jpeg_decode_rgb(bad)
+
+
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:2:2"])
+def test_mjpg_without_dht(oracle_lib, subsampling):
+    """camera MJPG may omit DHT => the Annex-K default tables.  A non-optimised PIL stream carries exactly
+    those tables; without its DHT segments (a) libjpeg-turbo itself (PIL), (b) the oracle and (c) the product's host
+    entropy decoder must all give what the ORIGINAL stream gives (identical tables => identical pixels / coefficients)."""
+    from PIL import Image
+    from infercam_onnx_amd import nn, synth
+
+    for kw in ({}, {"restart_rows": 1}):
+        jpeg = synth.encode_jpeg(synth.synth_frame(9, 4, 320, 240), subsampling=subsampling, **kw)
+        bare = synth.strip_dht(jpeg)
+        assert len(bare) < len(jpeg) and b"\xff\xc4" not in bare[:bare.index(b"\xff\xda")]
+        ref = np.asarray(Image.open(io.BytesIO(jpeg)).convert("RGB"))
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(bare)).convert("RGB")), ref)  # libjpeg-turbo's own default tables
+        assert np.array_equal(oracle_lib.jpeg_decode_rgb(bare), ref)
+        c0, w0, h0 = nn.jpeg_coefficients(jpeg)
+        c1, w1, h1 = nn.jpeg_coefficients(bare)
+        assert (w0, h0) == (w1, h1) == (320, 240) and np.array_equal(c0, c1)

@@ -102,3 +102,55 @@ def test_normalize_closure(oracle_lib):
     std = np.array([0.229, 0.224, 0.225], np.float32)
     ref = ((rgb.astype(np.float32) / np.float32(255.0) - mean) / std).transpose(2, 0, 1)
     assert got.shape == (3, 16, 16) and np.array_equal(got, ref.astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# Exact-rational derivation of the Triangle windows, independent of the float32 numpy
+# twin above: the window formula evaluated with Python fractions, then rounded ONCE to float32.
+def exact_axis_window(S, D, o):
+    from fractions import Fraction as F
+
+    ratio = F(S, D)
+    sratio = max(ratio, F(1))
+    c = (F(o) + F(1, 2)) * ratio
+    import math
+
+    left = min(max(math.floor(c - sratio), 0), S - 1)
+    right = min(max(math.ceil(c + sratio), left + 1), S)
+    c = c - F(1, 2)
+    w = [max(F(0), F(1) - abs((F(i) - c) / sratio)) for i in range(left, right)]
+    tot = sum(w)
+    return left, [x / tot for x in w]
+
+
+# every axis of the seven source sizes x two model sizes of tests/test_gpu_parity.py::test_preproc_bit_exact
+AXES = sorted({(s, d) for s in (1280, 640, 320, 100, 333) for d in (320, 640)} |
+              {(s, d) for s in (720, 427, 960, 240, 480, 37, 500) for d in (240, 480)})
+
+
+@pytest.mark.parametrize("S,D", AXES)
+def test_oracle_windows_are_the_rounded_exact_rational_ones(oracle_lib, S, D):
+    """The oracle's f32 weights (image 0.24.5 computes them in f32 too) against the exact rational weights, as a
+    function over the source axis.  The f32 evaluation carries the rounding of `ratio` and of the centre
+    c = (o + 0.5) * ratio, i.e. an absolute error of about ulp(c) <= S * 2^-23 in (i - c), divided by sratio: the
+    bound asserted is 2 * 2^-23 * (2 + S / sratio) absolute (37 -> 240: 9e-6, i.e. 0.002 grey levels).  The weights
+    sum to 1 within 2^-21, and where every quantity is dyadic (ratios 2 and 4) they are the exact values bit for bit."""
+    dyadic = (S % D == 0) and ((S // D) & ((S // D) - 1)) == 0 and S != D
+    worst = 0.0
+    for o in range(D):
+        left, w = oracle_lib.axis_taps(S, D, o)
+        eleft, ew = exact_axis_window(S, D, o)
+        dense = np.zeros(S, np.float64)
+        dense[left:left + len(w)] = w
+        edense = np.zeros(S, np.float64)
+        edense[eleft:eleft + len(ew)] = [float(x) for x in ew]
+        if S == D:  # image's resize() copies same-size images; the window degenerates to the pixel itself
+            assert np.count_nonzero(dense) == 1 and dense[o] == 1.0
+            continue
+        worst = max(worst, np.abs(dense - edense).max())
+        assert abs(float(np.sum(w, dtype=np.float64)) - 1.0) <= 2.0 ** -21
+        if dyadic:
+            assert left == eleft or dense[min(left, eleft):max(left, eleft)].sum() == 0
+            assert np.array_equal(dense.astype(np.float32), edense.astype(np.float32)), (S, D, o)
+    tol = 2.0 * 2.0 ** -23 * (2.0 + S / max(S / D, 1.0))
+    assert worst <= tol, "S=%d D=%d: %.3g from the exact rational window (bound %.3g)" % (S, D, worst, tol)
