@@ -295,15 +295,19 @@ def main():
 
     # ---- per-rank record: which device each rank ran on and what it did alone
     props = torch.cuda.get_device_properties(local_rank)
+    place = model.placement()  # NUMA node of the GPU and the CPUs the handle's host threads are pinned to
     mine = torch.tensor([rank, local_rank, B * args.steps / el_local, getattr(props, "pci_bus_id", -1),
-                         getattr(props, "pci_device_id", -1)], dtype=torch.float64, device=xdev if dist is not None else dev)
+                         getattr(props, "pci_device_id", -1), place["numa_node"], place["pinned_cpus"]],
+                        dtype=torch.float64, device=xdev if dist is not None else dev)
     if dist is not None:
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
     else:
         allr = [mine]
     ranks = [{"rank": int(t[0]), "local_rank": int(t[1]), "fps": round(float(t[2]), 1),
-              "pci": "%02x:%02x" % (int(t[3]), int(t[4]))} for t in (x.cpu() for x in allr)]
+              "pci": "%02x:%02x" % (int(t[3]), int(t[4])), "numa_node": int(t[5]), "pinned_cpus": int(t[6])}
+             for t in (x.cpu() for x in allr)]
+    ranks[rank]["cpu_list"] = place["cpu_list"]
     if dist is not None and not args.rehearse_one_gpu:
         assert len({r["pci"] for r in ranks}) == world or ranks[0]["pci"] == "-1:-1", "two ranks share a GPU: %s" % ranks
 

@@ -84,14 +84,36 @@ typedef struct ufd_config {
 #define UFD_FLAG_NO_CHAIN 32u      /* m1->m2 / m3->m4 as two launches each instead of the chained kernel */
 #define UFD_FLAG_NO_RFB_SUM 64u    /* ConvLinear and shortcut of the RFB block as two convs instead of one summed conv */
 #define UFD_FLAG_NO_STEM_FUSE 128u /* upsample/colour/normalise kernel + stem conv instead of the stem reading the sample planes */
+/* Host placement: by default the handle's issue workers and pool threads are pinned to the CPUs of the NUMA node the GPU
+ * hangs off (/sys/bus/pci/devices/<bdf>/numa_node), inside the process's affinity mask -- eight handles on a two-socket
+ * box then stage their JPEG bytes and issue their launches from the socket next to their GPU (ufd_model_placement
+ * reports what was resolved).  Nothing is pinned when the node is unknown or with this flag. */
+#define UFD_FLAG_NO_NUMA_PIN 256u
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
 void ufd_destroy(ufd_model* m);
+/* Multi-GPU start-up in ONE process -- the reference server is one process whose tasks share one model
+ * (infer_server.rs:39-68; the single Inferer is spawned at :48-50).  Streams shard one-per-GPU (independent: run(&self)
+ * is pure, nn.rs:178-186), so a host keeps one handle per GPU and N Inferer tasks.  This call
+ *   - reads the weight source of `cfg` ONCE (get_model, nn.rs:143-175: one parse of the .onnx, not one per GPU),
+ *   - creates the handle of device_ids[0] from it,
+ *   - creates the other handles empty and fills them by the path's ONLY collective: ncclBroadcast (RCCL over xGMI,
+ *     communicators from ncclCommInitAll) of the packed weight image and the priors from device_ids[0].
+ * cfg->device_id is ignored; out[n] receives the handles in device_ids order (destroy each with ufd_destroy).  RCCL is
+ * loaded on first use (dlopen): the single-GPU entry points do not depend on it.  On failure out[] is all NULL and
+ * ufd_last_error(NULL) says why: UFD_E_ARG (n == 0, n > UFD_MAX_REPLICAS, an id out of range or listed twice),
+ * UFD_E_WEIGHTS, UFD_E_DEVICE (no GPU, librccl missing, a RCCL or HIP error). */
+#define UFD_MAX_REPLICAS 64
+int ufd_create_replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_model** out);
 /* Message for the last failing call on this handle (or on creation when m == NULL). */
 const char* ufd_last_error(const ufd_model* m);
 /* UltrafaceVariant::width_height (nn.rs:36-41) and K (number of priors) of the loaded model. */
 int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32_t* num_priors);
+/* Where the handle lives: HIP device, PCI address ("0000:63:00.0"), NUMA node of that PCI device (-1: unknown) and the
+ * CPUs its host threads are pinned to (count, and a "0-15,128-143" list; 0 / "" when nothing was pinned).  Any output may be NULL. */
+int ufd_model_placement(const ufd_model* m, int32_t* device_id, int32_t* numa_node, uint32_t* pinned_cpus, char* pci_bdf,
+                        size_t pci_cap, char* cpu_list, size_t cpu_cap);
 /* Limits given at ufd_create (defaults resolved): frames per batch, largest decoded frame. */
 int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height);
 
@@ -163,6 +185,13 @@ void ufd_staged_free(ufd_model* m, ufd_staged* staged);
  * ufd_encode_bound(w, h) bytes per frame always suffice.  Detections, n[] and status[] as ufd_submit_jpeg_batch. */
 #define UFD_ANNOT_MULTIPART 1u
 #define UFD_ANNOT_NO_TEXT 2u
+/* What is pinned about the annotated pixels.  Rectangles (first-party arithmetic, inferer.rs:66-76),
+ * the blend (imageproc weighted_sum) and the encoder (byte-identical to libjpeg-turbo) are pinned; the label's GLYPH
+ * COVERAGE values are restated from rusttype 0.9.3 / ab_glyph_rasterizer and could not be checked against the crates
+ * (FreeType agrees on ink boxes within a pixel and on ink within 12 %: tests).  UFD_ANNOT_NO_TEXT is the exact mode. */
+#define UFD_PARITY_EXACT 0
+#define UFD_PARITY_LABELS_UNPINNED 1
+int ufd_annotate_parity(uint32_t annot_flags);
 typedef struct ufd_annotate {
   uint32_t struct_size;   /* = sizeof(ufd_annotate) */
   float label_width;      /* inferer.rs:32-33: recv_ref.0 / .1 (1280 / 720 in the reference's router) */
@@ -185,6 +214,9 @@ size_t ufd_encode_bound(uint32_t w, uint32_t h);
 /* Page-locked host memory for jpeg_out (and for input rings): the D2H copy then runs at PCIe speed. */
 void* ufd_host_alloc(size_t bytes);
 void ufd_host_free(void* p);
+/* The same, allocated with the handle's GPU current (on a multi-GPU box a bare allocation would open a context on device 0
+ * from every rank) and visible to every device; free with ufd_host_free. */
+void* ufd_model_host_alloc(ufd_model* m, size_t bytes);
 
 /* ---- N4: multi-stream batching scheduler ----
  * The FrameRouter -> INFER_IMAGES_CHANNEL -> Inferer leg of the reference (router.rs:64-71, lib.rs:32-37,
@@ -200,6 +232,7 @@ void ufd_host_free(void* p);
  *   - up to max_inflight batches per model in flight (the handle overlaps them on its three device contexts).
  * Results are delivered on a completion thread through on_result, per frame, in dispatch order per stream. */
 #define UFD_E_FULL (-9) /* ufd_sched_push: the stream's ring is full, the frame was dropped (router.rs:65) */
+#define UFD_SCHED_NO_WAIT 0xFFFFFFFFu
 typedef struct ufd_sched ufd_sched;
 typedef struct ufd_frame_result {
   uint64_t stream_id;  /* as given in ufd_stream_config (e.g. lib.rs:39-46 hashed(name)) */
@@ -220,7 +253,7 @@ typedef struct ufd_sched_config {
   ufd_model* model_320;      /* handles the scheduler submits to (not owned; either may be NULL) */
   ufd_model* model_640;
   uint32_t ring_slots;       /* frames a stream may have queued; 0 -> 10 (INFER_IMAGES_CHANNEL, lib.rs:37) */
-  uint32_t max_wait_us;      /* 0 -> 2000 */
+  uint32_t max_wait_us;      /* 0 -> 2000; UFD_SCHED_NO_WAIT: a batch leaves as soon as the model has a slot for it */
   uint32_t max_inflight;     /* per model; 0 -> 6 */
   uint32_t det_cap;          /* 0 -> 256 */
   uint32_t jpeg_bytes_per_frame; /* output reserved per annotated frame; 0 -> 524288 (larger streams: UFD_E_TRUNCATED) */
@@ -244,8 +277,13 @@ typedef struct ufd_sched_stats {
 int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out);
 /* Delivers everything queued, then stops the threads. */
 void ufd_sched_destroy(ufd_sched* s);
+/* *stream receives the stream's handle.  A removed stream still delivers what it had queued; once that is out its ring
+ * slots are freed and its table entry is reused by a later ufd_sched_add_stream (cameras that reconnect do not grow the
+ * scheduler); the old handle then fails with UFD_E_STATE / UFD_E_ARG instead of reaching the new stream. */
 int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* stream);
 int ufd_sched_remove_stream(ufd_sched* s, uint32_t stream);
+/* Table entries in use (live + draining streams) and ever allocated: flat under add / remove churn. */
+int ufd_sched_debug_table(ufd_sched* s, uint32_t* live, uint32_t* allocated);
 /* router.rs:64-71: copies the JPEG into a free slot of the stream's ring (the caller's buffer is free on return);
  * UFD_E_FULL when there is none. */
 int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag);

@@ -790,21 +790,36 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
 }
 
 __global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, size_t coef_stride, uint32_t vec_per_frame,
-                                                   uint32_t* __restrict__ status) {
+                                                   uint32_t* __restrict__ status, int16_t* __restrict__ dc, size_t dc_stride,
+                                                   uint32_t dc_vec_per_frame) {
   // the batch's first kernel also clears the per-frame decode status (a memset launch of its own otherwise)
   if (blockIdx.x == 0 && threadIdx.x == 0) status[blockIdx.y] = 0;
   // 16-byte stores; coef_stride is a multiple of 8 int16
   uint4* dst = reinterpret_cast<uint4*>(coef + (size_t)blockIdx.y * coef_stride);
   for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < vec_per_frame; v += gridDim.x * 256) dst[v] = make_uint4(0, 0, 0, 0);
+  // the DC side array of the frame (one int16 per block: 1/64 of the slab)
+  if (dc && (dc_stride & 7) == 0) {
+    uint4* d = reinterpret_cast<uint4*>(dc + (size_t)blockIdx.y * dc_stride);
+    for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < dc_vec_per_frame; v += gridDim.x * 256) d[v] = make_uint4(0, 0, 0, 0);
+  } else if (dc) {  // (frame bases not 16-byte aligned: tiny max_src sizes only)
+    int16_t* d = dc + (size_t)blockIdx.y * dc_stride;
+    for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < dc_vec_per_frame * 8; v += gridDim.x * 256)
+      if (v < dc_stride) d[v] = 0;
+  }
 }
 
 }  // namespace
 
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s) {
+void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s,
+                      int16_t* d_dc, size_t dc_stride) {
   if (!frames) return;
   const uint32_t vecs = (uint32_t)((used_int16 + 7) / 8);
   const unsigned gx = std::min<unsigned>((vecs + 1023) / 1024, 256u);  // >= 4 stores per thread
-  hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs, d_status);
+  // DC entries of the used blocks, in whole 16-byte stores that stay inside the frame's dc_stride
+  uint32_t dc_vecs = 0;
+  if (d_dc) dc_vecs = (uint32_t)std::min<size_t>((used_int16 / 64 + 7) / 8, (dc_stride + 7) / 8);
+  hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs, d_status,
+                     dc_vecs ? d_dc : nullptr, dc_stride, dc_vecs);
 }
 
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride, SyncBuffers* layout) {

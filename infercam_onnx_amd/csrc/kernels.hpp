@@ -97,7 +97,9 @@ using HuffStageHook = std::function<void(const char* kernel, bool begin)>;
 // Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride /* blocks per frame */, SyncBuffers* layout);
 // Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s);
+// d_dc (optional): the frames' DC side array (SyncBuffers::dc), cleared for the used blocks as well.
+void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s,
+                      int16_t* d_dc = nullptr, size_t dc_stride = 0);
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,

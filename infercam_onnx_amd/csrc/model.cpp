@@ -24,12 +24,18 @@
 #include <string>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <fstream>
+
 #include "../../include/ufd.h"
 #include "jpeg_host.hpp"
 #include "kernels.hpp"
 #include "onnx_loader.hpp"
 #include "thread_pool.hpp"
 #include "topology.hpp"
+#include "model_internal.hpp"
 
 namespace ufd {
 namespace {
@@ -91,6 +97,7 @@ struct ProfEntry {
 
 struct Slot {
   bool busy = false;
+  bool waiting = false;  // a ufd_wait is finishing this slot outside the handle lock (guarded by ufd_model::mu)
   uint32_t ticket = 0, count = 0, cap = 0;
   JpegFrameDesc* h_descs = nullptr;
   int16_t* h_coef = nullptr;
@@ -173,13 +180,25 @@ struct Ctx {
   float4* d_spill = nullptr;
   unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
   uint32_t last_forward_count = 0;
-  // N1 encoder scratch (allocated by the first annotate batch on this context) and the quality it is set up for
+  // N1 encoder scratch, sized for the largest frame an annotate batch of this context has had (regrown when a larger
+  // one arrives), and the (quality, framing) set-ups seen: quantiser + marker segments, each with its own device header,
+  // so that streams of one model that differ in quality or framing alternate without a stream drain
   EncBuffers enc;
-  EncQuant enc_q{};
-  bool enc_ready = false, enc_ifast = true;
-  int enc_quality = -1, enc_multipart = -1;
+  bool enc_ready = false;
+  size_t enc_mcus = 0;  // MCUs per frame the scratch holds
+  struct EncSetup {
+    int quality = -1, multipart = -1;
+    EncQuant q{};
+    bool ifast = true;
+    uint8_t* d_header = nullptr;
+    uint32_t pre_len = 0, hdr_len = 0, dim_off = 0, post_len = 0;
+    uint64_t last_use = 0;
+  };
+  static constexpr int kEncSetups = 4;
+  EncSetup enc_setups[kEncSetups];
+  int enc_cur = 0;  // set-up of the batch being issued
+  uint64_t enc_seq = 0;
   uint32_t* d_enc_tables = nullptr;
-  uint8_t* d_enc_header = nullptr;
   JpegFrameDesc* d_enc_descs = nullptr;  // descriptors of frames that did not come out of the decoder (debug taps)
   void* d_label_ops = nullptr;           // one drawing operation per detection of the batch
   int* d_glyphs = nullptr;               // label glyph atlas (glyph_atlas.inc)
@@ -218,7 +237,14 @@ struct ufd_model {
   std::unique_ptr<ThreadPool> pool;
   unsigned host_threads = 1;
 
+  // host placement: NUMA node of the GPU's PCIe root and the CPUs of it this process may use; the handle's issue
+  // workers and pool threads are pinned to them (8 ranks on a two-socket box must not stage JPEG bytes across sockets)
+  int numa_node = -1;
+  std::vector<int> pin_cpus;
+  std::string pci_bdf, cpu_list;
+
   // resident model
+  size_t weight_img_floats = 0, priors_floats = 0;
   float* d_weights = nullptr;
   float* d_priors = nullptr;
   float* d_lut = nullptr;
@@ -774,6 +800,7 @@ int upload_weights(ufd_model* m, const float* blob) {
       img.insert(img.end(), bsum.begin(), bsum.end());
     }
   }
+  m->weight_img_floats = img.size();
   HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
   HIPC(m, hipMemcpy(m->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   for (int i = 0; i < kNumConv; i++) {
@@ -1097,9 +1124,12 @@ int fetch_streams(ufd_model* m, Slot& s) {
   size_t fit = 0;  // bytes of the packed output that hold whole streams and fit the caller's buffer
   int rc = UFD_OK;
   for (uint32_t i = 0; i < s.count; i++) {
-    const bool failed = (s.status ? s.status[i] : UFD_OK) != UFD_OK && (s.status ? s.status[i] : UFD_OK) != UFD_E_TRUNCATED;
+    // (the frame's final status as finish_slot merged it -- host parse, device entropy decoder, truncation -- whether or
+    // not the caller passed a status array: a frame the device decoder flagged never hands out its stream)
+    const bool failed = s.st[i] != UFD_OK && s.st[i] != UFD_E_TRUNCATED;
     if (failed || !len[i]) continue;
     if ((size_t)off[i] + len[i] > a.jpeg_cap) {
+      if (s.st[i] == UFD_OK) s.st[i] = UFD_E_TRUNCATED;
       if (s.status && s.status[i] == UFD_OK) s.status[i] = UFD_E_TRUNCATED;
       if (!s.status && rc == UFD_OK) rc = UFD_E_TRUNCATED;
       continue;
@@ -1118,12 +1148,29 @@ int fetch_streams(ufd_model* m, Slot& s) {
   return rc;
 }
 
+// Releases the slot on every exit path of finish_slot (an early HIP error return must not leak it for the life of the
+// handle).  `locked`: the caller holds m->mu (synchronous entry points); otherwise the release takes it -- ufd_wait runs
+// the copies below WITHOUT the handle lock, so that other threads can submit while a batch's annotated streams cross PCIe.
+struct SlotRelease {
+  ufd_model* m;
+  Slot& s;
+  bool locked;
+  ~SlotRelease() {
+    if (locked) {
+      s.busy = s.waiting = false;
+    } else {
+      std::lock_guard<std::mutex> lk(m->mu);
+      s.busy = s.waiting = false;
+    }
+  }
+};
+
 // waits for the slot's batch and hands results to the caller's arrays
-int finish_slot(ufd_model* m, Slot& s) {
+int finish_slot(ufd_model* m, Slot& s, bool locked = true) {
+  SlotRelease release{m, s, locked};
   if (s.issue_rc != UFD_OK) {  // the worker could not issue the batch
     const int rc = s.issue_rc;
     m->fail(rc, s.issue_err);
-    s.busy = false;
     return rc;
   }
   HIPC(m, hipEventSynchronize(s.done));
@@ -1153,6 +1200,7 @@ int finish_slot(ufd_model* m, Slot& s) {
       }
       if (nd > s.cap) st = UFD_E_TRUNCATED;
     }
+    s.st[i] = st;  // the frame's final status (fetch_streams reads it)
     if (s.n) s.n[i] = nd;
     if (s.status) s.status[i] = st;
     if (st != UFD_OK && rc == UFD_OK && !s.status) rc = st;
@@ -1161,7 +1209,6 @@ int finish_slot(ufd_model* m, Slot& s) {
     const int arc = fetch_streams(m, s);
     if (arc != UFD_OK && rc == UFD_OK) rc = arc;
   }
-  s.busy = false;
   return rc;
 }
 
@@ -1339,7 +1386,9 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
                            const JpegFrameDesc* d_descs, const HuffScan* d_scans, const HuffInterval* d_ivs, int16_t* d_coef) {
   {
     ProfScope ps(m, "zero_coef", (double)p.used_coef * 2 * count, 0);
-    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.d_status, c.stream);  // (also clears d_status)
+    // (also clears d_status and the frames' DC side array: a frame the decoder flags corrupt then reconstructs from zeros,
+    // not from what an earlier batch left there)
+    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.d_status, c.stream, c.sync.dc, c.sync.dc_stride);
   }
   {
     std::unique_ptr<ProfScope> scope;
@@ -1432,26 +1481,14 @@ size_t enc_frame_bound(uint32_t w, uint32_t h) {
   return 2 * enc_stream_bound(mcus) + 1024;  // every entropy-coded byte stuffed + header, EOI, framing
 }
 
-// Encoder scratch of a context (first annotate batch) and the tables of the requested quality.
-int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart) {
+// Encoder scratch of a context for frames of up to mw x mh (grown on demand: a camera stream has one frame size, so
+// this happens on its first annotate batch) and the set-up of the requested (quality, framing).
+int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart, uint32_t mw, uint32_t mh) {
   if (quality < 1 || quality > 100) return m->fail(UFD_E_ARG, "quality must be in 1..100");
   EncBuffers& e = c.enc;
-  if (!c.enc_ready) {
-    const size_t mcus = (size_t)((m->max_w + 15) / 16) * ((m->max_h + 15) / 16);
-    const size_t sb = enc_stream_bound(mcus);
-    e.coef_stride = mcus * 6 * 64;
-    e.blk_stride = mcus * 6;
-    e.word_stride = (((sb + 3) / 4 + 3) & ~(size_t)3) + 8;  // whole 16-byte groups + the padding the scan zeroes
-    e.chunk_stride = (sb + 4095) / 4096 + 1;
-    e.plane_stride = mcus * 384;  // 256 luma + 2 x 64 chroma samples per MCU
-    HIPC(m, hipMalloc(&e.planes, e.plane_stride * m->B));
-    HIPC(m, hipMalloc(&e.coef, sizeof(int16_t) * e.coef_stride * m->B));
-    HIPC(m, hipMalloc(&e.bits, sizeof(uint32_t) * e.blk_stride * m->B));
+  if (!c.enc_ready) {  // fixed-size pieces, once
     HIPC(m, hipMalloc(&e.total_bits, sizeof(uint32_t) * m->B));
-    HIPC(m, hipMalloc(&e.words, sizeof(uint32_t) * e.word_stride * m->B));
-    HIPC(m, hipMalloc(&e.chunk_ff, sizeof(uint32_t) * e.chunk_stride * m->B));
     HIPC(m, hipMalloc(&c.d_enc_tables, sizeof(uint32_t) * 2 * 272));
-    HIPC(m, hipMalloc(&c.d_enc_header, 1024));
     HIPC(m, hipMalloc(&c.d_enc_descs, sizeof(JpegFrameDesc) * m->B));
     HIPC(m, hipMalloc(&c.d_label_ops, label_ops_bytes(m->B, (uint32_t)m->K)));
     {
@@ -1468,30 +1505,74 @@ int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart) {
     enc_make_code_tables(tabs);
     HIPC(m, hipMemcpy(c.d_enc_tables, tabs, sizeof(tabs), hipMemcpyHostToDevice));
     e.tables = c.d_enc_tables;
-    e.header = c.d_enc_header;
     c.enc_ready = true;
   }
-  if (c.enc_quality != (int)quality || c.enc_multipart != (int)multipart) {
+  const size_t mcus = (size_t)((mw + 15) / 16) * ((mh + 15) / 16);
+  if (mcus > c.enc_mcus) {
+    // earlier encodes of this context may still use the old scratch: drain, free, allocate the larger set.  A failed
+    // allocation leaves enc_mcus = 0 and null pointers behind (nothing leaks, the next batch tries again).
+    HIPC(m, hipStreamSynchronize(c.stream));
+    (void)hipFree(e.planes), (void)hipFree(e.coef), (void)hipFree(e.bits), (void)hipFree(e.words), (void)hipFree(e.chunk_ff);
+    e.planes = nullptr, e.coef = nullptr, e.bits = nullptr, e.words = nullptr, e.chunk_ff = nullptr;
+    c.enc_mcus = 0;
+    const size_t sb = enc_stream_bound(mcus);
+    e.coef_stride = mcus * 6 * 64;
+    e.blk_stride = mcus * 6;
+    e.word_stride = (((sb + 3) / 4 + 3) & ~(size_t)3) + 8;  // whole 16-byte groups + the padding the scan zeroes
+    e.chunk_stride = (sb + 4095) / 4096 + 1;
+    e.plane_stride = mcus * 384;  // 256 luma + 2 x 64 chroma samples per MCU
+    HIPC(m, hipMalloc(&e.planes, e.plane_stride * m->B));
+    HIPC(m, hipMalloc(&e.coef, sizeof(int16_t) * e.coef_stride * m->B));
+    HIPC(m, hipMalloc(&e.bits, sizeof(uint32_t) * e.blk_stride * m->B));
+    HIPC(m, hipMalloc(&e.words, sizeof(uint32_t) * e.word_stride * m->B));
+    HIPC(m, hipMalloc(&e.chunk_ff, sizeof(uint32_t) * e.chunk_stride * m->B));
+    c.enc_mcus = mcus;
+  }
+  // the (quality, framing) set-up: a cached one, a free entry (its fresh device header has no reader yet: no drain), or
+  // the least recently used entry, rewritten behind the stream's earlier encodes
+  int pick = -1, lru = 0;
+  for (int i = 0; i < Ctx::kEncSetups; i++) {
+    const Ctx::EncSetup& q = c.enc_setups[i];
+    if (q.quality == (int)quality && q.multipart == (int)multipart) pick = i;
+    if (q.last_use < c.enc_setups[lru].last_use) lru = i;
+  }
+  if (pick < 0) {
+    pick = lru;
+    Ctx::EncSetup& q = c.enc_setups[pick];
     uint8_t ql[64], qc[64], hdr[1024];
     enc_quant_tables((int)quality, ql, qc);
-    c.enc_ifast = quality < 96;  // turbojpeg.c setCompDefaults: JDCT_ISLOW from quality 96 on, JDCT_FASTEST below
-    enc_make_quant(ql, qc, c.enc_ifast, &c.enc_q);
-    const size_t n = enc_make_header(ql, qc, multipart, hdr, &e.pre_len, &e.hdr_len, &e.dim_off, &e.post_len);
-    // earlier encodes of this context still read the old header: order the update behind them
-    HIPC(m, hipStreamSynchronize(c.stream));
-    HIPC(m, hipMemcpy(c.d_enc_header, hdr, n, hipMemcpyHostToDevice));
-    c.enc_quality = (int)quality, c.enc_multipart = (int)multipart;
+    q.ifast = quality < 96;  // turbojpeg.c setCompDefaults: JDCT_ISLOW from quality 96 on, JDCT_FASTEST below
+    enc_make_quant(ql, qc, q.ifast, &q.q);
+    const size_t n = enc_make_header(ql, qc, multipart, hdr, &q.pre_len, &q.hdr_len, &q.dim_off, &q.post_len);
+    if (q.d_header) HIPC(m, hipStreamSynchronize(c.stream));  // an evicted set-up: earlier encodes still read its header
+    else HIPC(m, hipMalloc(&q.d_header, 1024));
+    q.quality = -1;
+    HIPC(m, hipMemcpy(q.d_header, hdr, n, hipMemcpyHostToDevice));
+    q.quality = (int)quality, q.multipart = (int)multipart;
   }
+  Ctx::EncSetup& q = c.enc_setups[pick];
+  q.last_use = ++c.enc_seq;
+  c.enc_cur = pick;
+  e.header = q.d_header;
+  e.pre_len = q.pre_len, e.hdr_len = q.hdr_len, e.dim_off = q.dim_off, e.post_len = q.post_len;
   return UFD_OK;
 }
 
-int ensure_slot_encoder(ufd_model* m, Slot& s) {
-  if (s.d_enc_out) return UFD_OK;
-  s.enc_out_cap = enc_frame_bound(m->max_w, m->max_h) * m->B;
-  HIPC(m, hipMalloc(&s.d_enc_out, s.enc_out_cap));
-  HIPC(m, hipMalloc(&s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1)));
-  HIPC(m, hipHostMalloc(&s.h_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipHostMallocDefault));
-  HIPC(m, hipEventCreateWithFlags(&s.enc_copied, hipEventDisableTiming));
+// Output of a slot's batch for frames of up to mw x mh (grown on demand; the slot is ours and its previous batch has
+// been waited for, so nothing on the GPU still refers to the old buffer).
+int ensure_slot_encoder(ufd_model* m, Slot& s, uint32_t mw, uint32_t mh) {
+  if (!s.d_enc_meta) {
+    HIPC(m, hipMalloc(&s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1)));
+    HIPC(m, hipHostMalloc(&s.h_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipHostMallocDefault));
+    HIPC(m, hipEventCreateWithFlags(&s.enc_copied, hipEventDisableTiming));
+  }
+  const size_t need = enc_frame_bound(mw, mh) * m->B;
+  if (need > s.enc_out_cap) {
+    (void)hipFree(s.d_enc_out);
+    s.d_enc_out = nullptr, s.enc_out_cap = 0;
+    HIPC(m, hipMalloc(&s.d_enc_out, need));
+    s.enc_out_cap = need;
+  }
   return UFD_OK;
 }
 
@@ -1499,9 +1580,9 @@ int ensure_slot_encoder(ufd_model* m, Slot& s) {
 // finished streams follow the detections to the host.  On the context's stream, behind the NMS.
 int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count) {
   Ctx& c = *tl_cur;
-  int rc = ensure_encoder(m, c, s.annot_args.quality, (s.annot_args.flags & UFD_ANNOT_MULTIPART) != 0);
+  int rc = ensure_encoder(m, c, s.annot_args.quality, (s.annot_args.flags & UFD_ANNOT_MULTIPART) != 0, mw, mh);
   if (rc) return rc;
-  rc = ensure_slot_encoder(m, s);
+  rc = ensure_slot_encoder(m, s, mw, mh);
   if (rc) return rc;
   {
     ProfScope ps(m, "draw_labels", 0, 0);
@@ -1519,7 +1600,8 @@ int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32
       if (begin) scope.reset(new ProfScope(m, stage, bytes, 0));
       else scope.reset();
     };
-    launch_jpeg_encode(d_descs, c.d_rgb, m->rgb_stride, mw, mh, count, c.enc_q, c.enc_ifast, e, c.stream, &hook);
+    launch_jpeg_encode(d_descs, c.d_rgb, m->rgb_stride, mw, mh, count, c.enc_setups[c.enc_cur].q, c.enc_setups[c.enc_cur].ifast, e, c.stream,
+                       &hook);
   }
   HIPC(m, hipMemcpyAsync(s.h_enc_meta, s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, c.stream));
   s.annot_ran = true;
@@ -1715,10 +1797,78 @@ int upload_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h, uint32_
   return UFD_OK;
 }
 
+// ---------------------------------------------------------------- host placement
+// "0-3,8,10-11" -> cpu ids
+std::vector<int> parse_cpu_list(const std::string& txt) {
+  std::vector<int> out;
+  size_t i = 0;
+  while (i < txt.size()) {
+    while (i < txt.size() && !std::isdigit((unsigned char)txt[i])) i++;
+    if (i >= txt.size()) break;
+    int a = 0;
+    while (i < txt.size() && std::isdigit((unsigned char)txt[i])) a = a * 10 + (txt[i++] - '0');
+    int b = a;
+    if (i < txt.size() && txt[i] == '-') {
+      i++;
+      b = 0;
+      while (i < txt.size() && std::isdigit((unsigned char)txt[i])) b = b * 10 + (txt[i++] - '0');
+    }
+    for (int c = a; c <= b && out.size() < 4096; c++) out.push_back(c);
+  }
+  return out;
+}
+
+std::string read_first_line(const std::string& path) {
+  std::ifstream f(path);
+  std::string line;
+  if (f) std::getline(f, line);
+  return line;
+}
+
+// NUMA node of the device (/sys/bus/pci/devices/<bdf>/numa_node) and the CPUs of that node inside this process's
+// affinity mask.  Nothing is pinned when the node is unknown (-1: one socket, or a VM that hides the topology), when
+// the mask and the node do not intersect, or with UFD_FLAG_NO_NUMA_PIN.
+void resolve_placement(ufd_model* m) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), m->cfg.device_id) != hipSuccess) return;
+  for (char* p = bdf; *p; p++) *p = (char)std::tolower((unsigned char)*p);
+  m->pci_bdf = bdf;
+  const std::string node_txt = read_first_line(std::string("/sys/bus/pci/devices/") + bdf + "/numa_node");
+  if (node_txt.empty()) return;
+  m->numa_node = std::atoi(node_txt.c_str());
+  if (m->numa_node < 0 || (m->cfg.flags & UFD_FLAG_NO_NUMA_PIN)) return;
+  const std::vector<int> node_cpus =
+      parse_cpu_list(read_first_line("/sys/devices/system/node/node" + std::to_string(m->numa_node) + "/cpulist"));
+  cpu_set_t cur;
+  CPU_ZERO(&cur);
+  if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
+  for (int c : node_cpus)
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &cur)) m->pin_cpus.push_back(c);
+  // compact "a-b,c" form for reports
+  std::string txt;
+  for (size_t i = 0; i < m->pin_cpus.size();) {
+    size_t j = i;
+    while (j + 1 < m->pin_cpus.size() && m->pin_cpus[j + 1] == m->pin_cpus[j] + 1) j++;
+    txt += (txt.empty() ? "" : ",") + std::to_string(m->pin_cpus[i]) + (j > i ? "-" + std::to_string(m->pin_cpus[j]) : "");
+    i = j + 1;
+  }
+  m->cpu_list = txt;
+}
+
+// Calling thread -> the handle's CPUs (no-op when nothing was resolved).
+void pin_this_thread(const ufd_model* m) {
+  if (m->pin_cpus.empty()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : m->pin_cpus) CPU_SET(c, &set);
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
 // Worker of one context: issues queued batches (host entropy stage + every GPU enqueue) so that
 // the caller's submit returns at once and the host work of consecutive batches runs in parallel
 // on the two contexts.
 void worker_main(ufd_model* m, Worker* w) {
+  pin_this_thread(m);
   (void)hipSetDevice(m->cfg.device_id);
   tl_cur = w->ctx;
   tl_pool = w->pool.get();
@@ -1812,7 +1962,8 @@ void destroy(ufd_model* m) {
     dfree(c.d_spill);
     dfree(c.d_nms_mat);
     dfree(c.enc.planes), dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
-    dfree(c.d_enc_tables), dfree(c.d_enc_header), dfree(c.d_enc_descs);
+    dfree(c.d_enc_tables), dfree(c.d_enc_descs);
+    for (auto& q : c.enc_setups) dfree(q.d_header);
     dfree(c.d_label_ops), dfree(c.d_glyphs), dfree(c.d_coverage);
   }
   for (float* t : m->tap_buf) dfree(t);
@@ -1878,7 +2029,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->max_h = std::max<uint32_t>(m->max_h, m->H);
   m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
   unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-  m->pool.reset(new ThreadPool(std::min(threads, 8u)));  // synchronous entry points and taps
   m->host_threads = threads;
 #define HIPB(expr)                                                                      \
   do {                                                                                  \
@@ -1897,6 +2047,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return bail(UFD_E_DEVICE);
     }
   }
+  resolve_placement(m);
+  m->pool.reset(new ThreadPool(std::min(threads, 8u), [m] { pin_this_thread(m); }));  // synchronous entry points and taps
   // More than four live HSA queues cost throughput (host pipeline): if the process raised the
   // runtime's cap, stay at two contexts = four streams (34 k instead of 30 k frames/s at GPU_MAX_HW_QUEUES=8).
   if (const char* q = std::getenv("GPU_MAX_HW_QUEUES"))
@@ -1955,6 +2107,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   }
   int rc = upload_weights(m, blob.data());
   if (rc) return bail(rc);
+  m->priors_floats = priors.size();
   HIPB(hipMalloc(&m->d_priors, priors.size() * sizeof(float)));
   HIPB(hipMemcpy(m->d_priors, priors.data(), priors.size() * sizeof(float), hipMemcpyHostToDevice));
   {
@@ -2039,7 +2192,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Worker& w = m->workers[ci];
     w.ctx = &m->ctx[ci];
-    w.pool.reset(new ThreadPool(std::max(1u, m->host_threads / (unsigned)m->num_ctx)));
+    w.pool.reset(new ThreadPool(std::max(1u, m->host_threads / (unsigned)m->num_ctx), [m] { pin_this_thread(m); }));
     w.th = std::thread(worker_main, m, &w);
   }
   // pinned staging of every slot now: a first-use allocation (milliseconds) would land inside the
@@ -2106,6 +2259,21 @@ int ufd_model_info(const ufd_model* m, uint32_t* width, uint32_t* height, uint32
   if (height) *height = m->H;
   if (num_priors) *num_priors = m->K;
   return UFD_OK;
+}
+
+int ufd_model_placement(const ufd_model* m, int32_t* device_id, int32_t* numa_node, uint32_t* pinned_cpus, char* pci_bdf,
+                        size_t pci_cap, char* cpu_list, size_t cpu_cap) {
+  if (!m) return UFD_E_ARG;
+  if (device_id) *device_id = m->cfg.device_id;
+  if (numa_node) *numa_node = m->numa_node;
+  if (pinned_cpus) *pinned_cpus = (uint32_t)m->pin_cpus.size();
+  if (pci_bdf && pci_cap) std::snprintf(pci_bdf, pci_cap, "%s", m->pci_bdf.c_str());
+  if (cpu_list && cpu_cap) std::snprintf(cpu_list, cpu_cap, "%s", m->cpu_list.c_str());
+  return UFD_OK;
+}
+
+int ufd_annotate_parity(uint32_t annot_flags) {
+  return (annot_flags & UFD_ANNOT_NO_TEXT) ? UFD_PARITY_EXACT : UFD_PARITY_LABELS_UNPINNED;
 }
 
 int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height) {
@@ -2220,6 +2388,12 @@ void* ufd_host_alloc(size_t bytes) {
   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
   return p;
 }
+void* ufd_model_host_alloc(ufd_model* m, size_t bytes) {
+  if (!m || hipSetDevice(m->cfg.device_id) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+  return p;
+}
 void ufd_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
@@ -2288,15 +2462,15 @@ int ufd_wait(ufd_model* m, uint32_t ticket) {
     for (auto& c : m->slots)
       if (c.busy && c.ticket == ticket) s = &c;
     if (!s) return m->fail(UFD_E_STATE, "unknown ticket");
+    if (s->waiting) return m->fail(UFD_E_STATE, "another thread is already waiting for this ticket");
+    s->waiting = true;
   }
   // not holding the handle lock while the worker and the GPU finish: other threads may submit
   wait_issued(m, *s);
   try {
-    if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
-    if (s->issue_rc == UFD_OK && hipEventSynchronize(s->done) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipEventSynchronize failed");
-    std::lock_guard<std::mutex> lk(m->mu);
+    (void)hipSetDevice(m->cfg.device_id);  // (a failure shows up in the event wait below, which also releases the slot)
     tl_cur = s->ctx;
-    return finish_slot(m, *s);
+    return finish_slot(m, *s, /*locked=*/false);  // (copies and waits outside m->mu; the slot is released under it)
   } catch (...) {
     return m->fail(UFD_E_DEVICE, "unknown exception");
   }
@@ -2365,7 +2539,8 @@ int ufd_debug_draw_labels(ufd_model* m, uint8_t* rgb, uint32_t w, uint32_t h, ui
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
     int rc = alloc_slot(m, *s);
     if (rc) return rc;
-    rc = ensure_encoder(m, *tl_cur, 95, false);
+    if (!w || !h || w > m->max_w || h > m->max_h) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+    rc = ensure_encoder(m, *tl_cur, 95, false, w, h);
     if (rc) return rc;
     rc = upload_plain_frame(m, rgb, w, h, pitch);
     if (rc) return rc;
@@ -2389,17 +2564,18 @@ int ufd_debug_encode_rgb(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t 
     if (!s) return m->fail(UFD_E_STATE, "all slots busy");
     int rc = alloc_slot(m, *s);
     if (rc) return rc;
-    rc = ensure_encoder(m, *tl_cur, quality, (flags & UFD_ANNOT_MULTIPART) != 0);
+    if (!w || !h || w > m->max_w || h > m->max_h) return m->fail(UFD_E_TOO_LARGE, "frame larger than max_src_width/height");
+    rc = ensure_encoder(m, *tl_cur, quality, (flags & UFD_ANNOT_MULTIPART) != 0, w, h);
     if (rc) return rc;
-    rc = ensure_slot_encoder(m, *s);
+    rc = ensure_slot_encoder(m, *s, w, h);
     if (rc) return rc;
     rc = upload_plain_frame(m, rgb, w, h, pitch);
     if (rc) return rc;
     EncBuffers e = tl_cur->enc;
     e.out = s->d_enc_out;
     e.out_len = s->d_enc_meta, e.out_off = s->d_enc_meta + m->B, e.out_total = s->d_enc_meta + 2 * m->B;
-    launch_jpeg_encode(tl_cur->d_enc_descs, tl_cur->d_rgb, m->rgb_stride, w, h, 1, tl_cur->enc_q, tl_cur->enc_ifast, e,
-                       tl_cur->stream);
+    launch_jpeg_encode(tl_cur->d_enc_descs, tl_cur->d_rgb, m->rgb_stride, w, h, 1, tl_cur->enc_setups[tl_cur->enc_cur].q,
+                       tl_cur->enc_setups[tl_cur->enc_cur].ifast, e, tl_cur->stream);
     HIPC(m, hipMemcpyAsync(s->h_enc_meta, s->d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipStreamSynchronize(tl_cur->stream));
     *len = s->h_enc_meta[0];
@@ -2604,3 +2780,34 @@ int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- hooks of replicas.cpp (not part of the C ABI)
+namespace ufd {
+int create_handle(const ufd_config* cfg, ufd_model** out) { return create(cfg, out); }
+void set_create_error(const std::string& msg) { g_create_error = msg; }
+std::string get_create_error() { return g_create_error; }
+void weight_buffers(ufd_model* m, float** d_weights, size_t* weight_floats, float** d_priors, size_t* prior_floats) {
+  *d_weights = m->d_weights, *weight_floats = m->weight_img_floats;
+  *d_priors = m->d_priors, *prior_floats = m->priors_floats;
+}
+bool load_weights_once(const ufd_config* cfg, std::vector<float>* blob, std::vector<float>* priors, std::string* why) {
+  const int W = cfg->variant == 640 ? 640 : 320, H = cfg->variant == 640 ? 480 : 240;
+  if (cfg->weights) {
+    if (cfg->weights_floats != total_weight_floats()) {
+      *why = "weights blob must hold " + std::to_string(total_weight_floats()) + " floats";
+      return false;
+    }
+    blob->assign(cfg->weights, cfg->weights + cfg->weights_floats);
+    if (cfg->priors) priors->assign(cfg->priors, cfg->priors + cfg->priors_floats);
+  } else {
+    const std::string path = cfg->weights_path ? cfg->weights_path : default_weights_path(cfg->variant);
+    if (!load_ultraface_onnx(path, W, H, blob, priors, why)) {
+      *why = "cannot load " + path + ": " + *why;
+      return false;
+    }
+  }
+  if (priors->empty()) gen_priors(W, H, *priors);
+  return true;
+}
+}  // namespace ufd
+

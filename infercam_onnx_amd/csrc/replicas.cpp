@@ -1,0 +1,216 @@
+// replicas.cpp -- ufd_create_replicas: the multi-GPU start-up of the hot path inside ONE process.
+//
+// The reference server is one process whose tasks share one model (infer_server.rs:39-68 spawns the
+// single Inferer at :48-50); north_star shards independent camera streams one-per-GPU and allows
+// exactly one collective: the start-up weight broadcast.  A Rust host therefore calls this once and
+// gets one handle per GPU:
+//   1. the weight source is read ONCE (get_model, nn.rs:143-175: the .onnx is parsed on the host a
+//      single time, not once per GPU);
+//   2. the handle of device_ids[0] is created from it: its resident image is the packed form the
+//      kernels read (MFMA A-operand order, depthwise [c][12] records, summed / stacked 1x1 pairs);
+//   3. the other handles are created with a zero blob (same plan, same image layout, no parsing)
+//      and receive that packed image and the priors by ncclBroadcast -- RCCL over xGMI, one
+//      communicator per device from ncclCommInitAll, the broadcasts issued as one group.
+// Nothing is exchanged afterwards: streams are independent (run(&self) is pure, nn.rs:178-186).
+//
+// RCCL is loaded with dlopen at the first call: the single-GPU library has no link-time dependency
+// on it (librccl brings its own kernels and start-up cost), and a box without it fails here loudly.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ufd.h"
+#include "model_internal.hpp"
+
+namespace {
+
+struct Rccl {
+  void* so = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+};
+
+Rccl* load_rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // the librccl beside the HIP runtime THIS library is bound to (a process may hold a second ROCm copy, e.g. the one
+    // bundled with PyTorch: RCCL must talk to the runtime that owns the handles' memory), then the usual names
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+      const std::string hip = info.dli_fname;
+      const size_t slash = hip.rfind('/');
+      if (slash != std::string::npos) names.push_back(hip.substr(0, slash) + "/librccl.so.1");
+    }
+    names.insert(names.end(), {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"});
+    for (const std::string& name : names) {
+      r.so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (r.so) break;
+    }
+    if (!r.so) {
+      r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+      return;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(r.so, n);
+      if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n;
+      return p;
+    };
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return &r;
+}
+
+int replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_model** out) {
+  using namespace ufd;
+  if (out)
+    for (uint32_t i = 0; i < n && i < UFD_MAX_REPLICAS; i++) out[i] = nullptr;
+  if (!cfg || !device_ids || !out || cfg->struct_size != sizeof(ufd_config)) {
+    set_create_error("ufd_create_replicas: null argument or struct_size mismatch");
+    return UFD_E_ARG;
+  }
+  if (n < 1 || n > UFD_MAX_REPLICAS) {
+    set_create_error("ufd_create_replicas: n must be in 1.." + std::to_string(UFD_MAX_REPLICAS));
+    return UFD_E_ARG;
+  }
+  if (cfg->variant != 640 && cfg->variant != 320) {
+    set_create_error("ufd_create_replicas: variant must be 640 or 320");
+    return UFD_E_ARG;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t j = 0; j < i; j++)
+      if (device_ids[i] == device_ids[j]) {
+        set_create_error("ufd_create_replicas: device " + std::to_string(device_ids[i]) + " listed twice (one handle per GPU)");
+        return UFD_E_ARG;
+      }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_create_error("no HIP device: libufacehip needs a gfx950 GPU (there is no CPU fallback)");
+    return UFD_E_DEVICE;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (device_ids[i] < 0 || device_ids[i] >= ndev) {
+      set_create_error("ufd_create_replicas: device id " + std::to_string(device_ids[i]) + " out of range (" + std::to_string(ndev) + " devices)");
+      return UFD_E_ARG;
+    }
+  Rccl* r = load_rccl();
+  if (!r->why.empty()) {
+    set_create_error(r->why);
+    return UFD_E_DEVICE;
+  }
+  // 1. the weight source, once
+  std::vector<float> blob, priors;
+  std::string why;
+  if (!load_weights_once(cfg, &blob, &priors, &why)) {
+    set_create_error(why);
+    return UFD_E_WEIGHTS;
+  }
+  auto destroy_all = [&] {
+    for (uint32_t i = 0; i < n; i++) {
+      if (out[i]) ufd_destroy(out[i]);
+      out[i] = nullptr;
+    }
+  };
+  // 2./3. handle 0 from the blob, the others from zeros (identical plan and image layout, nothing parsed or packed twice
+  // that matters: their image is overwritten below)
+  std::vector<float> zeros(blob.size(), 0.0f);
+  for (uint32_t i = 0; i < n; i++) {
+    ufd_config c = *cfg;
+    c.device_id = device_ids[i];
+    c.weights_path = nullptr;
+    c.weights = i == 0 ? blob.data() : zeros.data();
+    c.weights_floats = blob.size();
+    c.priors = priors.data();
+    c.priors_floats = priors.size();
+    const int rc = create_handle(&c, &out[i]);
+    if (rc != UFD_OK) {
+      const std::string msg = "replica on device " + std::to_string(device_ids[i]) + ": " + get_create_error();
+      destroy_all();
+      set_create_error(msg);
+      return rc;
+    }
+  }
+  // the one collective of the path: packed weight image + priors from device_ids[0] to every other device
+  std::vector<ncclComm_t> comms(n, nullptr);
+  std::vector<hipStream_t> streams(n, nullptr);
+  std::vector<int> devs(device_ids, device_ids + n);
+  std::string err;
+  auto nccl_ok = [&](ncclResult_t rc, const char* what) {
+    if (rc == ncclSuccess) return true;
+    if (err.empty()) err = std::string(what) + ": " + r->GetErrorString(rc);
+    return false;
+  };
+  auto hip_ok = [&](hipError_t rc, const char* what) {
+    if (rc == hipSuccess) return true;
+    if (err.empty()) err = std::string(what) + ": " + hipGetErrorString(rc);
+    return false;
+  };
+  bool ok = nccl_ok(r->CommInitAll(comms.data(), (int)n, devs.data()), "ncclCommInitAll");
+  for (uint32_t i = 0; ok && i < n; i++)
+    ok = hip_ok(hipSetDevice(devs[i]), "hipSetDevice") && hip_ok(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking), "hipStreamCreate");
+  if (ok) {
+    size_t wf0 = 0, pf0 = 0;
+    ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
+    for (uint32_t i = 0; ok && i < n; i++) {
+      float *dw = nullptr, *dp = nullptr;
+      size_t wf = 0, pf = 0;
+      weight_buffers(out[i], &dw, &wf, &dp, &pf);
+      if (i == 0) wf0 = wf, pf0 = pf;
+      if (wf != wf0 || pf != pf0) {  // (same variant and flags on every device: cannot happen)
+        err = "replica images differ in size";
+        ok = false;
+        break;
+      }
+      ok = hip_ok(hipSetDevice(devs[i]), "hipSetDevice") &&
+           nccl_ok(r->Broadcast(dw, dw, wf, ncclFloat, 0, comms[i], streams[i]), "ncclBroadcast(weights)") &&
+           nccl_ok(r->Broadcast(dp, dp, pf, ncclFloat, 0, comms[i], streams[i]), "ncclBroadcast(priors)");
+    }
+    const bool ended = nccl_ok(r->GroupEnd(), "ncclGroupEnd");
+    ok = ok && ended;
+    for (uint32_t i = 0; i < n; i++)
+      if (streams[i]) ok = hip_ok(hipSetDevice(devs[i]), "hipSetDevice") && hip_ok(hipStreamSynchronize(streams[i]), "hipStreamSynchronize") && ok;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    if (streams[i]) {
+      (void)hipSetDevice(devs[i]);
+      (void)hipStreamDestroy(streams[i]);
+    }
+    if (comms[i]) (void)r->CommDestroy(comms[i]);
+  }
+  if (!ok) {
+    destroy_all();
+    set_create_error("ufd_create_replicas: " + err);
+    return UFD_E_DEVICE;
+  }
+  return UFD_OK;
+}
+
+}  // namespace
+
+extern "C" int ufd_create_replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_model** out) {
+  try {
+    return replicas(cfg, device_ids, n, out);
+  } catch (const std::exception& e) {
+    ufd::set_create_error(std::string("exception: ") + e.what());
+    return UFD_E_DEVICE;
+  } catch (...) {
+    ufd::set_create_error("unknown exception");
+    return UFD_E_DEVICE;
+  }
+}

@@ -36,7 +36,12 @@ struct Stream {
   std::vector<Frame*> free_;   // ring slots not in use
   std::vector<std::unique_ptr<Frame>> slots;
   uint32_t in_batches = 0;     // frames currently inside dispatched batches
+  uint32_t filling = 0;        // ring slots a ufd_sched_push is copying into outside the lock
 };
+
+// A stream handle = table index (low kIndexBits) | generation of that table entry: an index is reused once its stream has
+// been removed and has drained, and a stale handle of the old stream then fails instead of reaching the new one.
+constexpr uint32_t kIndexBits = 20, kIndexMask = (1u << kIndexBits) - 1;
 
 // Streams that can share a batch: same model and same kind of output.
 struct Klass {
@@ -71,7 +76,10 @@ struct ufd_sched {
   uint32_t max_batch[2] = {0, 0};
   std::mutex mu;
   std::condition_variable cv_dispatch, cv_complete, cv_flush;
-  std::deque<Stream> streams;  // (a deque: entries never move; always accessed with the lock held)
+  // stream table: entry i is a live (or draining) stream, or null with i on free_ids.  Always accessed with the lock held.
+  std::vector<std::unique_ptr<Stream>> streams;
+  std::vector<uint32_t> gen;       // generation of every table entry
+  std::vector<uint32_t> free_ids;  // reclaimed entries, reused by ufd_sched_add_stream
   std::vector<Klass> klasses;
   std::deque<Batch*> inflight;             // dispatch order
   std::vector<std::unique_ptr<Batch>> pool;
@@ -111,7 +119,7 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
   uint32_t waiting = 0;
   Clock::time_point oldest = Clock::time_point::max();
   for (size_t i = 0; i < kl.streams.size(); i++) {
-    const Stream& st = s->streams[kl.streams[i]];
+    const Stream& st = *s->streams[kl.streams[i]];
     queued[i] = (uint32_t)st.queued.size();
     waiting += queued[i];
     if (!st.queued.empty()) oldest = std::min(oldest, st.queued.front()->pushed);
@@ -130,8 +138,12 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
     s->pool.emplace_back(new Batch);
     s->free_batches.push_back(s->pool.back().get());
   }
-  Batch* b = s->free_batches.back();
-  s->free_batches.pop_back();
+  // an annotate class takes a batch object that already owns pinned output, the others one that does not
+  size_t pick = s->free_batches.size() - 1;
+  for (size_t i = 0; i < s->free_batches.size(); i++)
+    if ((s->free_batches[i]->jpeg_cap != 0) == (kl.annotate != 0)) pick = i;
+  Batch* b = s->free_batches[pick];
+  s->free_batches.erase(s->free_batches.begin() + (long)pick);
   const uint32_t count = ufd_sched_debug_plan(queued.data(), (uint32_t)queued.size(), kl.last, s->max_batch[vi], take.data());
   b->klass = k, b->count = count, b->why = why;
   b->stream.clear(), b->stream_id.clear(), b->frame.clear(), b->ptrs.clear(), b->lens.clear();
@@ -145,7 +157,7 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
       const uint32_t i = (start + q) % (uint32_t)kl.streams.size();
       if (!left[i]) continue;
       kl.last = i;  // the stream served last: the next batch starts after it
-      Stream& st = s->streams[kl.streams[i]];
+      Stream& st = *s->streams[kl.streams[i]];
       Frame* f = st.queued.front();
       st.queued.pop_front();
       st.in_batches++;
@@ -165,6 +177,34 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
   return b;
 }
 
+// With the lock held: a removed stream that has nothing queued, nothing in a dispatched batch and no push in progress
+// leaves the tables -- its ring slots (each keeps the capacity of the largest JPEG it held) are freed, its class forgets
+// it (the round-robin position is kept on the same neighbour) and its table index goes back on the free list.
+void reclaim_if_drained(ufd_sched* s, uint32_t idx) {
+  Stream* st = s->streams[idx].get();
+  if (!st || st->alive || !st->queued.empty() || st->in_batches || st->filling) return;
+  Klass& kl = s->klasses[st->klass];
+  for (size_t i = 0; i < kl.streams.size(); i++) {
+    if (kl.streams[i] != idx) continue;
+    kl.streams.erase(kl.streams.begin() + (long)i);
+    const uint32_t left = (uint32_t)kl.streams.size();
+    // the next batch still starts behind the stream served last (or, if that was this one, at its successor)
+    if (!left) kl.last = 0;
+    else if (kl.last >= i) kl.last = (kl.last + left - 1) % left;
+    break;
+  }
+  s->streams[idx].reset();
+  s->gen[idx] = (s->gen[idx] + 1) & ((1u << (32 - kIndexBits)) - 1);
+  s->free_ids.push_back(idx);
+}
+
+// table index of a stream handle, or -1 (unknown, reclaimed, or a stale handle of a reused index)
+long stream_index(const ufd_sched* s, uint32_t handle) {
+  const uint32_t idx = handle & kIndexMask;
+  if (idx >= s->streams.size() || !s->streams[idx] || s->gen[idx] != (handle >> kIndexBits)) return -1;
+  return (long)idx;
+}
+
 void dispatcher_main(ufd_sched* s) {
   std::unique_lock<std::mutex> lk(s->mu);
   for (;;) {
@@ -180,32 +220,41 @@ void dispatcher_main(ufd_sched* s) {
       s->inflight_of[vi]++;
       s->stats.batches++, s->stats.frames_in_batches += b->count;
       (b->why == 0 ? s->stats.sent_full : (b->why == 1 ? s->stats.sent_deadline : s->stats.sent_idle))++;
-      // the submit only queues the batch on the handle's worker: cheap enough to do under the lock
+      // The batch is detached from the stream queues: submit WITHOUT the scheduler lock (ufd_submit_* takes the handle's
+      // lock, which a ufd_wait of the completion thread may hold across its result copies -- pushes must not stall on that),
+      // and allocate its pinned output, if it has none yet, out here too (normally done at ufd_sched_add_stream).
+      struct {
+        ufd_model* model;
+        uint32_t annotate, quality, flags;
+        float label_w, label_h;
+      } kc = {kl.model, kl.annotate, kl.quality, kl.flags, kl.label_w, kl.label_h};
+      const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * std::max(s->max_batch[0], s->max_batch[1]);
+      lk.unlock();
       int rc;
-      if (kl.annotate) {
-        const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * s->max_batch[vi];
+      if (kc.annotate) {
         if (b->jpeg_cap < need) {
           if (b->jpeg_out) ufd_host_free(b->jpeg_out);
-          b->jpeg_out = static_cast<uint8_t*>(ufd_host_alloc(need));
+          b->jpeg_out = static_cast<uint8_t*>(ufd_model_host_alloc(kc.model, need));
           b->jpeg_cap = b->jpeg_out ? need : 0;
         }
         ufd_annotate a;
         std::memset(&a, 0, sizeof(a));
         a.struct_size = sizeof(a);
-        a.label_width = kl.label_w, a.label_height = kl.label_h;
-        a.quality = kl.quality, a.flags = kl.flags;
+        a.label_width = kc.label_w, a.label_height = kc.label_h;
+        a.quality = kc.quality, a.flags = kc.flags;
         a.jpeg_out = b->jpeg_out, a.jpeg_cap = b->jpeg_cap;
         a.jpeg_off = b->joff.data(), a.jpeg_len = b->jlen.data();
-        rc = ufd_submit_annotate_batch(kl.model, b->ptrs.data(), b->lens.data(), b->count, &a, b->dets.data(), s->cfg.det_cap,
+        rc = ufd_submit_annotate_batch(kc.model, b->ptrs.data(), b->lens.data(), b->count, &a, b->dets.data(), s->cfg.det_cap,
                                        b->n.data(), b->status.data(), &b->ticket);
       } else {
-        rc = ufd_submit_jpeg_batch(kl.model, b->ptrs.data(), b->lens.data(), b->count, b->dets.data(), s->cfg.det_cap, b->n.data(),
+        rc = ufd_submit_jpeg_batch(kc.model, b->ptrs.data(), b->lens.data(), b->count, b->dets.data(), s->cfg.det_cap, b->n.data(),
                                    b->status.data(), &b->ticket);
       }
       if (rc != UFD_OK) {  // nothing ran (all slots busy, bad handle): every frame of the batch reports the failure
         for (auto& st : b->status) st = rc;
         b->ticket = 0;
       }
+      lk.lock();
       s->inflight.push_back(b);
       sent = true;
     }
@@ -215,7 +264,7 @@ void dispatcher_main(ufd_sched* s) {
     }
     if (s->stop) {  // destroy: leave once everything queued has been dispatched
       bool empty = true;
-      for (const Stream& st : s->streams) empty = empty && st.queued.empty();
+      for (const auto& st : s->streams) empty = empty && (!st || st->queued.empty());
       if (empty) break;
     }
     if (wake == Clock::time_point::max()) s->cv_dispatch.wait(lk);
@@ -265,10 +314,11 @@ void completer_main(ufd_sched* s) {
     s->inflight.pop_front();
     s->inflight_of[variant_index(kl.variant)]--;
     for (uint32_t i = 0; i < b->count; i++) {
-      Stream& st = s->streams[b->stream[i]];
+      Stream& st = *s->streams[b->stream[i]];  // (alive or draining: an entry with frames in a batch is never reclaimed)
       st.free_.push_back(b->frame[i]);
       st.in_batches--;
     }
+    for (uint32_t i = 0; i < b->count; i++) reclaim_if_drained(s, b->stream[i]);  // removed streams whose last frames these were
     s->stats.delivered += b->count;
     s->free_batches.push_back(b);
     s->cv_dispatch.notify_all();
@@ -287,6 +337,7 @@ int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out) {
   s->cfg = *cfg;
   if (!s->cfg.ring_slots) s->cfg.ring_slots = 10;
   if (!s->cfg.max_wait_us) s->cfg.max_wait_us = 2000;
+  if (s->cfg.max_wait_us == UFD_SCHED_NO_WAIT) s->cfg.max_wait_us = 0;  // a batch leaves as soon as the model has a free slot
   if (!s->cfg.max_inflight) s->cfg.max_inflight = 6;
   s->cfg.max_inflight = std::min<uint32_t>(s->cfg.max_inflight, UFD_MAX_SLOTS);
   if (!s->cfg.det_cap) s->cfg.det_cap = 256;
@@ -327,7 +378,32 @@ int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* s
   if (vi < 0 || !(vi ? s->cfg.model_640 : s->cfg.model_320)) return UFD_E_ARG;
   const uint32_t quality = cfg->quality ? cfg->quality : 95;
   if (cfg->annotate && (quality < 1 || quality > 100)) return UFD_E_ARG;
+  // Pinned output of the batches an annotate class can have in flight: allocated now, on the model's device and without
+  // the scheduler lock -- not by the dispatcher in the middle of the stream (a first-use hipHostMalloc of tens of MB
+  // used to stall every push behind it).
+  std::vector<std::unique_ptr<Batch>> fresh;
+  if (cfg->annotate) {
+    const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * std::max(s->max_batch[0], s->max_batch[1]);
+    uint32_t have = 0;
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      for (auto& b : s->pool)
+        if (b->jpeg_cap >= need) have++;
+    }
+    ufd_model* model = vi ? s->cfg.model_640 : s->cfg.model_320;
+    for (; have < s->cfg.max_inflight; have++) {
+      std::unique_ptr<Batch> b(new Batch);
+      b->jpeg_out = static_cast<uint8_t*>(ufd_model_host_alloc(model, need));
+      if (!b->jpeg_out) break;  // (the dispatcher tries again for the batch that needs it)
+      b->jpeg_cap = need;
+      fresh.push_back(std::move(b));
+    }
+  }
   std::lock_guard<std::mutex> lk(s->mu);
+  for (auto& b : fresh) {
+    s->free_batches.push_back(b.get());
+    s->pool.push_back(std::move(b));
+  }
   int k = -1;
   for (size_t i = 0; i < s->klasses.size(); i++) {
     const Klass& c = s->klasses[i];
@@ -343,42 +419,68 @@ int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* s
     s->klasses.push_back(c);
     k = (int)s->klasses.size() - 1;
   }
-  s->streams.emplace_back();
-  Stream& st = s->streams.back();
+  uint32_t idx;
+  if (!s->free_ids.empty()) {
+    idx = s->free_ids.back();
+    s->free_ids.pop_back();
+  } else {
+    if (s->streams.size() > kIndexMask) return UFD_E_TOO_LARGE;
+    idx = (uint32_t)s->streams.size();
+    s->streams.emplace_back();
+    s->gen.push_back(0);
+  }
+  s->streams[idx].reset(new Stream);
+  Stream& st = *s->streams[idx];
   st.cfg = *cfg, st.alive = true, st.klass = k;
   for (uint32_t i = 0; i < s->cfg.ring_slots; i++) {
     st.slots.emplace_back(new Frame);
     st.free_.push_back(st.slots.back().get());
   }
-  *stream = (uint32_t)s->streams.size() - 1;
-  s->klasses[k].streams.push_back(*stream);
+  *stream = idx | (s->gen[idx] << kIndexBits);
+  s->klasses[k].streams.push_back(idx);
   return UFD_OK;
 }
 
 int ufd_sched_remove_stream(ufd_sched* s, uint32_t stream) {
   if (!s) return UFD_E_ARG;
   std::lock_guard<std::mutex> lk(s->mu);
-  if (stream >= s->streams.size() || !s->streams[stream].alive) return UFD_E_ARG;
-  Stream& st = s->streams[stream];
-  st.alive = false;  // frames already queued are still delivered; nothing new is accepted
+  const long idx = stream_index(s, stream);
+  if (idx < 0 || !s->streams[idx]->alive) return UFD_E_ARG;
+  s->streams[idx]->alive = false;  // frames already queued are still delivered; nothing new is accepted
+  reclaim_if_drained(s, (uint32_t)idx);  // (otherwise the completion thread reclaims it behind its last frame)
   return UFD_OK;
 }
 
 int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag) {
   if (!s || !jpeg || !len) return UFD_E_ARG;
+  Frame* f = nullptr;
+  long idx;
   {
     std::lock_guard<std::mutex> lk(s->mu);
-    if (s->stop || stream >= s->streams.size() || !s->streams[stream].alive) return UFD_E_STATE;
-    Stream& st = s->streams[stream];
+    idx = stream_index(s, stream);
+    if (s->stop || idx < 0 || !s->streams[idx]->alive) return UFD_E_STATE;
+    Stream& st = *s->streams[idx];
     s->stats.pushed++;
     if (st.free_.empty()) {  // router.rs:65: `if let Ok(mut frame) = self.infer_tx.try_send_ref()` -- else the frame is dropped
       s->stats.dropped++;
       return UFD_E_FULL;
     }
-    Frame* f = st.free_.back();
+    f = st.free_.back();
     st.free_.pop_back();
-    f->jpeg.assign(jpeg, jpeg + len);  // frame.2.clear(); frame.2.extend_from_slice(..) (router.rs:68-69)
-    f->tag = tag;
+    st.filling++;  // the slot is ours: the stream cannot be reclaimed while the copy below runs without the lock
+  }
+  f->jpeg.assign(jpeg, jpeg + len);  // frame.2.clear(); frame.2.extend_from_slice(..) (router.rs:68-69)
+  f->tag = tag;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    Stream& st = *s->streams[idx];
+    st.filling--;
+    if (!st.alive || s->stop) {  // removed (or the scheduler stopped) during the copy: as if the push had come too late
+      st.free_.push_back(f);
+      s->stats.pushed--;
+      reclaim_if_drained(s, (uint32_t)idx);
+      return UFD_E_STATE;
+    }
     f->pushed = Clock::now();
     st.queued.push_back(f);
   }
@@ -391,6 +493,16 @@ int ufd_sched_flush(ufd_sched* s) {
   std::unique_lock<std::mutex> lk(s->mu);
   const uint64_t target = s->stats.pushed - s->stats.dropped;
   s->cv_flush.wait(lk, [&] { return s->stats.delivered >= target; });
+  return UFD_OK;
+}
+
+int ufd_sched_debug_table(ufd_sched* s, uint32_t* live, uint32_t* allocated) {
+  if (!s) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  uint32_t n = 0;
+  for (const auto& st : s->streams) n += st ? 1u : 0u;
+  if (live) *live = n;
+  if (allocated) *allocated = (uint32_t)s->streams.size();
   return UFD_OK;
 }
 

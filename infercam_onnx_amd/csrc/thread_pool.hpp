@@ -12,8 +12,13 @@ namespace ufd {
 
 class ThreadPool {
  public:
-  explicit ThreadPool(unsigned n) {
-    for (unsigned i = 1; i < n; i++) workers_.emplace_back([this] { worker(); });
+  // on_start runs first in every worker thread (CPU affinity of the handle's NUMA node).
+  explicit ThreadPool(unsigned n, std::function<void()> on_start = nullptr) {
+    for (unsigned i = 1; i < n; i++)
+      workers_.emplace_back([this, on_start] {
+        if (on_start) on_start();
+        worker();
+      });
   }
   ~ThreadPool() {
     {

@@ -20,6 +20,10 @@ UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
 UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
+UFD_FLAG_NO_NUMA_PIN = 256
+UFD_MAX_REPLICAS = 64
+UFD_SCHED_NO_WAIT = 0xFFFFFFFF
+UFD_PARITY_EXACT, UFD_PARITY_LABELS_UNPINNED = 0, 1
 UFD_MAX_SLOTS = 8
 UFD_ANNOT_MULTIPART = 1
 UFD_ANNOT_NO_TEXT = 2
@@ -93,6 +97,7 @@ ABI_SYMBOLS = (
     "ufd_debug_draw_labels", "ufd_debug_encode_rgb", "ufd_model_limits",
     "ufd_sched_create", "ufd_sched_destroy", "ufd_sched_add_stream", "ufd_sched_remove_stream", "ufd_sched_push",
     "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
+    "ufd_create_replicas", "ufd_model_placement", "ufd_annotate_parity", "ufd_model_host_alloc", "ufd_sched_debug_table",
 )
 
 _lib = None
@@ -149,6 +154,12 @@ def load_library():
     L.ufd_debug_draw_labels.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_float, ctypes.c_float, u32]
     L.ufd_debug_encode_rgb.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, sz, ctypes.POINTER(sz)]
     L.ufd_model_limits.argtypes = [vp, pu32, pu32, pu32]
+    L.ufd_create_replicas.argtypes = [ctypes.POINTER(UfdConfig), ctypes.POINTER(i32), u32, ctypes.POINTER(vp)]
+    L.ufd_model_placement.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), pu32, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+    L.ufd_annotate_parity.argtypes = [u32]
+    L.ufd_model_host_alloc.argtypes = [vp, sz]
+    L.ufd_model_host_alloc.restype = vp
+    L.ufd_sched_debug_table.argtypes = [vp, pu32, pu32]
     L.ufd_sched_create.argtypes = [ctypes.POINTER(UfdSchedConfig), ctypes.POINTER(vp)]
     L.ufd_sched_destroy.argtypes = [vp]
     L.ufd_sched_destroy.restype = None
@@ -237,7 +248,7 @@ class UltrafaceModel(InferModel):
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
                  weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
                  device_entropy=False, host_entropy=False, tap_layers=False, no_chain=False, no_rfb_sum=False,
-                 no_stem_fuse=False):
+                 no_stem_fuse=False, no_numa_pin=False, _handle=None):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -245,17 +256,41 @@ class UltrafaceModel(InferModel):
         self.max_iou, self.min_confidence = float(max_iou), float(min_confidence)
         self.max_batch = int(max_batch)
         self.det_cap = int(det_cap)
+        if _handle is not None:  # a handle ufd_create_replicas made
+            h = _handle
+        else:
+            cfg, _keep = self._config(variant, max_iou, min_confidence, device_id=device_id, max_batch=max_batch, weights=weights,
+                                      priors=priors, weights_path=weights_path, max_src=max_src, host_threads=host_threads,
+                                      keep_layers=keep_layers, profile=profile, device_entropy=device_entropy,
+                                      host_entropy=host_entropy, tap_layers=tap_layers, no_chain=no_chain, no_rfb_sum=no_rfb_sum,
+                                      no_stem_fuse=no_stem_fuse, no_numa_pin=no_numa_pin)
+            h = ctypes.c_void_p()
+            rc = self._lib.ufd_create(ctypes.byref(cfg), ctypes.byref(h))
+            if rc != UFD_OK:
+                raise UfdError(rc, (self._lib.ufd_last_error(None) or b"").decode())
+        self._h = h
+        k = ctypes.c_uint32()
+        self._lib.ufd_model_info(h, None, None, ctypes.byref(k))
+        self.num_priors = k.value
+        self._pending = {}
+
+    @staticmethod
+    def _config(variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None, weights_path=None,
+                max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, device_entropy=False, host_entropy=False,
+                tap_layers=False, no_chain=False, no_rfb_sum=False, no_stem_fuse=False, no_numa_pin=False):
+        """ufd_config of UltrafaceModel::new's arguments; returns (cfg, arrays the cfg points into)."""
         cfg = UfdConfig()
         cfg.struct_size = ctypes.sizeof(UfdConfig)
         cfg.variant = variant.value
-        cfg.max_iou, cfg.min_confidence = self.max_iou, self.min_confidence
-        cfg.device_id, cfg.max_batch = int(device_id), self.max_batch
+        cfg.max_iou, cfg.min_confidence = float(max_iou), float(min_confidence)
+        cfg.device_id, cfg.max_batch = int(device_id), int(max_batch)
         cfg.max_src_width, cfg.max_src_height = int(max_src[0]), int(max_src[1])
         cfg.host_threads = int(host_threads)
         cfg.flags = ((UFD_FLAG_KEEP_LAYERS if keep_layers else 0) | (UFD_FLAG_PROFILE if profile else 0) |
                      (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0) |
                      (UFD_FLAG_TAP_LAYERS if tap_layers else 0) | (UFD_FLAG_NO_CHAIN if no_chain else 0) |
-                     (UFD_FLAG_NO_RFB_SUM if no_rfb_sum else 0) | (UFD_FLAG_NO_STEM_FUSE if no_stem_fuse else 0))
+                     (UFD_FLAG_NO_RFB_SUM if no_rfb_sum else 0) | (UFD_FLAG_NO_STEM_FUSE if no_stem_fuse else 0) |
+                     (UFD_FLAG_NO_NUMA_PIN if no_numa_pin else 0))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()
@@ -266,16 +301,31 @@ class UltrafaceModel(InferModel):
                 keep.append(p)
                 cfg.priors, cfg.priors_floats = p.ctypes.data, p.size
         elif weights_path is not None:
-            cfg.weights_path = os.fsencode(weights_path)
-        h = ctypes.c_void_p()
-        rc = self._lib.ufd_create(ctypes.byref(cfg), ctypes.byref(h))
+            keep.append(os.fsencode(weights_path))
+            cfg.weights_path = keep[-1]
+        return cfg, keep
+
+    @classmethod
+    def create_replicas(cls, variant, max_iou, min_confidence, device_ids, *, det_cap=1024, **kw):
+        """One handle per GPU of `device_ids` from ONE process (ufd_create_replicas): the weight source is read once,
+        device_ids[0]'s packed image is broadcast to the others over RCCL.  Returns [UltrafaceModel] in device order."""
+        lib = load_library()
+        cfg, _keep = cls._config(variant, max_iou, min_confidence, **kw)
+        ids = (ctypes.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        hs = (ctypes.c_void_p * max(len(device_ids), 1))()
+        rc = lib.ufd_create_replicas(ctypes.byref(cfg), ids, len(device_ids), hs)
         if rc != UFD_OK:
-            raise UfdError(rc, (self._lib.ufd_last_error(None) or b"").decode())
-        self._h = h
-        k = ctypes.c_uint32()
-        self._lib.ufd_model_info(h, None, None, ctypes.byref(k))
-        self.num_priors = k.value
-        self._pending = {}
+            raise UfdError(rc, (lib.ufd_last_error(None) or b"").decode())
+        return [cls(variant, max_iou, min_confidence, max_batch=kw.get("max_batch", 1), det_cap=det_cap,
+                    _handle=ctypes.c_void_p(hs[i])) for i in range(len(device_ids))]
+
+    def placement(self):
+        """Where the handle lives: {device_id, pci, numa_node, pinned_cpus, cpu_list} (ufd_model_placement)."""
+        dev, node, n = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint32()
+        pci, cpus = ctypes.create_string_buffer(64), ctypes.create_string_buffer(1024)
+        self._check(self._lib.ufd_model_placement(self._h, ctypes.byref(dev), ctypes.byref(node), ctypes.byref(n), pci, 64, cpus, 1024))
+        return {"device_id": dev.value, "pci": pci.value.decode(), "numa_node": node.value, "pinned_cpus": n.value,
+                "cpu_list": cpus.value.decode()}
 
     # -- lifetime
     def close(self):

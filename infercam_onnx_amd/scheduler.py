@@ -83,6 +83,12 @@ class Scheduler:
     def flush(self):
         self._lib.ufd_sched_flush(self._h)
 
+    def table(self):
+        """(stream-table entries in use, entries ever allocated): flat under add / remove churn."""
+        live, alloc = ctypes.c_uint32(), ctypes.c_uint32()
+        self._lib.ufd_sched_debug_table(self._h, ctypes.byref(live), ctypes.byref(alloc))
+        return live.value, alloc.value
+
     def stats(self):
         st = nn.UfdSchedStats()
         self._lib.ufd_sched_get_stats(self._h, ctypes.byref(st))

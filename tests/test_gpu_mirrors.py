@@ -184,3 +184,69 @@ def test_concurrent_callers_on_one_handle(weights):
         assert not errors, errors
     finally:
         m.close()
+
+
+def test_create_replicas_runs_the_rccl_broadcast(tmp_path, oracle_lib, weights):
+    """ufd_create_replicas from a plain C++ host process (tests/cpp/replicas_test.cpp: no Python, no torch -- the
+    environment of the reference's one Rust binary) on every GPU of this box: ncclCommInitAll + ncclBroadcast of the packed
+    weight image and the priors really execute (a one-GPU box forms a one-rank communicator; with more GPUs every other
+    handle's weights exist ONLY through the broadcast, since it is created from a zero blob), and every replica gives the
+    oracle's detections.  (In-process after `import torch` this would mix torch's bundled ROCm runtime with the system one
+    RCCL is loaded from, which RCCL's start-up does not survive: hence the separate process.)"""
+    from infercam_onnx_amd import nn, synth
+
+    W, H = 320, 240
+    pri = synth.gen_priors(W, H)
+    exe = str(tmp_path / "replicas_test")
+    lib_dir = os.path.join(ROOT, "infercam_onnx_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "replicas_test.cpp"),
+                           "-o", exe, "-L" + lib_dir, "-lufacehip", "-Wl,-rpath," + lib_dir])
+    wfile, jfile = str(tmp_path / "w.f32"), str(tmp_path / "f.jpg")
+    np.asarray(weights, np.float32).tofile(wfile)
+    jpeg = synth.encode_jpeg(synth.synth_frame(synth.DEFAULT_FRAME_SEED, 2, W, H))
+    open(jfile, "wb").write(jpeg)
+    out = subprocess.run([exe, wfile, jfile, "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    ref = oracle_lib.infer_jpeg(jpeg, W, H, weights, pri, 0.5, 0.5)
+    assert len(ref) > 0
+    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("replica ")]
+    assert len(lines) >= 1
+    for l in lines:
+        cnt = int(l[11])
+        got = np.array([float(v) for v in l[12:]], np.float32).reshape(cnt, 5)
+        assert_dets_match(got, ref, what="replica " + l[1])
+        assert l[5].count(":") == 2  # pci address
+    # with a device present, ids out of range / listed twice are still refused (argument checks: tests/test_host_logic.py)
+    for bad in ([len(lines)], [0, 0], [-1]):
+        with pytest.raises(nn.UfdError) as e:
+            nn.UltrafaceModel.create_replicas(nn.UltrafaceVariant.W320H240, 0.5, 0.5, bad, weights=weights, priors=pri)
+        assert e.value.code == nn.UFD_E_ARG
+
+
+def test_numa_pinning_follows_the_gpu_and_can_be_switched_off(weights):
+    """Host placement: the handle reports its PCI address and NUMA node; when the node is known its host threads are
+    pinned to that node's CPUs inside the process's affinity mask (never to a CPU outside it); UFD_FLAG_NO_NUMA_PIN
+    pins nothing.  Results do not depend on it."""
+    from infercam_onnx_amd import nn, synth
+
+    pri = synth.gen_priors(320, 240)
+    jpeg = synth.encode_jpeg(synth.synth_frame(3, 3, 320, 240))
+    allowed = os.sched_getaffinity(0)
+    res = []
+    for off in (False, True):
+        with nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights, priors=pri, no_numa_pin=off) as m:
+            pl = m.placement()
+            res.append(dets_array(m.infer_jpeg(jpeg)))
+            assert pl["pci"].count(":") == 2, pl
+            if off or pl["numa_node"] < 0:
+                assert pl["pinned_cpus"] == 0 and pl["cpu_list"] == ""
+            elif pl["pinned_cpus"]:  # (0: the node's CPUs and this process's affinity mask do not intersect)
+                cpus = set()
+                for part in pl["cpu_list"].split(","):
+                    a, _, b = part.partition("-")
+                    cpus |= set(range(int(a), int(b or a) + 1))
+                assert len(cpus) == pl["pinned_cpus"] and cpus <= allowed
+                node_cpus = open("/sys/devices/system/node/node%d/cpulist" % pl["numa_node"]).read().strip()
+                assert node_cpus  # the node the kernel reports for the GPU exists
+    assert np.array_equal(res[0], res[1])
+    assert os.sched_getaffinity(0) == allowed  # the CALLER's thread is never re-pinned

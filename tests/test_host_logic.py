@@ -199,3 +199,47 @@ def test_host_parsers_clean_under_asan_ubsan():
         pytest.skip("no g++")
     r = subprocess.run([os.path.join(ROOT, "tools", "fuzz", "run_host_fuzz.sh"), "30", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_create_replicas_argument_and_error_paths(weights):
+    """ufd_create_replicas (one process, one handle per GPU, RCCL broadcast of the packed weights): every refusal leaves
+    out[] NULL and says why.  Argument checks come before any device or RCCL work, so they run without a GPU."""
+    import ctypes
+    import torch
+    from infercam_onnx_amd import nn
+
+    L = nn.load_library()
+    V = nn.UltrafaceVariant.W320H240
+
+    def call(ids, n=None, cfg_mut=None, pass_cfg=True, pass_out=True):
+        cfg, keep = nn.UltrafaceModel._config(V, 0.5, 0.5, weights=weights)
+        if cfg_mut:
+            cfg_mut(cfg)
+        arr = (ctypes.c_int32 * max(len(ids), 1))(*ids)
+        out = (ctypes.c_void_p * 70)(*([0xDEAD] * 70))
+        rc = L.ufd_create_replicas(ctypes.byref(cfg) if pass_cfg else None, arr, len(ids) if n is None else n,
+                                   out if pass_out else None)
+        return rc, (L.ufd_last_error(None) or b"").decode(), out
+
+    rc, msg, _ = call([0], pass_cfg=False)
+    assert rc == nn.UFD_E_ARG and "null" in msg
+    rc, msg, _ = call([0], pass_out=False)
+    assert rc == nn.UFD_E_ARG
+    rc, msg, out = call([0], n=0)
+    assert rc == nn.UFD_E_ARG and "1..64" in msg
+    rc, msg, out = call([0] * 65)
+    assert rc == nn.UFD_E_ARG and "1..64" in msg
+    rc, msg, out = call([0, 1, 0])
+    assert rc == nn.UFD_E_ARG and "listed twice" in msg and all(out[i] is None for i in range(3))
+    rc, msg, _ = call([0], cfg_mut=lambda c: setattr(c, "variant", 512))
+    assert rc == nn.UFD_E_ARG and "variant" in msg
+    rc, msg, _ = call([0], cfg_mut=lambda c: setattr(c, "struct_size", 8))
+    assert rc == nn.UFD_E_ARG and "struct_size" in msg
+    if torch.cuda.device_count() == 0:
+        rc, msg, out = call([0, 1])
+        assert rc == nn.UFD_E_DEVICE and "no CPU fallback" in msg and out[0] is None and out[1] is None
+        with pytest.raises(nn.UfdError) as e:
+            nn.UltrafaceModel.create_replicas(V, 0.5, 0.5, [0, 1], weights=weights)
+        assert e.value.code == nn.UFD_E_DEVICE
+    assert L.ufd_annotate_parity(0) == nn.UFD_PARITY_LABELS_UNPINNED
+    assert L.ufd_annotate_parity(nn.UFD_ANNOT_NO_TEXT | nn.UFD_ANNOT_MULTIPART) == nn.UFD_PARITY_EXACT

@@ -142,3 +142,97 @@ def test_full_ring_drops_the_new_frame_and_lone_frames_do_not_wait(weights):
     finally:
         m320.close()
         m640.close()
+
+
+@gpu
+def test_reconnecting_cameras_do_not_grow_the_scheduler(oracle_lib, weights):
+    """Cameras that reconnect (the reference's use case: socket_sender.rs:53-59 retries every 3 s): 1000 streams are added,
+    push a frame and are removed, a few at a time.  Every frame is delivered with the oracle's detections, the stream
+    table stays as small as the number of streams alive at once (entries are reused), dispatch stays as fast at the end as
+    at the start, and a handle of a removed stream is refused instead of reaching the stream that reused its entry."""
+    from infercam_onnx_amd import nn, synth
+
+    m320, m640 = _models(weights)
+    got = {}
+    jpegs = [synth.encode_jpeg(synth.synth_frame(41, i, 320, 240)) for i in range(4)]
+    pri = synth.gen_priors(320, 240)
+    refs = [oracle_lib.infer_jpeg(j, 320, 240, weights, pri, 0.5, 0.5) for j in jpegs]
+    try:
+        with scheduler.Scheduler(model_320=m320, model_640=m640, on_result=lambda r: got.__setitem__(r["tag"], r),
+                                 max_wait_us=nn.UFD_SCHED_NO_WAIT) as sch:
+            keeper = sch.add_stream(stream_id=999_999, variant=320)  # a stream that stays: its class survives the churn
+            handles, first_old = [], None
+            t_first = t_last = 0.0
+            for i in range(1000):
+                t0 = time.perf_counter()
+                h = sch.add_stream(stream_id=i, variant=320)
+                assert sch.push(h, jpegs[i % 4], tag=i)
+                handles.append(h)
+                if len(handles) == 4:  # four alive at once, then all four leave
+                    for x in handles:
+                        assert sch.remove_stream(x) == 0
+                    sch.flush()
+                    first_old = first_old if first_old is not None else handles[0]
+                    handles = []
+                dt = time.perf_counter() - t0
+                if i < 100:
+                    t_first += dt
+                if i >= 900:
+                    t_last += dt
+            sch.flush()
+            live, allocated = sch.table()
+            assert live == 1 and allocated <= 8, (live, allocated)  # the keeper; entries were reused, not appended
+            assert t_last < 3 * t_first + 0.05, (t_first, t_last)   # no walk over 1000 dead streams per dispatch
+            # a stale handle: refused (UFD_E_STATE on push, UFD_E_ARG on remove), never the stream that reused the entry
+            with pytest.raises(nn.UfdError) as e:
+                sch.push(first_old, jpegs[0], tag=5555)
+            assert e.value.code == nn.UFD_E_STATE and sch.remove_stream(first_old) == nn.UFD_E_ARG
+            assert sch.push(keeper, jpegs[0], tag=7777)
+            sch.flush()
+            st = sch.stats()
+            assert st["delivered"] == 1001 and st["dropped"] == 0
+        assert sorted(got) == list(range(1000)) + [7777]
+        for i in list(range(0, 1000, 37)) + [7777]:
+            r = got[i]
+            assert r["status"] == 0 and r["stream_id"] == (999_999 if i == 7777 else i)
+            ref = refs[0 if i == 7777 else i % 4]
+            assert len(r["dets"]) == min(len(ref), 256)
+            if len(ref):
+                assert np.abs(np.array([list(b) + [c] for b, c in r["dets"]], np.float32) - ref[:256]).max() <= 1e-4
+    finally:
+        m320.close()
+        m640.close()
+
+
+@gpu
+def test_annotate_classes_of_one_model_alternate_without_losing_streams(oracle_lib, weights):
+    """Two annotate streams on one model that differ in quality and framing (two batch classes, one handle): their
+    batches alternate on the handle's contexts, each context keeps both encoder set-ups resident, and every stream gets
+    its own quality's byte-exact JPEG."""
+    import oracle
+    from infercam_onnx_amd import synth
+
+    m320, m640 = _models(weights)
+    got = []
+    jpegs = [synth.encode_jpeg(synth.synth_frame(43, i, 320, 240)) for i in range(6)]
+    try:
+        with scheduler.Scheduler(model_320=m320, model_640=m640, on_result=got.append) as sch:
+            a = sch.add_stream(stream_id=1, variant=320, annotate=True, label_size=(320, 240), quality=95)
+            b = sch.add_stream(stream_id=2, variant=320, annotate=True, label_size=(320, 240), quality=80, multipart=True)
+            for rnd in range(4):
+                for i, j in enumerate(jpegs):
+                    assert sch.push(a if (i + rnd) % 2 else b, j, tag=rnd * 100 + i)
+                sch.flush()
+        assert len(got) == 24
+        for r in got:
+            assert r["status"] == 0 and r["jpeg"]
+            j = jpegs[r["tag"] % 100]
+            dets = np.array([list(bb) + [c] for bb, c in r["dets"]], np.float32).reshape(-1, 5)
+            frame = oracle.draw_labels(oracle.jpeg_decode_rgb(j), dets, 320, 240)
+            want = oracle.jpeg_encode_rgb(frame, 95 if r["stream_id"] == 1 else 80)
+            if r["stream_id"] == 2:
+                want = oracle.stream_item(want)
+            assert r["jpeg"] == want, (r["stream_id"], r["tag"])
+    finally:
+        m320.close()
+        m640.close()
