@@ -24,8 +24,12 @@ constexpr int kNmsBlock = 256;            // candidates per greedy block (4 x 64
 // by one wave per frame (k_nms_scan).  Inside k_sort_nms the quadratic work of such a frame runs on
 // ONE compute unit and set the latency of the whole batch (1359 candidates: 380 us).
 constexpr int kMatMin = 256;              // frames with more candidates than this take the matrix path
-constexpr int kMatMax = 2048;             // = kSortLds: the sorted keys of such a frame are in LDS
+constexpr int kMatHalf = 2048;            // the scan walks the matrix in halves of this many rows / columns
+constexpr int kMatMax = 4096;             // frames up to this many candidates take it: their keys are sorted in LDS (kSortLdsHeavy)
 constexpr int kMatWords = kMatMax / 64;   // 64-bit words per matrix row
+constexpr int kHalfWords = kMatHalf / 64;
+constexpr int kSortLdsHeavy = 4096;       // a frame with more than kSortLds candidates leaves for the matrix path after its
+                                          // sort: the LDS of the greedy phase (selected boxes, block rows) holds its keys instead
 constexpr uint32_t kHeavyFlag = 0x80000000u;  // ndet[frame] = kHeavyFlag | n between the kernels
 
 __device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
@@ -103,21 +107,29 @@ __device__ __forceinline__ float bbox_area(float x0, float y0, float x1, float y
   return __fmul_rn(width, height);
 }
 
-// descending bitonic sort of n2 (power of two) keys by one workgroup
-// Bitonic sort, descending.  Pair t of a stage with stride s is (lo, lo + s), lo = 2t - (t & (s-1)):
-// for s <= 64 the 64 pairs of a wave (t = 64w .. 64w+63, every pass of the t loop) stay inside one
-// 128-key chunk that no other wave touches, so those stages need no workgroup barrier -- only the
-// wave's own LDS/global accesses in order.  A 2048-key sort has 10 barrier stages instead of 66
-// (a barrier of 16 waves costs ~0.5-1 us: the sort was most of the kernel).
-__device__ void bitonic_desc(unsigned long long* keys, int n2, int tid, int nthreads, bool in_lds) {
-  for (int size = 2; size <= n2; size <<= 1) {
+// Bitonic sort by one workgroup: every block of `top` keys (a power of two <= n2, itself a power of two) ends up sorted
+// descending.  Pair t of a stage with stride s is (lo, lo + s), lo = 2t - (t & (s-1)).  In LDS a wave owns a CONTIGUOUS
+// run of pairs, i.e. a chunk of 128 * iters keys: a stage with 2s <= chunk touches only the wave's own chunk and needs no
+// workgroup barrier -- only the wave's own LDS accesses in order -- unless the stage before it crossed chunks.  A 2048-key
+// sort has 10 barrier stages instead of 66, the 1024-key blocks of a 4096-key frame 5 (a barrier of 16 waves costs
+// ~0.5-1 us: the sort was most of the kernel).
+__device__ void bitonic_desc(unsigned long long* keys, int n2, int top, int tid, int nthreads, bool in_lds) {
+  const int pairs = n2 >> 1, lane = tid & 63, wave = tid >> 6;
+  const int iters = max(1, pairs / nthreads);
+  const int chunk = in_lds ? iters * 128 : 0;
+  bool prev_cross = true;
+  for (int size = 2; size <= top; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride >= 64 || !in_lds) __syncthreads();              // pairs cross the waves' chunks (64: the stage before did)
+      const bool cross = 2 * stride > chunk;
+      if (cross || prev_cross) __syncthreads();
       else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // own stores before own loads
-      for (int t = tid; t < (n2 >> 1); t += nthreads) {
+      prev_cross = cross;
+      for (int p = 0; p < iters; p++) {
+        const int t = in_lds ? (wave * iters + p) * 64 + lane : tid + p * nthreads;
+        if (t >= pairs) break;
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
-        const bool desc = (lo & size) == 0;
+        const bool desc = size == top || (lo & size) == 0;
         const unsigned long long a = keys[lo], b = keys[hi];
         if ((a < b) == desc) {
           keys[lo] = b;
@@ -152,12 +164,18 @@ __device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const 
 __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
                                                   uint32_t* __restrict__ counts, const float* __restrict__ boxes,
                                                   int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
-                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min) {
-  __shared__ unsigned long long s_keys[kSortLds];
-  __shared__ float4 s_sel[kSelLds];
-  __shared__ float4 s_cand[kNmsBlock];
-  __shared__ float4 s_box[kBoxLds];
-  __shared__ unsigned long long s_row[kNmsBlock][kNmsBlock / 64];  // row i: later candidates of the block that i suppresses
+                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min, int mat_max) {
+  // One 40 KB block of LDS, carved twice.  Greedy path (frames the kernel finishes itself): 2048 sort keys | selected
+  // boxes | the block's candidates | gathered boxes | block rows.  A frame with 2049..4096 candidates only sorts here
+  // (it leaves for the matrix path): its 4096 key slots lie over the first four pieces, which it never uses.
+  constexpr int kRawWords = kSortLds + 2 * kSelLds + 2 * kNmsBlock + 2 * kBoxLds + kNmsBlock * (kNmsBlock / 64);
+  static_assert(kRawWords >= kSortLdsHeavy, "the heavy sort's keys must fit the greedy phase's LDS");
+  __shared__ __attribute__((aligned(16))) unsigned long long s_raw[kRawWords];
+  unsigned long long* const s_keys = s_raw;
+  float4* const s_sel = reinterpret_cast<float4*>(s_raw + kSortLds);
+  float4* const s_cand = s_sel + kSelLds;
+  float4* const s_box = s_cand + kNmsBlock;
+  unsigned long long(*const s_row)[kNmsBlock / 64] = reinterpret_cast<unsigned long long(*)[kNmsBlock / 64]>(s_box + kBoxLds);
   __shared__ unsigned long long s_dead[kNmsBlock / 64], s_keep[kNmsBlock / 64];
   __shared__ int s_nsel;
   const int frame = blockIdx.x;
@@ -168,7 +186,8 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
   unsigned long long* keys;
-  if (n2 <= kSortLds) {
+  const bool heavy = n > mat_min && n <= mat_max;  // finished by k_nms_matrix / k_nms_scan
+  if (n2 <= kSortLds || (heavy && n2 <= kSortLdsHeavy)) {
     for (int i = tid; i < n2; i += nthr) s_keys[i] = i < n ? fkeys[i] : 0ull;
     keys = s_keys;
   } else {
@@ -180,17 +199,46 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   // every thread has read the frame's candidate count: leave it at zero for the next batch's k_head_decode / k_threshold
   // (the counters are zero whenever no batch is between those kernels and this one: no memset launch per batch)
   if (tid == 0) counts[frame] = 0;
-  if (n > 1) bitonic_desc(keys, n2, tid, nthr, keys == s_keys);
+  // (a frame of 2049..4096 candidates: its four 1024-key blocks only -- they are merged by rank on the way out)
+  const bool merge4 = heavy && n2 > kSortLds;
+  if (n > 1) bitonic_desc(keys, n2, merge4 ? kSortLds / 2 : n2, tid, nthr, keys == s_keys);
   const float4* fb = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
   float4* fspill = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
-  if (n > mat_min && n <= kMatMax) {
+  if (heavy) {
     // sorted keys and boxes for k_nms_matrix / k_nms_scan (the spill area is free: it only holds
     // selected boxes of the in-kernel path)
-    for (int i = tid; i < n; i += nthr) {
-      const unsigned long long key = keys[i];
-      fkeys[i] = key;
-      fspill[i] = fb[(int)(key & 0xffffffffull) - 1];
+    if (merge4) {
+      // Four sorted 1024-key blocks -> the frame's order: a key's rank is its place in its own block plus, per other
+      // block, the number of keys there that precede it (keys are distinct: confidence bits | prior index), found by
+      // binary search -- 30 LDS reads per key instead of 23 more sort stages with 11 barriers.  Padding keys (0) sort
+      // last in their block and precede nothing.
+      constexpr int CB = kSortLds / 2;  // 1024
+      for (int e = tid; e < n2; e += nthr) {
+        const unsigned long long key = keys[e];
+        if (!key) continue;
+        const int c = e / CB;
+        int rank = e - c * CB;
+        for (int o = 0; o < n2 / CB; o++) {
+          if (o == c) continue;
+          const unsigned long long* blk = keys + o * CB;
+          int lo = 0, hi = CB;  // first position whose key is smaller = number of keys greater
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (blk[mid] > key) lo = mid + 1;
+            else hi = mid;
+          }
+          rank += lo;
+        }
+        fkeys[rank] = key;
+        fspill[rank] = fb[(int)(key & 0xffffffffull) - 1];
+      }
+    } else {
+      for (int i = tid; i < n; i += nthr) {
+        const unsigned long long key = keys[i];
+        fkeys[i] = key;
+        fspill[i] = fb[(int)(key & 0xffffffffull) - 1];
+      }
     }
     if (tid == 0) ndet[frame] = kHeavyFlag | (uint32_t)n;
     return;
@@ -321,73 +369,78 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
 // Suppression matrix of a heavy frame: bit j of row i (i < j, sorted order) = "i, once selected,
 // suppresses j".  Block (rb, cg) = 64 rows x 4 column words, one word per wave, lane = row; every
 // test is iou_exceeds(candidate j, selected i), the in-kernel path's call.
-constexpr int kMatColGroups = kMatWords / 4;
+// A frame with more than kMatHalf candidates has four times the blocks: the grid covers all its row blocks but only the
+// column groups of one half (most batches have no such frame, and every block of the grid is launched for every frame:
+// 4.6 us for the 8192 blocks of a batch that leave at once), and a block of such a frame walks the column halves.
+constexpr int kMatColGroups = kHalfWords / 4;
 __global__ __launch_bounds__(256) void k_nms_matrix(const uint32_t* __restrict__ ndet, const float4* __restrict__ spill, int K,
                                                     float max_iou, unsigned long long* __restrict__ mat) {
   __shared__ float4 s_col[4][64];
   __shared__ float s_area[4][64];
-  const int frame = blockIdx.z, rb = blockIdx.x, cg = blockIdx.y;
+  const int frame = blockIdx.z;
   const uint32_t flag = ndet[frame];
   if (!(flag & kHeavyFlag)) return;
   const int n = (int)(flag & ~kHeavyFlag);
-  if (rb * 64 >= n || cg * 4 + 3 < rb || cg * 256 >= n) return;  // past the end / below the diagonal
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float4* fsp = spill + (size_t)frame * K;
-  const int cb = cg * 4 + wave;  // this wave's column word
-  {
-    const int j = min(cb * 64 + lane, n - 1);
-    const float4 b = fsp[j];
-    s_col[wave][lane] = b;
-    s_area[wave][lane] = bbox_area(b.x, b.y, b.z, b.w);
+  const int quads = n > kMatHalf ? 2 : 1;
+  const int rb = (int)blockIdx.x;
+  if (rb * 64 >= n) return;
+  for (int cq = rb / kHalfWords; cq < quads; cq++) {  // (the column half left of the row's own is below the diagonal)
+      const int cg = (int)blockIdx.y + kMatColGroups * cq;
+      if (cg * 4 + 3 < rb || cg * 256 >= n) continue;  // below the diagonal / past the end (block-uniform)
+      const int cb = cg * 4 + wave;  // this wave's column word
+      {
+        const int j = min(cb * 64 + lane, n - 1);
+        const float4 b = fsp[j];
+        s_col[wave][lane] = b;
+        s_area[wave][lane] = bbox_area(b.x, b.y, b.z, b.w);
+      }
+      const int i = rb * 64 + lane;
+      const float4 bi = fsp[min(i, n - 1)];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave reads only its own s_col / s_area row
+      if (cb >= rb && cb * 64 < n) {
+        unsigned long long word = 0ull;
+        const int jn = min(64, n - cb * 64);
+        for (int b = 0; b < jn; b++) {
+          const int j = cb * 64 + b;
+          const bool hit = iou_exceeds(s_col[wave][b], s_area[wave][b], bi, max_iou);  // (wave-uniform j: the ballot inside sees all rows)
+          word |= (hit && j > i) ? (1ull << b) : 0ull;
+        }
+        if (i < n) mat[((size_t)frame * kMatMax + i) * kMatWords + cb] = word;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // own reads of s_col before the next column half's stores
   }
-  const int i = rb * 64 + lane;
-  const float4 bi = fsp[min(i, n - 1)];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave reads only its own s_col / s_area row
-  if (cb < rb || cb * 64 >= n) return;
-  unsigned long long word = 0ull;
-  const int jn = min(64, n - cb * 64);
-  for (int b = 0; b < jn; b++) {
-    const int j = cb * 64 + b;
-    const bool hit = iou_exceeds(s_col[wave][b], s_area[wave][b], bi, max_iou);  // (wave-uniform j: the ballot inside sees all rows)
-    word |= (hit && j > i) ? (1ull << b) : 0ull;
-  }
-  if (i < n) mat[((size_t)frame * kMatMax + i) * kMatWords + cb] = word;
 }
 
 // Greedy pass over the matrix, exactly the reference's order (nn.rs:198-224): candidate i is
-// selected iff no selected earlier candidate has its bit set.  One wave per frame walks the 64-row
-// blocks; the removed-mask is spread over the lanes (lanes l and l + 32 both hold word l), a block's
+// selected iff no selected earlier candidate has its bit set.  One wave walks the 64-row blocks of a
+// HALF of the matrix (rows row0 .. row0 + 2047, words word0 .. word0 + 31: the square on the diagonal);
+// the removed-mask is spread over the lanes (lanes l and l + 32 both hold word word0 + l), a block's
 // rows arrive two per load instruction (lane = row parity x word) and are prefetched one block
-// ahead in registers; no LDS, no barrier.
-__global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __restrict__ gkeys, size_t key_stride,
-                                                 const float4* __restrict__ spill, int K, const unsigned long long* __restrict__ mat,
-                                                 Det* __restrict__ dets, uint32_t det_stride, uint32_t* __restrict__ ndet) {
-  static_assert(kMatWords == 32, "lane = (row parity, word) layout");
-  const int frame = blockIdx.x;
-  const uint32_t flag = ndet[frame];
-  if (!(flag & kHeavyFlag)) return;
-  const int n = (int)(flag & ~kHeavyFlag);
-  const int lane = threadIdx.x, half = lane >> 5, word = lane & 31;
-  const int nrb = (n + 63) >> 6;
-  const unsigned long long* fmat = mat + (size_t)frame * kMatMax * kMatWords;
-  const unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
-  const float4* fsp = spill + (size_t)frame * K;
-  Det* fd = dets + (size_t)frame * det_stride;
+// ahead in registers; no LDS, no barrier.  Returns the number of selected candidates so far.
+__device__ __forceinline__ int nms_scan_half(const unsigned long long* __restrict__ fmat, int n, int row0, int word0,
+                                             unsigned long long removed, const unsigned long long* __restrict__ fkeys,
+                                             const float4* __restrict__ fsp, Det* __restrict__ fd, uint32_t det_stride, int nsel,
+                                             unsigned long long* s_kept /* kept mask per row block, or null */,
+                                             int* s_progress /* row blocks published in s_kept */) {
+  static_assert(kHalfWords == 32, "lane = (row parity, word) layout");
+  const int lane = threadIdx.x & 63, half = lane >> 5, word = lane & 31;
+  const int nl = min(n - row0, kMatHalf);  // rows of this half
+  const int nrb = (nl + 63) >> 6;
   unsigned long long rows[32], rows_next[32], diag, diag_next;
   // rows 2q + half of block rb, word `word`; the diagonal word of row `lane` (rows past n and words
   // below the diagonal were never written: loaded from clamped rows and masked where they are used)
   auto load_block = [&](int rb, unsigned long long (&r)[32], unsigned long long& d) {
     const int rbc = min(rb, nrb - 1);
 #pragma unroll
-    for (int q = 0; q < 32; q++) r[q] = fmat[(size_t)min(rbc * 64 + 2 * q + half, n - 1) * kMatWords + word];
-    d = fmat[(size_t)min(rbc * 64 + lane, n - 1) * kMatWords + rbc];
+    for (int q = 0; q < 32; q++) r[q] = fmat[(size_t)(row0 + min(rbc * 64 + 2 * q + half, nl - 1)) * kMatWords + word0 + word];
+    d = fmat[(size_t)(row0 + min(rbc * 64 + lane, nl - 1)) * kMatWords + word0 + rbc];
   };
   load_block(0, rows, diag);
-  unsigned long long removed = 0ull;
-  int nsel = 0;
   for (int rb = 0; rb < nrb; rb++) {
     load_block(rb + 1, rows_next, diag_next);
-    const int cnt = min(64, n - rb * 64);
+    const int cnt = min(64, nl - rb * 64);
     const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
     const uint32_t rm_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)removed, rb);
     const uint32_t rm_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(removed >> 32), rb);
@@ -411,6 +464,10 @@ __global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __res
                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dlo, b);
       alive &= ~(row | upto);
     }
+    if (s_kept && lane == 0) {  // the folding waves pick the block up while this wave goes on
+      s_kept[rb] = kept;
+      __hip_atomic_store(s_progress, rb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // the kept rows' later words join the mask
     const unsigned long long kh = kept >> half;  // bit 2q = row 2q + half
     unsigned long long acc = 0ull;
@@ -422,9 +479,9 @@ __global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __res
     if ((kept >> lane) & 1ull) {
       const int pos = nsel + __popcll(kept & ((1ull << lane) - 1ull));
       if ((uint32_t)pos < det_stride) {
-        const float4 cc = fsp[rb * 64 + lane];
+        const float4 cc = fsp[row0 + rb * 64 + lane];
         Det dd;
-        dd.x_tl = cc.x, dd.y_tl = cc.y, dd.x_br = cc.z, dd.y_br = cc.w, dd.conf = key_conf(fkeys[rb * 64 + lane]);
+        dd.x_tl = cc.x, dd.y_tl = cc.y, dd.x_br = cc.z, dd.y_br = cc.w, dd.conf = key_conf(fkeys[row0 + rb * 64 + lane]);
         fd[pos] = dd;
       }
     }
@@ -433,6 +490,63 @@ __global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __res
     for (int q = 0; q < 32; q++) rows[q] = rows_next[q];
     diag = diag_next;
   }
+  return nsel;
+}
+
+// One workgroup per heavy frame.  Up to kMatHalf candidates: wave 0 scans the one square, the other waves leave at once.
+// More (two halves): wave 0 scans the first square and publishes, block by block, which rows it kept; waves 1..3 follow
+// it and OR the kept rows' words of the SECOND column half (the off-diagonal square: bulk loads, no serial chain) into
+// the mask the second square starts from; wave 0 then scans the second square.
+__global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __restrict__ gkeys, size_t key_stride,
+                                                 const float4* __restrict__ spill, int K, const unsigned long long* __restrict__ mat,
+                                                 Det* __restrict__ dets, uint32_t det_stride, uint32_t* __restrict__ ndet) {
+  __shared__ unsigned long long s_kept[kHalfWords];
+  __shared__ unsigned long long s_hi[3][kHalfWords];
+  __shared__ int s_progress;
+  const int frame = blockIdx.x;
+  const uint32_t flag = ndet[frame];
+  if (!(flag & kHeavyFlag)) return;
+  const int n = (int)(flag & ~kHeavyFlag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, word = lane & 31;
+  const bool two = n > kMatHalf;
+  if (!two && wave > 0) return;  // (no barrier on this path)
+  const unsigned long long* fmat = mat + (size_t)frame * kMatMax * kMatWords;
+  const unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
+  const float4* fsp = spill + (size_t)frame * K;
+  Det* fd = dets + (size_t)frame * det_stride;
+  if (!two) {
+    const int nsel = nms_scan_half(fmat, n, 0, 0, 0ull, fkeys, fsp, fd, det_stride, 0, nullptr, nullptr);
+    if (lane == 0) ndet[frame] = (uint32_t)nsel;
+    return;
+  }
+  if (threadIdx.x == 0) s_progress = 0;
+  __syncthreads();
+  int nsel = 0;
+  if (wave == 0) {
+    nsel = nms_scan_half(fmat, n, 0, 0, 0ull, fkeys, fsp, fd, det_stride, 0, s_kept, &s_progress);
+  } else {
+    // wave w: row blocks w - 1, w + 2, ... of the first half; lane = (row parity, word of the second column half)
+    unsigned long long acc = 0ull;
+    const int nw2 = (n - kMatHalf + 63) >> 6;  // words the second half uses
+    for (int rb = wave - 1; rb < kHalfWords; rb += 3) {
+      // all 32 row pairs of the block in flight at once (unconditional loads, selected afterwards: one memory round
+      // trip per block); they do not depend on what wave 0 keeps, so they are issued before the wait
+      unsigned long long v[32];
+#pragma unroll
+      for (int q = 0; q < 32; q++) v[q] = fmat[(size_t)(rb * 64 + 2 * q + half) * kMatWords + kHalfWords + min(word, nw2 - 1)];
+      while (__hip_atomic_load(&s_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= rb) __builtin_amdgcn_s_sleep(8);
+      const unsigned long long kh = s_kept[rb] >> half;
+#pragma unroll
+      for (int q = 0; q < 32; q++) acc |= ((kh >> (2 * q)) & 1ull) ? v[q] : 0ull;
+    }
+    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)acc, 32), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), 32);
+    acc |= ((unsigned long long)ohi << 32) | olo;
+    if (half == 0) s_hi[wave - 1][word] = word < nw2 ? acc : 0ull;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  const unsigned long long removed = s_hi[0][word] | s_hi[1][word] | s_hi[2][word];
+  nsel = nms_scan_half(fmat, n, kMatHalf, kHalfWords, removed, fkeys, fsp, fd, det_stride, nsel, nullptr, nullptr);
   if (lane == 0) ndet[frame] = (uint32_t)nsel;
 }
 
@@ -457,12 +571,13 @@ void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_
                      unsigned long long* d_mat, uint32_t B, hipStream_t s) {
   const int knob = kMatMin;
   const bool use_matrix = d_mat != nullptr && K > (uint32_t)knob;
+  // (without the matrix scratch no frame is "heavy": mat_min = mat_max = 0 keeps everything in the first kernel)
   hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
-                     d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : kMatMax);
+                     d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : 0, use_matrix ? kMatMax : 0);
   if (!use_matrix) return;
   // (both return at once for frames the first kernel finished itself)
   hipLaunchKernelGGL(k_nms_matrix, dim3(kMatWords, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
-  hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(64), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
+  hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
                      d_ndet);
 }
 size_t nms_matrix_bytes(uint32_t B) { return (size_t)B * kMatMax * kMatWords * sizeof(unsigned long long); }

@@ -184,6 +184,38 @@ def test_postproc_many_candidates_matrix_path(model320, oracle_lib, size):
             assert np.array_equal(g, ref), "%d candidates differ" % n
 
 
+@pytest.mark.parametrize("size", [0.015, 0.08])
+def test_postproc_two_matrix_halves(model640, oracle_lib, size):
+    """Frames with 2049..4096 candidates (nn.rs:198-224 has no cap): sorted in LDS like the lighter ones, suppression
+    matrix in four quadrants, scan in two halves with the off-diagonal square folded in between -- no HBM sort, no
+    one-CU block loop.  Beyond 4096 the in-kernel block loop still answers.  Bit-exact selection and order next to
+    light frames in the same batch, with confidence ties and zero-area boxes."""
+    rng = np.random.default_rng(int(size * 1000) + 7)
+    K = model640.num_priors
+    counts = [2049, 3000, 100, 4096, 4097, 2048, 3583, 0, 2112, 6000, 4095, 17640]
+    for b0 in range(0, len(counts), 4):
+        sc, bx = [], []
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            conf = rng.random(K).astype(np.float32) * 0.5
+            hot = rng.permutation(K)[:n]
+            conf[hot] = 0.5 + (1 + rng.random(n).astype(np.float32)) * 0.249
+            if f % 2 == 1:
+                conf[hot] = np.round(conf[hot] * 256) / 256  # many exact ties
+            c = rng.random((K, 2)).astype(np.float32)
+            s = (rng.random((K, 2)).astype(np.float32) * size + 0.005)
+            boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+            boxes[::53, 2] = boxes[::53, 0] - 0.01  # degenerate boxes: zero area
+            sc.append(np.stack([1 - conf, conf], 1).astype(np.float32))
+            bx.append(boxes)
+        got = model640.debug_postproc(np.stack(sc), np.stack(bx))
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            ref = oracle_lib.postproc(sc[f], bx[f], 0.5, 0.5)
+            g = dets_array(got[f])
+            assert int((sc[f][:, 1] > 0.5).sum()) == n
+            assert g.shape == ref.shape, "%d candidates: %d vs %d selected" % (n, len(g), len(ref))
+            assert np.array_equal(g, ref), "%d candidates differ" % n
+
+
 # ---------------------------------------------------------------- end to end
 @pytest.mark.parametrize("variant,src", [(320, (320, 240)), (640, (640, 480)), (640, (1280, 720)), (320, (1280, 720)),
                                          (640, (640, 427))])
