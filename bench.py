@@ -50,9 +50,9 @@ KERNEL_FUNCS = {
     "huff_unstuff": "k_huff_unstuff", "huff_seed": "k_huff_seed", "huff_extend": "k_huff_extend", "huff_link": "k_huff_link",
     "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
     "conv_dwpw_coop": "k_dwpw_coop", "stem_planes_mfma": "k_stem_planes_mfma",
-    "sort_nms": "k_sort_nms",
+    "sort_nms": "k_sort_nms", "conv_dual": "k_dual_dwpw",
 }
-MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "stem_planes_mfma", "conv3x3_mfma",
+MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual", "stem_planes_mfma", "conv3x3_mfma",
                 "conv3x3_rows_mfma")
 
 
@@ -557,7 +557,8 @@ def main():
         dump = os.environ.get("UFD_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:
-                json.dump({"steps": prof_steps, "batch": B, "stats": stats}, f, indent=1)
+                json.dump({"steps": prof_steps, "batch": B, "stats": stats, "roof_steps": ROOF_STEPS,
+                           "stats_loaded": extras.get("kernel_stats_loaded"), "stats_alone": extras.get("kernel_stats_alone")}, f, indent=1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H)
         print(json.dumps(out), flush=True)

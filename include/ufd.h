@@ -84,6 +84,7 @@ typedef struct ufd_config {
 #define UFD_FLAG_NO_CHAIN 32u      /* m1->m2 / m3->m4 as two launches each instead of the chained kernel */
 #define UFD_FLAG_NO_RFB_SUM 64u    /* ConvLinear and shortcut of the RFB block as two convs instead of one summed conv */
 #define UFD_FLAG_NO_STEM_FUSE 128u /* upsample/colour/normalise kernel + stem conv instead of the stem reading the sample planes */
+#define UFD_FLAG_NO_DUAL 512u      /* head pairs and the backbone block beside them as separate launches instead of one grid */
 /* Host placement: by default the handle's issue workers and pool threads are pinned to the CPUs of the NUMA node the GPU
  * hangs off (/sys/bus/pci/devices/<bdf>/numa_node), inside the process's affinity mask -- eight handles on a two-socket
  * box then stage their JPEG bytes and issue their launches from the socket next to their GPU (ufd_model_placement

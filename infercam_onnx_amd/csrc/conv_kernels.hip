@@ -79,9 +79,9 @@ __device__ __forceinline__ void store_tiles(const ConvArgs& a, floatx16 (&acc)[C
 // (each with a private L2).  Blocks that read the same activation tile but produce different
 // 32-cout tiles get ids 8 apart inside a group of 8*cts ids, so they run on the same XCD close in
 // time and the second..cts-th read of the tile hits that XCD's L2.  Placement only changes speed.
-__device__ __forceinline__ bool remap_block(const ConvArgs& a, int* tile, int* ct) {
+__device__ __forceinline__ bool remap_block(const ConvArgs& a, int bx, int* tile, int* ct) {
   const int per = 8 * a.cts;
-  const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+  const int grp = bx / per, r = bx - grp * per;
   *ct = r >> 3;
   *tile = grp * 8 + (r & 7);
   return *tile < a.tiles;
@@ -145,15 +145,16 @@ __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red
 // The k-loop keeps D k-steps of activations and weights in flight in a register ring (loads are
 // unconditional: dead lanes read a valid dummy address), so a wave does not pay one memory round
 // trip per k-step.  Needs ksteps % D == 0.
+// (bodies take the conv and the block id along x as arguments: a block of a DUAL launch -- two independent convs of the
+// graph in one grid, below -- runs one of them with its own numbering)
 template <int CT, int D, int SK>
-__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];
+__device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   // LDS: weights of this cout tile [ksteps][64] (one vector-memory instruction per k-step is left:
   // the activation load) | split-K reduction buffer
   extern __shared__ float s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
-  if (!remap_block(a, &tile, &ctile)) return;
+  if (!remap_block(a, bx, &tile, &ctile)) return;
   const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
   float* s_w = s_mem;
   float* s_red = s_mem + CT * ksteps * 64;
@@ -220,6 +221,10 @@ __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, pix, hw);
 }
+template <int CT, int D, int SK>
+__global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
+  pw_mfma_body<CT, D, SK>(p3.a[blockIdx.y], (int)blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fused depthwise 3x3 (pad 1, stride S, +bias, ReLU) -> pointwise 1x1 (+bias, optional ReLU).
@@ -263,13 +268,12 @@ __device__ __forceinline__ void fill_dw_variants(float* s_dw, const float* __res
 __device__ __forceinline__ int dw_variant(bool row0ok, bool row2ok) { return !row0ok ? 1 : (!row2ok ? 2 : 0); }
 
 template <int CT, int S, int D, int SK>
-__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];
+__device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
   // LDS: depthwise weights [cin][12] | pointwise weights of this cout tile [ksteps][64] | split-K buffer
   extern __shared__ float s_mem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile, ctile;
-  if (!remap_block(a, &tile, &ctile)) return;  // whole block, before the barrier
+  if (!remap_block(a, bx, &tile, &ctile)) return;  // whole block, before the barrier
   const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
   float* s_dw = s_mem;
   float* s_w = s_mem + 3 * a.cin * 12;
@@ -417,6 +421,10 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
 }
+template <int CT, int S, int D, int SK>
+__global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
+  dwpw_mfma_body<CT, S, D, SK>(p3.a[blockIdx.y], (int)blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fused depthwise 3x3 -> pointwise 1x1 for layers with several 32-cout tiles (cout >= 64).
@@ -433,8 +441,7 @@ __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
 // one chunk of prefetch.  fma order per output as k_dwpw_mfma.  Needs (cin/2) % 8 == 0,
 // cts % CTW == 0.
 template <int S, int CTW>
-__global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];
+__device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   constexpr int PT = 4 / CTW;   // pixel tiles per block
   constexpr int CH = 8;         // k-steps per chunk
   constexpr int NS = CH / CTW;  // depthwise steps per wave and chunk
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
   int tgrp, cgrp;
   {
     const int per = 8 * cgroups;
-    const int grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+    const int grp = bx / per, r = bx - grp * per;
     cgrp = r >> 3;
     tgrp = grp * 8 + (r & 7);
   }
@@ -583,6 +590,42 @@ __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
     __syncthreads();
   }
   if (live) store_tiles<1>(a, acc, ct, half, frame, oy * a.ow + ox, ohw);
+}
+template <int S, int CTW>
+__global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
+  dwpw_coop_body<S, CTW>(p3.a[blockIdx.y], (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DUAL launches: two convolutions of the graph that do not depend on each other -- a cls/reg head pair and the next
+// backbone block, which both read the tensor produced just before -- as ONE grid: the first ax * ay blocks run conv A
+// (numbered x + ax * y like its own launch), the rest conv B.  The small-map layers are latency-bound at one wave per
+// SIMD or less; side by side they fill each other's stalls, the dependent chain of a batch is one launch shorter per
+// pair, and no extra HIP stream is needed (streams beyond the runtime's four hardware queues cost more than they
+// bring: DESIGN.md, host pipeline).  Results are those of the separate launches bit for bit: the bodies are the same.
+struct DualArgs {
+  ConvArgs3 a, b;
+  int ax, ay;  // grid of conv A
+};
+template <int SA, int SKA, int SB>
+__global__ __launch_bounds__(256) void k_dual_dwpw_coop(DualArgs q) {  // A: k_dwpw_mfma<1, SA, 2, SKA> (merged head pair); B: k_dwpw_coop<SB, 4>
+  const int bid = (int)blockIdx.x, na = q.ax * q.ay;
+  if (bid < na) {
+    const int y = bid / q.ax;
+    dwpw_mfma_body<1, SA, 2, SKA>(q.a.a[y], bid - y * q.ax);
+  } else {
+    dwpw_coop_body<SB, 4>(q.b.a[0], bid - na);
+  }
+}
+template <int SA, int SKA, int SKB>
+__global__ __launch_bounds__(256) void k_dual_dwpw_pw(DualArgs q) {  // A as above; B: k_pw_mfma<1, 4, SKB> (one 1x1 conv)
+  const int bid = (int)blockIdx.x, na = q.ax * q.ay;
+  if (bid < na) {
+    const int y = bid / q.ax;
+    dwpw_mfma_body<1, SA, 2, SKA>(q.a.a[y], bid - y * q.ax);
+  } else {
+    pw_mfma_body<1, 4, SKB>(q.b.a[0], bid - na);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1503,30 +1546,44 @@ static void allow_large_lds(const void* kernel) {
 }
 constexpr size_t kSplitKBytes = 64 * 64 * sizeof(float);  // CT = 1: one partial tile at a time
 
-// n (<= 3) convolutions with identical shapes except cout / weights / outputs
-void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
-  ConvArgs3 p{};
+// Launch configuration of k_pw_mfma for n merged convs.
+struct PwConfig {
+  ConvArgs3 p;
+  unsigned gx, gy;
+  size_t lds;
+  bool sk;
+  int ksteps;
+};
+static PwConfig pw_config(const ConvArgs* args, int n) {
+  PwConfig c{};
   const ConvArgs& r = args[0];
   const long groups = (long)r.B * (r.oh * r.ow / 4);
   const long wave_tiles = (groups + 31) / 32;
-  const int ksteps = r.cin >> 1;
-  const size_t wlds = (size_t)ksteps * 64 * sizeof(float);
+  c.ksteps = r.cin >> 1;
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
-  const bool sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  c.sk = want_splitk(wave_tiles, max_cts * n, c.ksteps);
+  c.lds = (size_t)c.ksteps * 64 * sizeof(float) + (c.sk ? kSplitKBytes : 0);
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
-    p.a[i] = args[i];
-    p.a[i].cts = (args[i].cout + 31) / 32;
-    p.a[i].tiles = sk ? (int)wave_tiles : (int)((groups + 127) / 128);
-    grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
+    c.p.a[i] = args[i];
+    c.p.a[i].cts = (args[i].cout + 31) / 32;
+    c.p.a[i].tiles = c.sk ? (int)wave_tiles : (int)((groups + 127) / 128);
+    grid = std::max(grid, (unsigned)((c.p.a[i].tiles + 7) / 8) * 8 * c.p.a[i].cts);
   }
-  if (sk)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(grid, n), dim3(256), wlds + kSplitKBytes, s, p);
-  else if (ksteps % 4 == 0)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(grid, n), dim3(256), wlds, s, p);
+  c.gx = grid, c.gy = (unsigned)n;
+  return c;
+}
+
+// n (<= 3) convolutions with identical shapes except cout / weights / outputs
+void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
+  const PwConfig c = pw_config(args, n);
+  if (c.sk)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+  else if (c.ksteps % 4 == 0)
+    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
   else
-    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(grid, n), dim3(256), wlds, s, p);
+    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
 }
 
 // Template instance the launchers above / below pick for a launch, as rocprofv3 prints it behind the kernel name
@@ -1547,56 +1604,127 @@ bool dwpw_uses_coop(const ConvArgs* args, int n) {
   return n == 1 && ksteps % 8 == 0 && cts % 4 == 0;
 }
 
-void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t s) {
-  ConvArgs3 p{};
+// Launch configuration of k_dwpw_mfma for n merged convs (the non-cooperative form): arguments with tiles / cts set,
+// grid, dynamic LDS, split-K or not.
+struct DwpwConfig {
+  ConvArgs3 p;
+  unsigned gx, gy;
+  size_t lds;
+  bool sk, deep;
+};
+static DwpwConfig dwpw_config(const ConvArgs* args, int n) {
+  DwpwConfig c{};
   const ConvArgs& r = args[0];
   const long groups = (long)r.B * (r.oh * r.ow / 4);
   const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
   const int ksteps = r.cin >> 1;
-  const size_t lds = ((size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float);
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
-  const bool sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  c.sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  c.deep = ksteps % 4 == 0;
+  c.lds = ((size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
-    p.a[i] = args[i];
-    p.a[i].cts = (args[i].cout + 31) / 32;
-    p.a[i].tiles = sk ? (int)wave_tiles : (int)((wave_tiles + 3) / 4);
-    grid = std::max(grid, (unsigned)((p.a[i].tiles + 7) / 8) * 8 * p.a[i].cts);
+    c.p.a[i] = args[i];
+    c.p.a[i].cts = (args[i].cout + 31) / 32;
+    c.p.a[i].tiles = c.sk ? (int)wave_tiles : (int)((wave_tiles + 3) / 4);
+    grid = std::max(grid, (unsigned)((c.p.a[i].tiles + 7) / 8) * 8 * c.p.a[i].cts);
   }
+  c.gx = grid, c.gy = (unsigned)n;
+  return c;
+}
+// ... of k_dwpw_coop<S, 4> for one conv with a multiple of four cout tiles
+struct CoopConfig {
+  ConvArgs3 p;
+  unsigned blocks;
+  size_t lds;
+  int ctw;
+};
+static CoopConfig coop_config(const ConvArgs* args) {
+  CoopConfig c{};
+  const ConvArgs& r = args[0];
+  const long groups = (long)r.B * (r.oh * r.ow / 4);
+  const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
+  const int max_cts = (r.cout + 31) / 32;
+  c.ctw = (max_cts % 4 == 0) ? 4 : 2;
+  const int ptiles = 4 / c.ctw;
+  c.p.a[0] = r;
+  c.p.a[0].cts = max_cts;
+  c.p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups
+  c.blocks = (unsigned)((c.p.a[0].tiles + 7) / 8) * 8 * (max_cts / c.ctw);
+  c.lds = (size_t)r.cin * 36 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
+  return c;
+}
+
+void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t s) {
   // several cout tiles: the cooperative kernel shares the depthwise work among the waves of a block
   if (dwpw_uses_coop(args, n)) {
-    const int ctw = (max_cts % 4 == 0) ? 4 : 2, ptiles = 4 / ctw;
-    p.a[0].cts = max_cts;
-    p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups
-    const unsigned blocks = (unsigned)((p.a[0].tiles + 7) / 8) * 8 * (max_cts / ctw);
-    const size_t clds = (size_t)r.cin * 36 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
-    void (*kernel)(ConvArgs3) = stride == 1 ? (ctw == 4 ? k_dwpw_coop<1, 4> : k_dwpw_coop<1, 2>)
-                                             : (ctw == 4 ? k_dwpw_coop<2, 4> : k_dwpw_coop<2, 2>);
-    if (clds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, dim3(blocks, 1), dim3(256), clds, s, p);
+    const CoopConfig c = coop_config(args);
+    void (*kernel)(ConvArgs3) = stride == 1 ? (c.ctw == 4 ? k_dwpw_coop<1, 4> : k_dwpw_coop<1, 2>)
+                                             : (c.ctw == 4 ? k_dwpw_coop<2, 4> : k_dwpw_coop<2, 2>);
+    if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, dim3(c.blocks, 1), dim3(256), c.lds, s, c.p);
     return;
   }
-  const dim3 g(grid, n);
+  const DwpwConfig c = dwpw_config(args, n);
+  const dim3 g(c.gx, c.gy);
   // (the three copies of the depthwise table of a 256-channel layer need more than the default
   // 64 KB of dynamic LDS: raised once per instantiation)
-  auto launch = [&](void (*kernel)(ConvArgs3), size_t bytes) {
-    if (bytes > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, g, dim3(256), bytes, s, p);
+  auto launch = [&](void (*kernel)(ConvArgs3)) {
+    if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, g, dim3(256), c.lds, s, c.p);
   };
-  if (sk) {
-    if (stride == 1) launch(k_dwpw_mfma<1, 1, 2, 4>, lds + kSplitKBytes);
-    else launch(k_dwpw_mfma<1, 2, 2, 4>, lds + kSplitKBytes);
+  if (c.sk) {
+    if (stride == 1) launch(k_dwpw_mfma<1, 1, 2, 4>);
+    else launch(k_dwpw_mfma<1, 2, 2, 4>);
     return;
   }
-  const bool deep = ksteps % 4 == 0;
   if (stride == 1) {
-    if (deep) launch(k_dwpw_mfma<1, 1, 2, 1>, lds);
-    else launch(k_dwpw_mfma<1, 1, 1, 1>, lds);
+    if (c.deep) launch(k_dwpw_mfma<1, 1, 2, 1>);
+    else launch(k_dwpw_mfma<1, 1, 1, 1>);
   } else {
-    if (deep) launch(k_dwpw_mfma<1, 2, 2, 1>, lds);
-    else launch(k_dwpw_mfma<1, 2, 1, 1>, lds);
+    if (c.deep) launch(k_dwpw_mfma<1, 2, 2, 1>);
+    else launch(k_dwpw_mfma<1, 2, 1, 1>);
   }
+}
+
+// Dual launch (k_dual_*): conv group A = a merged cls/reg head pair on k_dwpw_mfma<1, 1, 2, SK>, conv B = one dw->pw block
+// on k_dwpw_coop<S, 4> (b_stride > 0) or one 1x1 conv on k_pw_mfma<1, 4, SK> (b_stride == 0).  False: this combination
+// of instances is not compiled -- the caller issues the two launches one after the other.
+bool launch_conv_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride, hipStream_t s) {
+  if (std::getenv("UFD_NO_DUAL")) return false;
+  if (na < 1 || na > 3 || a_stride != 1 || dwpw_uses_coop(a, na)) return false;
+  const DwpwConfig ca = dwpw_config(a, na);
+  if (!ca.deep) return false;
+  DualArgs q{};
+  q.a = ca.p;
+  q.ax = (int)ca.gx, q.ay = (int)ca.gy;
+  const unsigned blocks_a = ca.gx * ca.gy;
+  void (*kernel)(DualArgs) = nullptr;
+  size_t lds = ca.lds;
+  unsigned blocks_b = 0;
+  if (b_stride > 0) {
+    if (!dwpw_uses_coop(b, 1)) return false;
+    const CoopConfig cb = coop_config(b);
+    if (cb.ctw != 4) return false;
+    q.b = cb.p;
+    blocks_b = cb.blocks;
+    lds = std::max(lds, cb.lds);
+    if (b_stride == 2) kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 2> : k_dual_dwpw_coop<1, 1, 2>;
+    else kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 1> : k_dual_dwpw_coop<1, 1, 1>;
+  } else {
+    if (b[0].in2 || b[0].res) return false;
+    const PwConfig cb = pw_config(b, 1);
+    if (cb.ksteps % 4 != 0) return false;
+    q.b = cb.p;
+    blocks_b = cb.gx;
+    lds = std::max(lds, cb.lds);
+    if (cb.sk) kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 4> : k_dual_dwpw_pw<1, 1, 4>;
+    else kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 1> : k_dual_dwpw_pw<1, 1, 1>;
+  }
+  if (lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+  hipLaunchKernelGGL(kernel, dim3(blocks_a + blocks_b), dim3(256), lds, s, q);
+  return true;
 }
 
 const char* conv_dwpw_instance(const ConvArgs* args, int n, int stride) {

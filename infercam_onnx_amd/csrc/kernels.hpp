@@ -170,6 +170,10 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
 size_t depthwise_packed_floats(int c);
 void pack_depthwise_weights(const float* w /*[c][9]*/, const float* bias, int c, float* packed /*[c][12]*/);
 void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);
+// Two independent convs as ONE grid (k_dual_*): group A = n_a merged dw->pw convs (a cls/reg head pair), B = one dw->pw
+// block of stride b_stride (cooperative kernel) or, b_stride == 0, one 1x1 conv.  Returns false when that combination of
+// kernel instances is not compiled (the caller then issues the two launches one after the other).
+bool launch_conv_dual(const ConvArgs* a, int n_a, int a_stride, const ConvArgs* b, int b_stride, hipStream_t s);
 // Template arguments of the kernel instance those launchers pick, as rocprofv3 prints them ("<16, 1, true>"): profiling labels.
 const char* conv_pointwise_instance(const ConvArgs* a, int n);
 const char* conv_dwpw_instance(const ConvArgs* a, int n, int stride);

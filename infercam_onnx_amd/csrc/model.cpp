@@ -48,6 +48,7 @@ struct Ctx;
 thread_local Ctx* tl_cur = nullptr;
 thread_local ThreadPool* tl_pool = nullptr;
 thread_local bool tl_prof = true;  // record kernel events for the batch being issued by this thread
+thread_local bool tl_force_rider = false;  // enqueue_layer_launch: issue a riding layer on its own (its host could not take it)
 
 struct Tensor {
   size_t off = 0;  // float offset in the activation arena (for the whole batch)
@@ -74,6 +75,8 @@ struct Layer {
   int chain_first = -1;    // kKindDwPw2: the kKindDwPw layer of the first block
   bool chained = false;    // kKindDwPw layer computed inside a later kKindDwPw2 launch: its output never exists
   int leader = -1;         // first layer of the launch this layer is issued in (itself when not merged)
+  int rider = -1;          // leader only: leader of an independent launch that rides in this one's grid (dual launch)
+  int ride = -1;           // leader only: the launch it rides in (issued at that layer's turn, not at its own)
   int group[3] = {-1, -1, -1};  // leader only: members of its launch (itself first)
   bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
   const float* d_w = nullptr;  // kernel-specific packing
@@ -377,6 +380,14 @@ struct ProfScope {
     pe.flops = flops;
     (void)hipEventRecord(pe.e0, st);
   }
+  // the launch this scope was opened for did not happen: no sample, the events go back to the pool
+  void cancel() {
+    if (!on) return;
+    on = false;
+    std::lock_guard<std::mutex> lk(m->shared_mu);
+    m->prof_free.push_back(pe.e0);
+    m->prof_free.push_back(pe.e1);
+  }
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(pe.e1, st);
@@ -642,6 +653,26 @@ void plan_tensors(ufd_model* m, bool keep_all) {
       }
     }
   }
+  // Dual launches: a cls/reg head pair and the next backbone block both read the tensor produced just before them and
+  // do not depend on each other -- one grid for both (k_dual_*), issued at the head pair's turn.
+  if (!keep_all && !(flags & UFD_FLAG_NO_DUAL)) {
+    static const int kDuals[][2] = {{kHeadCls[0], 30}, {kHeadCls[1], 40}, {kHeadCls[2], 47}};
+    for (const auto& d : kDuals) {
+      Layer& A = m->layers[d[0]];
+      Layer& Bm = m->layers[d[1]];
+      if (A.kind != kKindDwPw || A.leader != d[0] || A.chained) continue;
+      if ((Bm.kind != kKindDwPw && Bm.kind != kKindPointwise) || Bm.leader != d[1] || Bm.group[1] >= 0 || Bm.chained ||
+          Bm.stack[0] >= 0 || Bm.sum_with >= 0 || Bm.res_tensor >= 0 || d[1] <= d[0])
+        continue;
+      // everything B reads exists before A's turn
+      const int src = Bm.kind == kKindDwPw ? m->layers[Bm.fused_dw].spec.src : Bm.spec.src;
+      if (src < 0 || src >= d[0] || m->layers[src].chained) continue;
+      const int src_turn = m->layers[src].ride >= 0 ? m->layers[src].ride : m->layers[src].leader;
+      if (src_turn >= d[0]) continue;
+      A.rider = d[1];
+      Bm.ride = d[0];
+    }
+  }
   // where each layer's output can be read back in this plan (ufd_debug_layer_output)
   for (int i = 0; i < kNumConv; i++) {
     Layer& L = m->layers[i];
@@ -656,7 +687,8 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     const Layer& L = m->layers[i];
     if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
     if (L.chained) continue;                                     // computed inside a later launch
-    first[L.out_tensor] = std::min(first[L.out_tensor], L.leader);  // a merged layer writes at its leader's turn
+    const int lead = m->layers[L.leader].ride >= 0 ? std::min(L.leader, m->layers[L.leader].ride) : L.leader;
+    first[L.out_tensor] = std::min(first[L.out_tensor], lead);  // a merged layer writes at its leader's turn, a rider at its host's
     last[L.out_tensor] = std::max(last[L.out_tensor], std::max(i, L.leader));
     const int when = std::max(i, L.leader);  // a merged member is read at its leader's turn
     int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
@@ -1000,6 +1032,7 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
   if (L.kind == kKindFusedAway && !L.materialize) return;
   if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
   if (L.leader != i) return;  // issued with its group leader
+  if (L.ride >= 0 && !tl_force_rider) return;  // issued in (or right behind) the launch of the layer it rides with
   if (i == 0 && tl_cur->stem_descs) {  // stem conv straight from the decoder's sample planes
     int st_ = 1;
     StemArgs sa;
@@ -1052,7 +1085,21 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
     case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
     case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
   }
+  if (L.rider >= 0 && L.kind == kKindDwPw) {  // dual launch with the rider's conv, when that pair of instances exists
+    const Layer& R = m->layers[L.rider];
+    int r_stride = 1;
+    const ConvArgs rb = layer_args(m, L.rider, f0, count, &r_stride);
+    bool done;
+    {
+      ProfScope ps(m, std::string("conv_dual:") + names + "|" + R.spec.name, bytes + R.bytes_per_frame * count + R.weight_bytes,
+                   flops + R.flops_per_frame * count, st);
+      done = launch_conv_dual(args, n, dw_stride, &rb, R.kind == kKindDwPw ? r_stride : 0, st);
+      if (!done) ps.cancel();
+    }
+    if (done) return;
+  }
   const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n) : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : "");
+  {
   ProfScope ps(m, std::string(kind) + inst + ":" + names, bytes, flops, st);
   switch (L.kind) {
     case kKindPointwise: launch_conv_pointwise_mfma(args, n, st); break;
@@ -1068,6 +1115,12 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
       }
       break;
     default: launch_conv_direct(a, st); break;
+  }
+  }
+  if (L.rider >= 0) {  // the pair is not compiled as one grid: the rider right behind its host, on its own
+    tl_force_rider = true;
+    enqueue_layer_launch(m, L.rider, f0, count, st);
+    tl_force_rider = false;
   }
 }
 

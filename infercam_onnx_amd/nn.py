@@ -21,6 +21,7 @@ UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_FLAG_NO_NUMA_PIN = 256
+UFD_FLAG_NO_DUAL = 512
 UFD_MAX_REPLICAS = 64
 UFD_SCHED_NO_WAIT = 0xFFFFFFFF
 UFD_PARITY_EXACT, UFD_PARITY_LABELS_UNPINNED = 0, 1
@@ -248,7 +249,7 @@ class UltrafaceModel(InferModel):
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
                  weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
                  device_entropy=False, host_entropy=False, tap_layers=False, no_chain=False, no_rfb_sum=False,
-                 no_stem_fuse=False, no_numa_pin=False, _handle=None):
+                 no_stem_fuse=False, no_numa_pin=False, no_dual=False, _handle=None):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -263,7 +264,7 @@ class UltrafaceModel(InferModel):
                                       priors=priors, weights_path=weights_path, max_src=max_src, host_threads=host_threads,
                                       keep_layers=keep_layers, profile=profile, device_entropy=device_entropy,
                                       host_entropy=host_entropy, tap_layers=tap_layers, no_chain=no_chain, no_rfb_sum=no_rfb_sum,
-                                      no_stem_fuse=no_stem_fuse, no_numa_pin=no_numa_pin)
+                                      no_stem_fuse=no_stem_fuse, no_numa_pin=no_numa_pin, no_dual=no_dual)
             h = ctypes.c_void_p()
             rc = self._lib.ufd_create(ctypes.byref(cfg), ctypes.byref(h))
             if rc != UFD_OK:
@@ -277,7 +278,7 @@ class UltrafaceModel(InferModel):
     @staticmethod
     def _config(variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None, weights_path=None,
                 max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, device_entropy=False, host_entropy=False,
-                tap_layers=False, no_chain=False, no_rfb_sum=False, no_stem_fuse=False, no_numa_pin=False):
+                tap_layers=False, no_chain=False, no_rfb_sum=False, no_stem_fuse=False, no_numa_pin=False, no_dual=False):
         """ufd_config of UltrafaceModel::new's arguments; returns (cfg, arrays the cfg points into)."""
         cfg = UfdConfig()
         cfg.struct_size = ctypes.sizeof(UfdConfig)
@@ -290,7 +291,7 @@ class UltrafaceModel(InferModel):
                      (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0) |
                      (UFD_FLAG_TAP_LAYERS if tap_layers else 0) | (UFD_FLAG_NO_CHAIN if no_chain else 0) |
                      (UFD_FLAG_NO_RFB_SUM if no_rfb_sum else 0) | (UFD_FLAG_NO_STEM_FUSE if no_stem_fuse else 0) |
-                     (UFD_FLAG_NO_NUMA_PIN if no_numa_pin else 0))
+                     (UFD_FLAG_NO_NUMA_PIN if no_numa_pin else 0) | (UFD_FLAG_NO_DUAL if no_dual else 0))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()

@@ -700,6 +700,35 @@ def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
         fused_model.close()
 
 
+@pytest.mark.parametrize("variant,batch", [(640, 32), (640, 3), (320, 32), (320, 1)])
+def test_dual_launches_are_bit_identical_to_separate_ones(weights, oracle_lib, variant, batch):
+    """A cls/reg head pair and the backbone block beside it as ONE grid (k_dual_*): same bodies, same numbering inside
+    each conv, so every tensor of the issued plan equals the separate-launch plan bit for bit -- at the bench's batch
+    (plain instances) and at small batches (split-K instances, or pairs that are not compiled and fall back)."""
+    from infercam_onnx_amd import synth
+
+    W, H = VARIANT_WH[variant]
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(97, i, W, H)) for i in range(min(batch, 3))])
+    x = np.concatenate([x] * ((batch + len(x) - 1) // len(x)))[:batch]
+    ref_model = make_model(variant, weights, max_batch=batch, profile=True, tap_layers=True, no_dual=True)
+    dual_model = make_model(variant, weights, max_batch=batch, profile=True, tap_layers=True)
+    try:
+        s0, b0 = ref_model.debug_forward(x)
+        s1, b1 = dual_model.debug_forward(x)
+        assert np.array_equal(s0, s1) and np.array_equal(b0, b1)
+        for layer in (26, 28, 30, 36, 38, 40, 44, 46, 47):
+            for f in (0, batch - 1):
+                assert np.array_equal(ref_model.debug_layer_output(layer, f), dual_model.debug_layer_output(layer, f)), (layer, f)
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names = {p["name"] for p in dual_model.profile_read() if p["launches"]}
+        assert not any(n.startswith("conv_dual") for n in names_ref)
+        if (variant, batch) == (640, 32):  # the bench's plan: all three pairs ride
+            assert sum(n.startswith("conv_dual") for n in names) == 3, names
+    finally:
+        ref_model.close()
+        dual_model.close()
+
+
 def test_unusual_restart_layouts(model320_auto, oracle_lib):
     """Restart intervals of a single MCU (1200 per frame: more than the device pipeline's segment
     table, so the batch decodes on the host workers), of a few MCUs (segments shorter than one
