@@ -1761,6 +1761,8 @@ bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
 static int dwpw2_band(const ConvArgs& second) {
   const long waves1 = (2L * second.B * (second.oh * second.ow / 4) + kDwGroups - 1) / kDwGroups;
   const double rounds = (double)waves1 / 2048.0;
+  if (const char* e = std::getenv("UFD_BAND_SMALL"))  // (experiment knob)
+    if (rounds < 3.0 && std::atoi(e) > 0 && second.oh % std::atoi(e) == 0) return std::atoi(e);
   if (rounds < 3.0) return 1;
   int best = 1;
   double best_d = 1e30;

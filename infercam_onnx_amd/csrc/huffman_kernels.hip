@@ -115,7 +115,15 @@ __device__ __forceinline__ int slow_symbol(const HuffSlow& t, uint32_t top) {
 // state in st; returns the number of MCUs those symbols complete.  One symbol per iteration for
 // every lane; a code word is <= 16 bits and its magnitude <= 15 bits, so everything happens in the
 // top 32 bits of the window.
-__device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, uint32_t limit, const SyncTables& T, int bpm) {
+// CHECKPOINTS (cp != null): the subsequence starts at bit sub_start and is cut into kWriteParts parts of part_bits; the
+// state at the first symbol that starts at or behind part boundary k (exactly what an entry state is for a subsequence)
+// and the MCUs completed in front of it go to cp[k-1] / cpn[k-1].  k_huff_write then decodes every part of the true
+// chain with a lane of its own: its serial symbol chain is a quarter as long.  Boundaries the walk never reaches
+// (limit inside the subsequence, entry behind a boundary) get the state the walk is in when it passes / ends: the
+// part's lane then starts at or behind its own limit and does nothing.
+constexpr int kWriteParts = 4;
+__device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, uint32_t limit, const SyncTables& T, int bpm,
+                                         uint32_t sub_start = 0, uint32_t part_bits = 0, uint2* cp = nullptr, int* cpn = nullptr) {
   int nmcu = 0;
   uint32_t pos = st.p;
   int c = (int)(st.cz & 0xFF), z = (int)(st.cz >> 8);
@@ -123,7 +131,16 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
   bw.init(words, pos);
   const uint32_t dc_bits = T.dc_bits, ac_bits = T.ac_bits;
   int cur_t = z == 0 ? (int)((dc_bits >> c) & 1) : 2 + (int)((ac_bits >> c) & 1);
+  int k = 1;                                                    // next boundary
+  uint32_t next_cp = cp ? sub_start + part_bits : 0xFFFFFFFFu;  // (no checkpoints: never reached)
   while (pos < limit) {
+    if (__builtin_expect(pos >= next_cp, 0)) {  // the symbol about to be decoded is the first one at / behind boundary k
+      cp[k - 1] = make_uint2(pos, (uint32_t)c | ((uint32_t)z << 8));
+      cpn[k - 1] = nmcu;
+      k++;
+      next_cp = k < kWriteParts ? next_cp + part_bits : 0xFFFFFFFFu;
+      continue;  // (the entry may lie behind several boundaries)
+    }
     bw.refill();
     const uint32_t top = bw.top();
     uint32_t e = T.tab[cur_t][top >> 22];
@@ -145,6 +162,11 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
     z = be ? 0 : z;
     cur_t = be ? (int)((dc_bits >> c) & 1) : 2 + (int)((ac_bits >> c) & 1);
   }
+  if (cp)
+    for (; k < kWriteParts; k++) {  // boundaries behind the end of the walk
+      cp[k - 1] = make_uint2(pos, (uint32_t)c | ((uint32_t)z << 8));
+      cpn[k - 1] = nmcu;
+    }
   st.p = pos;
   st.cz = (uint32_t)c | ((uint32_t)z << 8);
   return nmcu;
@@ -283,12 +305,38 @@ __device__ __forceinline__ void load_sync_tables(SyncTablesT<kWrite>& T, const H
 // ivs[q].first_sub) and fills the per-slot tables.  Two passes over the raw range with a block
 // scan each: pass 1 counts the stuffed zeros in front of every segment begin / end, pass 2 stores
 // the kept bytes at  slot offset + (position - begin) - (stuffed zeros since begin).
+// Rows blockIdx.y > 0 of the grid clear the frame's coefficient slab (the decoder stores non-zero coefficients only) and
+// its DC side array beside the unstuffing: independent work that used to be a launch of its own in front of the chain.
+struct ZeroArgs {
+  int16_t* coef;
+  size_t coef_stride;
+  uint32_t vec_per_frame;     // 16-byte stores per frame
+  int16_t* dc;
+  size_t dc_stride;
+  uint32_t dc_vec_per_frame;
+  uint32_t* status;           // per-frame decode status, cleared by the frame's unstuff block
+};
 __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __restrict__ blob,
                                                                const HuffScan* __restrict__ scans,
-                                                               const HuffInterval* __restrict__ ivs, SyncBuffers sb) {
+                                                               const HuffInterval* __restrict__ ivs, SyncBuffers sb, ZeroArgs za) {
   __shared__ int s_wave[kSyncThreads / 64];
   __shared__ uint32_t s_beg[kSyncMaxSeg], s_end[kSyncMaxSeg], s_zb[kSyncMaxSeg], s_ze[kSyncMaxSeg];
   const int frame = blockIdx.x, tid = threadIdx.x;
+  if (blockIdx.y > 0) {  // (whole block)
+    const uint32_t rows = gridDim.y - 1, row = blockIdx.y - 1;
+    uint4* dst = reinterpret_cast<uint4*>(za.coef + (size_t)frame * za.coef_stride);
+    for (uint32_t v = row * kSyncThreads + tid; v < za.vec_per_frame; v += rows * kSyncThreads) dst[v] = make_uint4(0, 0, 0, 0);
+    if (za.dc && (za.dc_stride & 7) == 0) {
+      uint4* d = reinterpret_cast<uint4*>(za.dc + (size_t)frame * za.dc_stride);
+      for (uint32_t v = row * kSyncThreads + tid; v < za.dc_vec_per_frame; v += rows * kSyncThreads) d[v] = make_uint4(0, 0, 0, 0);
+    } else if (za.dc) {  // (frame bases not 16-byte aligned: tiny max_src sizes only)
+      int16_t* d = za.dc + (size_t)frame * za.dc_stride;
+      for (uint32_t v = row * kSyncThreads + tid; v < za.dc_vec_per_frame * 8; v += rows * kSyncThreads)
+        if (v < za.dc_stride) d[v] = 0;
+    }
+    return;
+  }
+  if (tid == 0 && za.status) za.status[frame] = 0;
   const HuffScan& sc = scans[frame];
   SyncFrame* fr = sb.frames + frame;
   const int nseg = (int)sc.nseg;
@@ -438,8 +486,12 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_seed(const HuffScan* 
   st.p = i * fr.sub_bits, st.cz = (uint32_t)g;
   const SyncState entry = st;
   const uint32_t limit = lim & 0x7FFFFFFFu;
-  const int nm = staged ? sync_span(staged, st, limit, T, bpm) : sync_span(words, st, limit, T, bpm);
   const size_t slot = ((size_t)frame * kSyncMaxSub + i) * kHypSlots + g;
+  const uint32_t part_bits = fr.sub_bits / kWriteParts;
+  uint2* cp = sb.cp + slot * (kWriteParts - 1);
+  int* cpn = sb.cpn + slot * (kWriteParts - 1);
+  const int nm = staged ? sync_span(staged, st, limit, T, bpm, i * fr.sub_bits, part_bits, cp, cpn)
+                        : sync_span(words, st, limit, T, bpm, i * fr.sub_bits, part_bits, cp, cpn);
   sb.ent[slot] = make_uint2(entry.p, entry.cz);
   sb.ext[slot] = make_uint2(st.p, st.cz);
   sb.nm[slot] = nm;
@@ -494,9 +546,12 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_extend(const HuffScan
   SyncState st;
   st.p = cand.x, st.cz = cand.y;
   const uint32_t limit = lim & 0x7FFFFFFFu;
-  const int nm = staged ? sync_span(staged, st, limit, T, (int)sc.blocks_per_mcu)
-                        : sync_span(words, st, limit, T, (int)sc.blocks_per_mcu);
   const size_t o = (fbase + i) * kHypSlots + slot;
+  const uint32_t part_bits = fr.sub_bits / kWriteParts;
+  uint2* cp = sb.cp + o * (kWriteParts - 1);
+  int* cpn = sb.cpn + o * (kWriteParts - 1);
+  const int nm = staged ? sync_span(staged, st, limit, T, (int)sc.blocks_per_mcu, i * fr.sub_bits, part_bits, cp, cpn)
+                        : sync_span(words, st, limit, T, (int)sc.blocks_per_mcu, i * fr.sub_bits, part_bits, cp, cpn);
   sb.ent[o] = cand;
   sb.ext[o] = make_uint2(st.p, st.cz);
   sb.nm[o] = nm;
@@ -632,10 +687,11 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_resolve(const HuffScan* _
       const uint2 x = sb.ext[(fbase + m - 1) * kHypSlots + tq];
       SyncState st;
       st.p = x.x, st.cz = x.y;
-      const int nm = sync_span(words, st, sb.lim[fbase + m] & 0x7FFFFFFFu, T, (int)sc.blocks_per_mcu);
       const int n = cnt[fbase + m];
       const int dst = n < kHypSlots - 1 ? n : kHypSlots - 2;  // append, or recycle the last usable slot
       const size_t o = (fbase + m) * kHypSlots + dst;
+      const int nm = sync_span(words, st, sb.lim[fbase + m] & 0x7FFFFFFFu, T, (int)sc.blocks_per_mcu, (uint32_t)m * fr.sub_bits,
+                               fr.sub_bits / kWriteParts, sb.cp + o * (kWriteParts - 1), sb.cpn + o * (kWriteParts - 1));
       sb.ent[o] = x;
       sb.ext[o] = make_uint2(st.p, st.cz);
       sb.nm[o] = nm;
@@ -658,6 +714,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_resolve(const HuffScan* _
     if (i < nsub) {
       const size_t o = (fbase + i) * kHypSlots + slot[q];
       sb.start[fbase + i] = sb.ent[o];
+      sb.tslot[fbase + i] = (uint8_t)slot[q];  // k_huff_write finds the checkpoints of the true chain there
       my_nm[q] = sb.nm[o];
     }
     sum += my_nm[q];
@@ -694,35 +751,40 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
                                                                  const JpegFrameDesc* __restrict__ descs, SyncBuffers sb,
                                                                  int16_t* __restrict__ coef, size_t coef_stride,
                                                                  uint32_t* __restrict__ status) {
+  // kWriteParts lanes per subsequence: lane (i, q) decodes the symbols that start in part q, from the subsequence's true
+  // entry state (q = 0) or from the checkpoint the state-only walk of the true chain left at boundary q
+  constexpr uint32_t kSubsPerBlock = kSyncLaneThreads / kWriteParts;
   __shared__ WriteTables T;
   __shared__ uint32_t s_stream[kStageWords];
   const int frame = blockIdx.y, tid = threadIdx.x;
   const SyncFrame fr = sb.frames[frame];
-  if (blockIdx.x * kSyncLaneThreads >= fr.nsub) return;  // uniform
+  if (blockIdx.x * kSubsPerBlock >= fr.nsub) return;  // uniform
   const HuffScan& sc = scans[frame];
   load_sync_tables(T, sc, luts, descs + frame, tid, kSyncLaneThreads);
   const uint32_t* words = reinterpret_cast<const uint32_t*>(sb.stream + (size_t)frame * sb.stream_stride);
-  const uint32_t* staged = stage_stream(s_stream, words, fr, blockIdx.x * kSyncLaneThreads,
-                                        min(blockIdx.x * kSyncLaneThreads + kSyncLaneThreads - 1, fr.nsub - 1), tid,
-                                        kSyncLaneThreads);
+  const uint32_t* staged = stage_stream(s_stream, words, fr, blockIdx.x * kSubsPerBlock,
+                                        min(blockIdx.x * kSubsPerBlock + kSubsPerBlock - 1, fr.nsub - 1), tid, kSyncLaneThreads);
   __syncthreads();
-  const uint32_t i = blockIdx.x * kSyncLaneThreads + tid;
+  const uint32_t i = blockIdx.x * kSubsPerBlock + (uint32_t)tid / kWriteParts;
+  const uint32_t q = (uint32_t)tid % kWriteParts;
   if (i >= fr.nsub) return;
   const size_t fbase = (size_t)frame * kSyncMaxSub;
-  const uint2 e = sb.start[fbase + i];
+  const size_t cpo = ((fbase + i) * kHypSlots + sb.tslot[fbase + i]) * (kWriteParts - 1);
+  const uint2 e = q == 0 ? sb.start[fbase + i] : sb.cp[cpo + q - 1];
+  const int mcu_first = sb.mcu0[fbase + i] + (q == 0 ? 0 : sb.cpn[cpo + q - 1]);
   SyncState st;
   st.p = e.x, st.cz = e.y;
   bool bad = false;
-  const uint32_t limit = sb.lim[fbase + i] & 0x7FFFFFFFu;
+  const uint32_t part_bits = fr.sub_bits / kWriteParts;
+  uint32_t limit = sb.lim[fbase + i] & 0x7FFFFFFFu;
+  if (q + 1 < kWriteParts) limit = min(limit, i * fr.sub_bits + (q + 1) * part_bits);
   const HuffInterval& sg = ivs[sc.seg_base + sb.seg[fbase + i]];
   const int mcu_end = (int)(sg.mcu0 + sg.nmcu);  // (a segment never writes into the next one's MCUs)
   int16_t* fdc = sb.dc + (size_t)frame * sb.dc_stride;
   if (staged)
-    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, sb.mcu0[fbase + i], mcu_end,
-               &bad);
+    write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, mcu_first, mcu_end, &bad);
   else
-    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, sb.mcu0[fbase + i], mcu_end,
-               &bad);
+    write_span(words, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, mcu_first, mcu_end, &bad);
   if (bad) atomicOr(&status[frame], 1u);
 }
 
@@ -789,38 +851,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
   }
 }
 
-__global__ __launch_bounds__(256) void k_zero_coef(int16_t* __restrict__ coef, size_t coef_stride, uint32_t vec_per_frame,
-                                                   uint32_t* __restrict__ status, int16_t* __restrict__ dc, size_t dc_stride,
-                                                   uint32_t dc_vec_per_frame) {
-  // the batch's first kernel also clears the per-frame decode status (a memset launch of its own otherwise)
-  if (blockIdx.x == 0 && threadIdx.x == 0) status[blockIdx.y] = 0;
-  // 16-byte stores; coef_stride is a multiple of 8 int16
-  uint4* dst = reinterpret_cast<uint4*>(coef + (size_t)blockIdx.y * coef_stride);
-  for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < vec_per_frame; v += gridDim.x * 256) dst[v] = make_uint4(0, 0, 0, 0);
-  // the DC side array of the frame (one int16 per block: 1/64 of the slab)
-  if (dc && (dc_stride & 7) == 0) {
-    uint4* d = reinterpret_cast<uint4*>(dc + (size_t)blockIdx.y * dc_stride);
-    for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < dc_vec_per_frame; v += gridDim.x * 256) d[v] = make_uint4(0, 0, 0, 0);
-  } else if (dc) {  // (frame bases not 16-byte aligned: tiny max_src sizes only)
-    int16_t* d = dc + (size_t)blockIdx.y * dc_stride;
-    for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < dc_vec_per_frame * 8; v += gridDim.x * 256)
-      if (v < dc_stride) d[v] = 0;
-  }
-}
-
 }  // namespace
-
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s,
-                      int16_t* d_dc, size_t dc_stride) {
-  if (!frames) return;
-  const uint32_t vecs = (uint32_t)((used_int16 + 7) / 8);
-  const unsigned gx = std::min<unsigned>((vecs + 1023) / 1024, 256u);  // >= 4 stores per thread
-  // DC entries of the used blocks, in whole 16-byte stores that stay inside the frame's dc_stride
-  uint32_t dc_vecs = 0;
-  if (d_dc) dc_vecs = (uint32_t)std::min<size_t>((used_int16 / 64 + 7) / 8, (dc_stride + 7) / 8);
-  hipLaunchKernelGGL(k_zero_coef, dim3(std::max(gx, 1u), frames), dim3(256), 0, s, d_coef, coef_stride, vecs, d_status,
-                     dc_vecs ? d_dc : nullptr, dc_stride, dc_vecs);
-}
 
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride, SyncBuffers* layout) {
   // carve one allocation: returns the size; with layout != nullptr fills offsets relative to layout->stream
@@ -843,6 +874,9 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_s
   const size_t o_lim = take(subs * sizeof(uint32_t));
   const size_t o_seg = take(subs * sizeof(uint16_t));
   const size_t o_dc = take(dc_stride * sizeof(int16_t) * max_frames);
+  const size_t o_cp = take(subs * kHypSlots * (kWriteParts - 1) * sizeof(uint2));
+  const size_t o_cpn = take(subs * kHypSlots * (kWriteParts - 1) * sizeof(int));
+  const size_t o_tslot = take(subs);
   if (layout) {
     uint8_t* base = layout->stream;
     layout->stream = base + o_stream;
@@ -859,6 +893,9 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_s
     layout->seg = reinterpret_cast<uint16_t*>(base + o_seg);
     layout->dc = reinterpret_cast<int16_t*>(base + o_dc);
     layout->dc_stride = dc_stride;
+    layout->cp = reinterpret_cast<uint2*>(base + o_cp);
+    layout->cpn = reinterpret_cast<int*>(base + o_cpn);
+    layout->tslot = base + o_tslot;
     layout->max_frames = max_frames;
   }
   return off;
@@ -867,8 +904,16 @@ size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_s
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
-                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook) {
+                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook, size_t zero_int16) {
   if (!frames) return;
+  // the slab (first zero_int16 coefficients of every frame), the DC side array and the decode status are cleared by the
+  // first launch of the chain, beside the unstuffing
+  ZeroArgs za{};
+  za.coef = d_coef, za.coef_stride = coef_stride, za.vec_per_frame = (uint32_t)((zero_int16 + 7) / 8);
+  za.dc = sb.dc, za.dc_stride = sb.dc_stride;
+  za.dc_vec_per_frame = (uint32_t)std::min<size_t>((zero_int16 / 64 + 7) / 8, (sb.dc_stride + 7) / 8);
+  za.status = d_status;
+  const unsigned zero_rows = zero_int16 ? std::min<unsigned>((za.vec_per_frame + 4095) / 4096, 64u) : 0u;  // >= 4 stores per thread
   const uint32_t nsub = std::max(max_nsub, 1u);  // slots of the longest frame
   uint8_t* cnt_a = sb.cnt;
   uint8_t* cnt_b = sb.cnt + (size_t)sb.max_frames * kSyncMaxSub;
@@ -879,7 +924,9 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
     launch();
     if (hook && *hook) (*hook)(name, false);
   };
-  stage("huff_unstuff", [&] { hipLaunchKernelGGL(k_huff_unstuff, dim3(frames), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb); });
+  stage("huff_unstuff", [&] {
+    hipLaunchKernelGGL(k_huff_unstuff, dim3(frames, 1 + zero_rows), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb, za);
+  });
   stage("huff_seed", [&] {
     hipLaunchKernelGGL(k_huff_seed, dim3((nsub * max_blocks_per_mcu + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s,
                        d_scans, d_luts, sb, cnt_a);
@@ -892,7 +939,7 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
     hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_a, d_status);
   });
   stage("huff_write", [&] {
-    hipLaunchKernelGGL(k_huff_write, dim3((nsub + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
+    hipLaunchKernelGGL(k_huff_write, dim3((nsub * kWriteParts + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
                        d_luts, d_descs, sb, d_coef, coef_stride, d_status);
   });
   stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, sb.dc, sb.dc_stride); });

@@ -90,20 +90,21 @@ struct SyncBuffers {
   unsigned long long* map = nullptr;  // [frame][subsequence] slot -> slot of the next subsequence, 16 nibbles
   int16_t* dc = nullptr;   // [frame][block] DC term of every block (differences from k_huff_write, values after k_dc_prefix)
   size_t dc_stride = 0;
+  uint2* cp = nullptr;     // [frame][subsequence][slot][3] state at the part boundaries inside the subsequence (checkpoints of the walk)
+  int* cpn = nullptr;      // ... MCUs completed in front of each
+  uint8_t* tslot = nullptr;  // [frame][subsequence] slot of the true chain (k_huff_resolve)
   uint32_t max_frames = 0;
 };
 // Called before (true) and after (false) each kernel of the pipeline with its short name (profiling).
 using HuffStageHook = std::function<void(const char* kernel, bool begin)>;
 // Size of the allocation for `max_frames` frames; with `layout` (layout->stream = base pointer) fills it in.
 size_t sync_buffers_bytes(uint32_t max_frames, size_t stream_stride, size_t dc_stride /* blocks per frame */, SyncBuffers* layout);
-// Zeroes the first `used_int16` coefficients of `frames` slabs (the entropy kernels store non-zeros only).
-// d_dc (optional): the frames' DC side array (SyncBuffers::dc), cleared for the used blocks as well.
-void launch_zero_coef(int16_t* d_coef, size_t coef_stride, size_t used_int16, uint32_t frames, uint32_t* d_status, hipStream_t s,
-                      int16_t* d_dc = nullptr, size_t dc_stride = 0);
 void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const HuffInterval* d_ivs, uint32_t frames,
                          uint32_t max_nsub, uint32_t max_blocks_per_mcu, const SyncLutImage* d_luts,
                          const JpegFrameDesc* d_descs, int16_t* d_coef, size_t coef_stride, const SyncBuffers& sb,
-                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook = nullptr);
+                         uint32_t* d_status, hipStream_t s, const HuffStageHook* hook = nullptr, size_t zero_int16 = 0);
+// (zero_int16 > 0: the first launch also clears that many coefficients of every frame's slab, the DC side array and
+// d_status -- what launch_zero_coef does as a launch of its own)
 
 // 4:2:0 YCbCr specialisation (every frame of the batch: 3 components, 2x2 luma sampling, fancy
 // upsampling applicable, W % 8 == 0): same results, 8 pixels per thread with wide loads.

@@ -1437,12 +1437,8 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
 // pointers are device memory (the context's double buffers, or a staged batch).
 int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t count, const uint8_t* d_blob,
                            const JpegFrameDesc* d_descs, const HuffScan* d_scans, const HuffInterval* d_ivs, int16_t* d_coef) {
-  {
-    ProfScope ps(m, "zero_coef", (double)p.used_coef * 2 * count, 0);
-    // (also clears d_status and the frames' DC side array: a frame the decoder flags corrupt then reconstructs from zeros,
-    // not from what an earlier batch left there)
-    launch_zero_coef(d_coef, m->coef_stride, p.used_coef, count, c.d_status, c.stream, c.sync.dc, c.sync.dc_stride);
-  }
+  // (the slabs, the DC side array and d_status are cleared by the chain's first launch, beside the unstuffing: a frame
+  // the decoder flags corrupt then reconstructs from zeros, not from what an earlier batch left there)
   {
     std::unique_ptr<ProfScope> scope;
     const double bytes = (double)p.used_blob;
@@ -1451,7 +1447,7 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
       else scope.reset();
     };
     launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_nsub, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
-                        c.sync, c.d_status, c.stream, &hook);
+                        c.sync, c.d_status, c.stream, &hook, p.used_coef);
   }
   return UFD_OK;
 }
