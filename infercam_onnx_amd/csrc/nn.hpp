@@ -6,6 +6,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -50,6 +51,28 @@ class UltrafaceModel : public InferModel {
     cfg.weights = weights;
     cfg.weights_floats = weights_floats;
     if (ufd_create(&cfg, &h_) != UFD_OK) throw std::runtime_error(std::string("ufd_create: ") + ufd_last_error(nullptr));
+  }
+  // One model per GPU of `devices` inside ONE process (infer_server.rs:39-68 is one process): UltrafaceModel::new once,
+  // the packed weights broadcast to the other GPUs over RCCL (ufd_create_replicas).  Stream i -> models[i % devices.size()].
+  static std::vector<std::unique_ptr<UltrafaceModel>> new_replicas(UltrafaceVariant variant, float max_iou, float min_confidence,
+                                                                  const std::vector<int32_t>& devices, uint32_t max_batch = 1,
+                                                                  const char* weights_path = nullptr, const float* weights = nullptr,
+                                                                  size_t weights_floats = 0) {
+    ufd_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.variant = static_cast<uint32_t>(variant);
+    cfg.max_iou = max_iou;
+    cfg.min_confidence = min_confidence;
+    cfg.max_batch = max_batch;
+    cfg.weights_path = weights_path;
+    cfg.weights = weights;
+    cfg.weights_floats = weights_floats;
+    std::vector<ufd_model*> hs(devices.size(), nullptr);
+    if (ufd_create_replicas(&cfg, devices.data(), (uint32_t)devices.size(), hs.data()) != UFD_OK)
+      throw std::runtime_error(std::string("ufd_create_replicas: ") + ufd_last_error(nullptr));
+    std::vector<std::unique_ptr<UltrafaceModel>> models;
+    for (ufd_model* h : hs) models.emplace_back(new UltrafaceModel(h));
+    return models;
   }
   ~UltrafaceModel() override { ufd_destroy(h_); }
   UltrafaceModel(const UltrafaceModel&) = delete;
@@ -103,6 +126,7 @@ class UltrafaceModel : public InferModel {
   ufd_model* handle() { return h_; }
 
  private:
+  explicit UltrafaceModel(ufd_model* adopted) : h_(adopted) {}
   static constexpr uint32_t kCap = 1024;
   static std::vector<std::pair<Bbox, float>> collect(const std::vector<ufd_det>& d, uint32_t n) {
     std::vector<std::pair<Bbox, float>> r;

@@ -56,6 +56,12 @@ int main(int argc, char** argv) {
           aw != w || ah != h)
         return std::printf("annotated stream is not a %ux%u JPEG\n", w, h), 1;
     }
+    // the single-process multi-GPU constructor of the mirror (one replica here: RCCL forms a one-rank communicator)
+    auto replicas = ufd::UltrafaceModel::new_replicas(ufd::UltrafaceVariant::W640H480, 0.5f, 0.5f, {0}, 1, nullptr,
+                                                      reinterpret_cast<const float*>(wbytes.data()), wbytes.size() / 4);
+    std::vector<uint8_t> jpeg = slurp(dir + "/" + images_with_num_faces[0].first);
+    if (replicas.size() != 1 || replicas[0]->infer_jpeg(jpeg.data(), jpeg.size()) != model.infer_jpeg(jpeg.data(), jpeg.size()))
+      return std::printf("replica disagrees with the model it was copied from\n"), 1;
   } catch (const std::exception& e) {
     return std::printf("error: %s\n", e.what()), 1;
   }
