@@ -87,7 +87,8 @@ def test_create_refuses_a_batch_whose_tensors_outgrow_32_bit_offsets(weights):
 
 
 # ---------------------------------------------------------------- A2-A4
-@pytest.mark.parametrize("src", [(1280, 720), (640, 427), (640, 960), (320, 240), (640, 480), (100, 37), (333, 500)])
+@pytest.mark.parametrize("src", [(1280, 720), (640, 427), (640, 960), (320, 240), (640, 480), (100, 37), (333, 500),
+                                 (641, 479), (1279, 719), (17, 9), (1, 1), (1280, 960), (3, 700)])
 @pytest.mark.parametrize("variant", [320, 640])
 def test_preproc_bit_exact(model320, model640, oracle_lib, src, variant):
     from infercam_onnx_amd import synth
