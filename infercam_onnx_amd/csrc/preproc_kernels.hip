@@ -61,11 +61,14 @@ __global__ __launch_bounds__(256) void k_resize_norm(const uint8_t* __restrict__
   o[2 * hwp] = lut[512 + v2];
 }
 
-constexpr int kTileW = 256;        // output pixels per workgroup
 constexpr int kTileMaxRows = 16;   // source rows of a vertical window the tiled kernel takes
 constexpr int kTileMaxCols = 2048; // source columns under one tile
 
-__global__ __launch_bounds__(256) void k_resize_norm_tiled(const uint8_t* __restrict__ src, int sw, int sh, int pitch,
+// TW = output pixels per workgroup = threads.  Exact f32 arithmetic on bytes is instruction work, not bandwidth: ~270
+// instructions per output pixel (byte reads from LDS, conversions, separate multiplies and adds: nothing may be fused),
+// 1.1 TB/s of algorithmic traffic at 1280x720 -> 640x480; the per-pixel form above took 100 us for the same batch, this 87.
+template <int TW>
+__global__ __launch_bounds__(TW) void k_resize_norm_tiled(const uint8_t* __restrict__ src, int sw, int sh, int pitch,
                                                            size_t src_stride, ResizeTaps vt, ResizeTaps ht,
                                                            const float* __restrict__ lut, float* __restrict__ out, int dw,
                                                            int dh, int row_words) {
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_resize_norm_tiled(const uint8_t* __rest
   __shared__ float s_vw[kTileMaxRows];
   __shared__ int s_mis[kTileMaxRows];
   const int frame = blockIdx.z, oy = blockIdx.y, tid = threadIdx.x;
-  const int ox0 = blockIdx.x * kTileW, ox1 = min(ox0 + kTileW, dw) - 1;
+  const int ox0 = blockIdx.x * TW, ox1 = min(ox0 + TW, dw) - 1;
   const uint8_t* img = src + (size_t)frame * src_stride;
   const int vl = vt.left[oy], vn = vt.cnt[oy];
   const int c_lo = ht.left[ox0], c_hi = ht.left[ox1] + ht.cnt[ox1];  // source columns [c_lo, c_hi): windows move right with ox
@@ -87,12 +90,12 @@ __global__ __launch_bounds__(256) void k_resize_norm_tiled(const uint8_t* __rest
     if (tid == 0) s_mis[i] = mis;
     const uint32_t* wp = reinterpret_cast<const uint32_t*>(rp - mis);
     const int nw = (mis + nb + 3) >> 2;
-    for (int w = tid; w < nw; w += 256) s_raw[(size_t)i * row_words + w] = wp[w];
+    for (int w = tid; w < nw; w += TW) s_raw[(size_t)i * row_words + w] = wp[w];
   }
   __syncthreads();
   // ---- vertical pass, once per (source column, channel): t += px * w in row order (sample.rs vertical_sample)
   const uint8_t* s_bytes = reinterpret_cast<const uint8_t*>(s_raw);
-  for (int idx = tid; idx < nb; idx += 256) {
+  for (int idx = tid; idx < nb; idx += TW) {
     float t = 0.0f;
     for (int i = 0; i < vn; i++) t = __fadd_rn(t, __fmul_rn((float)s_bytes[(size_t)i * row_words * 4 + s_mis[i] + idx], s_vw[i]));
     s_t[idx] = t;
@@ -143,15 +146,16 @@ void launch_resize_norm(const uint8_t* d_src, uint32_t sw, uint32_t sh, uint32_t
                         uint32_t dh, uint32_t count, hipStream_t s) {
   if (!count) return;
   // The tiled kernel when the windows fit its LDS budget.  Window sizes from the axis ratios (the tap tables are on the
-  // device): the resampler takes ceil(2 * max(S/D, 1)) + 1 taps at most, a tile of 256 outputs spans 256 * S/D + that many columns.
+  // device): the resampler takes ceil(2 * max(S/D, 1)) + 1 taps at most, a tile of TW outputs spans TW * S/D + that many columns.
+  constexpr int tw = 128;  // (64 / 128 / 256 outputs per workgroup: 88.8 / 87.2 / 91.8 us for 1280x720 -> 640x480 at batch 16)
   const double ry = std::max((double)sh / dh, 1.0), rx = std::max((double)sw / dw, 1.0);
   const int max_rows = (int)std::ceil(2.0 * ry) + 2;
-  const int max_cols = (int)std::ceil(kTileW * (double)sw / dw + 2.0 * rx) + 4;
+  const int max_cols = (int)std::ceil(tw * (double)sw / dw + 2.0 * rx) + 4;
   const int row_words = (max_cols * 3 + 3 + 3) / 4 + 1;
   const size_t lds = ((size_t)max_rows * row_words + (size_t)max_cols * 3) * 4;
   if (max_rows <= kTileMaxRows && max_cols <= kTileMaxCols && vert.stride <= kTileMaxRows && lds <= 60 * 1024) {
-    dim3 grid((dw + kTileW - 1) / kTileW, dh, count);
-    hipLaunchKernelGGL(k_resize_norm_tiled, grid, dim3(256), lds, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
+    dim3 grid((dw + tw - 1) / tw, dh, count);
+    hipLaunchKernelGGL(k_resize_norm_tiled<tw>, grid, dim3(tw), lds, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
                        d_norm_lut, d_out, (int)dw, (int)dh, row_words);
     return;
   }
