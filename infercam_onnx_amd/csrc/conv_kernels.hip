@@ -23,6 +23,8 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+
+#include <type_traits>
 #include <vector>
 
 namespace ufd {
@@ -44,6 +46,14 @@ __device__ __forceinline__ float lane_next(float x) {  // value of lane + 1
 // ReLU of a value that comes out of an MFMA: fmaxf() costs a canonicalising v_max first (the
 // compiler cannot know the accumulator is not a signalling NaN); for non-NaN floats the integer
 // maximum with 0 is the same function (negative floats, -0 included, are negative integers).
+// a * b + c on the 24-bit multiplier (v_mad_i32_i24, full rate): exact for |a|, |b| < 2^23
+// (as an instruction: the compiler turns __mul24 of values it knows to be small back into a generic multiply and then
+// selects the quarter-rate v_mul_lo_u32 for some of them)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float relu_acc(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 __device__ __forceinline__ float4 relu4(float4 v) {
@@ -54,25 +64,57 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 // Shared tail of the 32x32x2 kernels.  D layout: reg r, lane l -> cout (r&3) + 8*(r>>2) + 4*(l>>5),
 // pixel column l&31; MFMA j of a k-step used component j of the lane's float4, so register r of
 // the four accumulators is the float4 of 4 consecutive pixels.
+// Everything the 16 * CT stores of a lane share is computed ONCE: tensor bases, channel step and flags pinned in scalar
+// registers (left to itself the compiler re-read them from the kernel arguments in front of every store, a scalar-memory
+// round trip apiece), the lane's 32-bit byte offset of its first channel (tensors stay below 4 GiB: ufd_create checks),
+// and whether the tile is a full one (wave-uniform: no per-store bound test then).  Before, every store carried its own
+// 64-bit (frame * channels + co) * hw + pix: a dozen quarter-rate integer multiplies each, 190 per wave.
 template <int CT>
 __device__ __forceinline__ void store_tiles(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half, size_t frame,
                                             int pix, int hw) {
+  typedef __attribute__((address_space(1))) char gchar;  // (global: a pointer that went through the asm below is generic, flat_store)
+  char* out = reinterpret_cast<char*>(a.out);
+  const char* res = reinterpret_cast<const char*>(a.res);
+  int cout = a.cout, relu = a.relu;
+  const int co0 = ct0 * 32 + 4 * half;  // the lane's first output channel
+  const uint32_t fr = (uint32_t)frame;
+  const uint32_t off = 4u * (__umul24(__umul24(fr, (uint32_t)a.out_ctotal) + (uint32_t)(a.out_coff + co0), (uint32_t)hw) + (uint32_t)pix);
+  const uint32_t roff = 4u * (__umul24(__umul24(fr, (uint32_t)cout) + (uint32_t)co0, (uint32_t)hw) + (uint32_t)pix);
+  uint32_t step = 4u * (uint32_t)hw;  // bytes between output channels
+  uint32_t step5 = 5u * step;         // ... and from channel 4q + 3 to 4q + 8 (the other half's channels lie between)
+  asm volatile("" : "+s"(out), "+s"(res), "+s"(cout), "+s"(relu), "+s"(step), "+s"(step5));
+  gchar* gout = (gchar*)out;
+  const gchar* gres = (const gchar*)res;
+  // ReLU without a test: the integer maximum with 0 is ReLU for non-NaN floats (relu_acc), with INT_MIN the identity
+  int lowest = relu ? 0 : (int)0x80000000;
+  asm volatile("" : "+s"(lowest));
+  auto emit = [&](auto guarded) {
+    // the offsets walk from channel to channel by one vector add of a scalar each (opaque to the compiler, which otherwise
+    // turns base + r * step back into a 64-bit multiply-add per store)
+    uint32_t o = off, ro = roff;
 #pragma unroll
-  for (int ct = 0; ct < CT; ct++) {
+    for (int ct = 0; ct < CT; ct++) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.cout) {
-        float4 v = make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
-        if (a.res) {
-          const float4 q = *reinterpret_cast<const float4*>(a.res + (frame * a.cout + co) * hw + pix);
-          v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+      for (int r = 0; r < 16; r++) {
+        const int cr = ct * 32 + (r & 3) + 8 * (r >> 2);
+        if (!decltype(guarded)::value || co0 + cr < cout) {
+          float4 v = make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
+          if (res) {  // (no launch of the product plan: the RFB's shortcut is summed as a second input of its 1x1 conv)
+            const floatx4 q = *reinterpret_cast<const __attribute__((address_space(1))) floatx4*>(gres + ro);
+            v.x += q[0], v.y += q[1], v.z += q[2], v.w += q[3];
+          }
+          const floatx4 vv = {__int_as_float(max(__float_as_int(v.x), lowest)), __int_as_float(max(__float_as_int(v.y), lowest)),
+                              __int_as_float(max(__float_as_int(v.z), lowest)), __int_as_float(max(__float_as_int(v.w), lowest))};
+          *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(gout + o) = vv;
         }
-        if (a.relu) v = relu4(v);
-        *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * hw + pix) = v;
+        const uint32_t d = (r & 3) == 3 ? step5 : step;
+        o += d, ro += d;
+        asm volatile("" : "+v"(o), "+v"(ro));
       }
     }
-  }
+  };
+  if ((ct0 + CT) * 32 <= cout) emit(std::false_type{});  // full tile (wave-uniform): no bound test per store
+  else emit(std::true_type{});
 }
 
 // XCD-aware block order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
@@ -90,16 +132,20 @@ __device__ __forceinline__ bool remap_block(const ConvArgs& a, int bx, int* tile
 template <int CT>
 __device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half) {
   // (pointer and bound pinned in scalar registers: left to itself the compiler re-reads them from the kernel arguments
-  // inside each of the 16 conditional blocks, a scalar-memory round trip apiece)
+  // inside each of the 16 conditional blocks, a scalar-memory round trip apiece.  The loads stay conditional: sixteen
+  // unconditional ones -- clamped, or on a wave-uniform "full tile" path -- make hipcc keep the 64 accumulators in vector
+  // registers through the prologue, 204 VGPRs for 98 and one wave per SIMD instead of three)
   const float* bias = a.bias;
   int cout = a.cout;
   asm volatile("" : "+s"(bias), "+s"(cout));
+  typedef const __attribute__((address_space(1))) float gfloat;  // (global: a pointer that went through the asm above is generic, flat_load)
+  gfloat* gbias = (gfloat*)bias;
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float b = co < cout ? bias[co] : 0.0f;
+      const float b = co < cout ? gbias[co] : 0.0f;
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[ct][j][r] = b;
     }
@@ -167,10 +213,13 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   }
   __syncthreads();
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
-  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * 32 + (lane & 31);
-  const bool live = g < (long)a.B * gpf;
-  const size_t frame = live ? g / gpf : 0;
-  const int pix = live ? (int)(g - (long)frame * gpf) * 4 : 0;
+  // (32-bit index arithmetic: a tensor below 4 GiB has fewer than 2^28 pixel groups; the 64-bit division this used to be
+  // is a ~100-instruction routine full of quarter-rate multiplies)
+  const int g = (SK == 1 ? (tile * 4 + wave) : tile) * 32 + (lane & 31);
+  const bool live = g < a.B * gpf;
+  const uint32_t frame32 = live ? (uint32_t)g / (uint32_t)gpf : 0u;
+  const size_t frame = frame32;
+  const int pix = live ? (g - (int)frame32 * gpf) * 4 : 0;
 
   floatx16 acc[CT][4];
   init_acc<CT>(a, acc, ct0, half);
@@ -185,12 +234,12 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   }
   // wave-uniform base pointer + 32-bit per-lane element offsets (tensors are < 2^32 bytes)
   const float* __restrict__ in = a.in;
-  const uint32_t in_off = (uint32_t)((frame * a.in_ctotal + half) * hw + pix);
+  const uint32_t in_off = (frame32 * (uint32_t)a.in_ctotal + (uint32_t)half) * (uint32_t)hw + (uint32_t)pix;
   const uint32_t in_step = 2u * (uint32_t)hw;
   // two 1x1 convs over different tensors summed as one (RFB: ConvLinear(cat) + shortcut(x)):
   // k-steps from ksplit on read the second tensor (wave-uniform choice)
   const float* __restrict__ in2 = a.in2;
-  const uint32_t in2_off = in2 ? (uint32_t)((frame * a.in2_ctotal + half) * hw + pix) : 0u;
+  const uint32_t in2_off = in2 ? (frame32 * (uint32_t)a.in2_ctotal + (uint32_t)half) * (uint32_t)hw + (uint32_t)pix : 0u;
   const int ksplit = in2 ? a.ksplit : 0x7FFFFFFF;
   auto load_b = [&](int ks) -> float4 {
     if (ks >= ksplit) return *reinterpret_cast<const float4*>(in2 + (in2_off + (uint32_t)(ks - ksplit) * in_step));
@@ -280,12 +329,13 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
   float* s_red = s_w + CT * ksteps * 64;
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int j32 = lane & 31;
-  const long total = (long)a.B * gpf;
-  const long g = (SK == 1 ? ((long)tile * 4 + wave) : (long)tile) * kDwGroups + j32 - 1;
+  const int total = a.B * gpf;  // (32-bit index arithmetic, as in k_pw_mfma)
+  const int g = (SK == 1 ? (tile * 4 + wave) : tile) * kDwGroups + j32 - 1;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;  // lanes that own an output group
-  const size_t frame = inrange ? g / gpf : 0;
-  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
+  const size_t frame = frame32;
+  const int rem = inrange ? g - (int)frame32 * gpf : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
   const int ihw = a.ih * a.iw;
 
@@ -306,7 +356,7 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
   // of windows are kept in flight in a register ring.
   const int iy0 = oy * S - 1, ix0 = ox * S;
   uint32_t rowoff[3];  // 32-bit BYTE offsets from the wave-uniform base a.in (< 2^32 bytes, launcher-checked)
-  const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
+  const uint32_t lane_base = (frame32 * (uint32_t)a.in_ctotal + (uint32_t)half) * (uint32_t)ihw;
 #pragma unroll
   for (int r = 0; r < 3; r++) rowoff[r] = 4u * (lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0));
   // rows outside the image are zero padding: the lane reads its taps from the LDS copy that has
@@ -462,12 +512,13 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   float* s_dw = s_mem;                                              // [3][cin][12] (fill_dw_variants)
   float4* s_t = reinterpret_cast<float4*>(s_mem + 3 * a.cin * 12);  // [PT][3][CH][64]
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long total = (long)a.B * gpf;
-  const long g = ((long)tgrp * PT + pt) * kDwGroups + j32 - 1;
+  const int total = a.B * gpf;
+  const int g = (tgrp * PT + pt) * kDwGroups + j32 - 1;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j32 >= 1 && j32 <= kDwGroups;
-  const size_t frame = inrange ? g / gpf : 0;
-  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
+  const size_t frame = frame32;
+  const int rem = inrange ? g - (int)frame32 * gpf : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
   const int ihw = a.ih * a.iw;
   const int ct = cgrp * CTW + cw;
@@ -479,7 +530,7 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   // base, tap rows over the image border zeroed in the lane's copy of the LDS table)
   const int iy0 = oy * S - 1, ix0 = ox * S;
   uint32_t rowoff[3];
-  const uint32_t lane_base = (uint32_t)((frame * a.in_ctotal + half) * ihw);
+  const uint32_t lane_base = (frame32 * (uint32_t)a.in_ctotal + (uint32_t)half) * (uint32_t)ihw;
 #pragma unroll
   for (int r = 0; r < 3; r++) rowoff[r] = 4u * (lane_base + (uint32_t)(min(max(iy0 + r, 0), a.ih - 1) * a.iw + ix0));
   const float* s_dw_lane = s_dw + (dw_variant(iy0 >= 0, iy0 + 2 < a.ih) * a.cin + half) * 12;
@@ -818,6 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // half-1 lanes:
   //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
   //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
+  const int lowest2 = a2.relu ? 0 : (int)0x80000000;
   auto finish = [&](int oy) {
     float bop[KS2][2];  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
 #pragma unroll
@@ -859,14 +911,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bop[ks][1], acc2[1], 0, 0, 0);
       }
       if (live) {
+        // (full cout tiles only: dwpw2_supported; ReLU as the integer maximum with 0 -- relu_acc -- or with INT_MIN, the
+        // identity: no bound or flag test per store)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co < a2.cout) {
-            float2 v = make_float2(acc2[0][r], acc2[1][r]);
-            if (a2.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
-            *reinterpret_cast<float2*>(out_base + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * ohw * 4 + out_off) = v;
-          }
+          const float2 v = make_float2(__int_as_float(max(__float_as_int(acc2[0][r]), lowest2)), __int_as_float(max(__float_as_int(acc2[1][r]), lowest2)));
+          *reinterpret_cast<float2*>(out_base + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * ohw * 4 + out_off) = v;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1105,33 +1155,44 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
     for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
     __syncthreads();
   }
+  // (The k-loop of these convs is two to four channel chunks long: what surrounds it counts as much.  32-bit index
+  // arithmetic -- a tensor below 4 GiB has fewer than 2^28 pixel groups, and the 64-bit division this used to be is a
+  // ~100-instruction routine of quarter-rate multiplies; the lane's four bias values as one 16-byte load; the store
+  // offsets from one 32-bit base, below.)
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
-  const long total = (long)a.B * gpf;
-  const long g = ((long)blockIdx.x * 4 + wave) * NG + j16 - HL;
+  const int total = a.B * gpf;
+  const int g = ((int)blockIdx.x * 4 + wave) * NG + j16 - HL;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j16 >= HL && j16 < 16 - HL;
-  const size_t frame = inrange ? g / gpf : 0;
-  const int rem = inrange ? (int)(g - (long)frame * gpf) : 0;
+  const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
+  const int rem = inrange ? g - (int)frame32 * gpf : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
   const int ihw = a.ih * a.iw;
+  const int cout = a.cout;
 
   floatx4 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int co = 4 * q + r;
-      acc[j][r] = co < a.cout ? a.bias[co] : 0.0f;
+  {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((cout & 3) == 0) {  // (wave-uniform) the lane's channels 4q .. 4q+3 exist together or not at all
+      if (4 * q < cout) b4 = *reinterpret_cast<const float4*>(a.bias + 4 * q);
+    } else {
+      const float* bias = a.bias;
+      b4.x = 4 * q + 0 < cout ? bias[4 * q + 0] : 0.0f, b4.y = 4 * q + 1 < cout ? bias[4 * q + 1] : 0.0f;
+      b4.z = 4 * q + 2 < cout ? bias[4 * q + 2] : 0.0f, b4.w = 4 * q + 3 < cout ? bias[4 * q + 3] : 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j][0] = b4.x, acc[j][1] = b4.y, acc[j][2] = b4.z, acc[j][3] = b4.w;
+  }
 
   const int ix0 = ox * S;
   bool rowok[3];
   uint32_t rowoff[3];
+  const uint32_t frame_off = __umul24(__umul24(frame32, (uint32_t)a.in_ctotal), (uint32_t)ihw);
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int iy = oy * S + (r - 1) * dil;
     rowok[r] = iy >= 0 && iy < a.ih;
-    rowoff[r] = (uint32_t)(frame * a.in_ctotal * (size_t)ihw) + (uint32_t)(min(max(iy, 0), a.ih - 1) * a.iw + ix0);
+    rowoff[r] = frame_off + (uint32_t)(min(max(iy, 0), a.ih - 1) * a.iw + ix0);
   }
   // column validity of the shifted taps (stride 1: x + j -/+ DIL inside the row; stride 2: left edge)
   bool lok[4], rok[4];
@@ -1205,14 +1266,20 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   }
   if (!live) return;
   const int pix = oy * a.ow + ox;
+  // byte offset of the lane's first channel from the tensor base, a channel step per store; ReLU as the integer maximum
+  // with 0 (relu_acc), or with INT_MIN = the identity: no flag test, no canonicalising v_max
+  char* out = reinterpret_cast<char*>(a.out);
+  const uint32_t step = 4u * (uint32_t)ohw;
+  uint32_t o = 4u * (__umul24(__umul24(frame32, (uint32_t)a.out_ctotal) + (uint32_t)(a.out_coff + 4 * q), (uint32_t)ohw) + (uint32_t)pix);
+  const int lowest = a.relu ? 0 : (int)0x80000000;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int co = 4 * q + r;
-    if (co < a.cout) {
-      float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-      if (a.relu) v = relu4(v);
-      *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = v;
+    if (4 * q + r < cout) {
+      const float4 v = make_float4(__int_as_float(max(__float_as_int(acc[0][r]), lowest)), __int_as_float(max(__float_as_int(acc[1][r]), lowest)),
+                                   __int_as_float(max(__float_as_int(acc[2][r]), lowest)), __int_as_float(max(__float_as_int(acc[3][r]), lowest)));
+      *reinterpret_cast<float4*>(out + o) = v;
     }
+    o += step;
   }
 }
 
@@ -1297,11 +1364,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   constexpr int HL = 1, NG = 16 - 2 * HL;
   extern __shared__ float s_sh[];
   float* s_w = s_sh;                 // packed weights [1][9][64]
-  float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table
+  float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table, then 256 zeros (the "table" of a padding row / the pad quad)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
   for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = sa.lut[i];
+  s_lut[768 + threadIdx.x] = 0.0f;
   __syncthreads();
   // Row rolling: a wave owns a band of a.band output rows of its 14 column groups.  Output row oy reads input rows
   // 2oy-1 .. 2oy+1, so consecutive output rows share one input row: its 8 upsampled, colour-converted, normalised
@@ -1309,12 +1377,13 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   // are loaded once per band.  Groups are numbered over (frame, band, column group).
   const int R = a.band, bands = a.oh / R;
   const int ohw = a.oh * a.ow, gpr = a.ow >> 2, gpb = bands * gpr;
-  const long total = (long)a.B * gpb;
-  const long g = ((long)blockIdx.x * 4 + wave) * NG + j16 - HL;
+  const int total = a.B * gpb;  // (32-bit index arithmetic: fewer than 2^28 groups in a tensor below 4 GiB)
+  const int g = ((int)blockIdx.x * 4 + wave) * NG + j16 - HL;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j16 >= HL && j16 < 16 - HL;
-  const size_t frame = inrange ? g / gpb : 0;
-  const int rem = inrange ? (int)(g - (long)frame * gpb) : 0;
+  const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpb : 0u;
+  const size_t frame = frame32;
+  const int rem = inrange ? g - (int)frame32 * gpb : 0;
   const int band = rem / gpr, ox = (rem - band * gpr) * 4, oy0 = band * R;
   const JpegFrameDesc& d = sa.descs[frame];
   const bool frame_ok = d.width == a.iw && d.height == a.ih;  // failed frames: zero input
@@ -1324,9 +1393,13 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const int ix0 = ox * 2;       // first input column of the lane (multiple of 8)
   const int c0 = ix0 >> 1;      // first chroma column (multiple of 4)
   // per-channel colour coefficients: out = y + ((ku * (cb - 128) + kv * (cr - 128) + 32768) >> 16)
+  // as ku * cb + kv * cr + kc on the 24-bit multiplier (v_mad_i32_i24, full rate; the 32-bit v_mul_lo_u32 the compiler picks
+  // for the plain expression is a quarter-rate instruction): the same integer, |ku|, |kv| < 2^17 and cb, cr < 2^8
   const int ku = q == 1 ? -22554 : (q == 2 ? 116130 : 0);
   const int kv = q == 0 ? 91881 : (q == 1 ? -46802 : 0);
+  const int kc = 32768 - 128 * (ku + kv);
   const float* lutq = s_lut + min(q, 2) * 256;
+  const float* lut_zero = s_lut + 768;
   // every lane upsamples ONE chroma plane for its 8 pixels (R: Cr, G and B: Cb); the G lanes
   // fetch Cr from the R lane of the same pixels (16 lanes down)
   const int plane = q == 0 || q == 3 ? 2 : 1;
@@ -1343,13 +1416,14 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     uint2 yy = make_uint2(0, 0);
     uint32_t wa = 0, wb = 0;
     if (frame_ok) {
-      yy = *reinterpret_cast<const uint2*>(yplane + (size_t)yc * ypitch);
-      wa = *reinterpret_cast<const uint32_t*>(cplane + (size_t)cy * cpitch);
-      wb = *reinterpret_cast<const uint32_t*>(cplane + (size_t)ny * cpitch);
+      yy = *reinterpret_cast<const uint2*>(yplane + (uint32_t)__mul24(yc, ypitch));  // (rows and pitches < 2^23: full-rate multiplies)
+      wa = *reinterpret_cast<const uint32_t*>(cplane + (uint32_t)__mul24(cy, cpitch));
+      wb = *reinterpret_cast<const uint32_t*>(cplane + (uint32_t)__mul24(ny, cpitch));
     }
+    const float* lut_row = ok ? lutq : lut_zero;  // (a select per row instead of a branch around each of the 8 table reads)
     int sc[6];
 #pragma unroll
-    for (int i = 0; i < 4; i++) sc[1 + i] = 3 * (int)((wa >> (8 * i)) & 255) + (int)((wb >> (8 * i)) & 255);
+    for (int i = 0; i < 4; i++) sc[1 + i] = mad24(3, (int)((wa >> (8 * i)) & 255), (int)((wb >> (8 * i)) & 255));
     {
       // neighbour columns c0-1 / c0+4 from the adjacent lanes (same input row when they exist)
       const int from_prev = __shfl(sc[4], lane - 1), from_next = __shfl(sc[1], lane + 1);
@@ -1359,12 +1433,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int i = 1 + (j >> 1);
-      const int mine = (j & 1) ? (sc[i] * 3 + sc[i + 1] + 7) >> 4 : (sc[i] * 3 + sc[i - 1] + 8) >> 4;
+      const int mine = (j & 1) ? (mad24(sc[i], 3, sc[i + 1]) + 7) >> 4 : (mad24(sc[i], 3, sc[i - 1]) + 8) >> 4;
       const int peer = __shfl(mine, lane - 16);  // the R lane's Cr for the G lane
       const int cbv = mine, crv = q == 1 ? peer : mine;
       const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
-      const int px = min(255, max(0, yv + ((ku * (cbv - 128) + 32768 + kv * (crv - 128)) >> 16)));
-      v[j] = ok ? lutq[px] : 0.0f;
+      const int px = min(255, max(0, yv + (mad24(kv, crv, mad24(ku, cbv, kc)) >> 16)));
+      v[j] = lut_row[px];
     }
     const float left_raw = __shfl(v[7], lane - 1);
     v[8] = (j16 > 0 && ix0 > 0) ? left_raw : 0.0f;  // column ix0 - 1 (zero padding at the row start)
@@ -1384,6 +1458,14 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
 #pragma unroll
   for (int r = 0; r < 4; r++) bias[r] = 4 * q + r < a.cout ? a.bias[4 * q + r] : 0.0f;
 
+  // stores: 32-bit byte offset of (frame, channel 4q, row oy0, column ox) from the tensor base, a channel step per store;
+  // ReLU as the integer maximum with 0 (relu_acc), or with INT_MIN = the identity
+  char* out = reinterpret_cast<char*>(a.out);
+  const int cout = a.cout;
+  const uint32_t out_step = 4u * (uint32_t)ohw;
+  const uint32_t out_off = 4u * (__umul24(__umul24(frame32, (uint32_t)a.out_ctotal) + (uint32_t)(a.out_coff + 4 * q), (uint32_t)ohw) + (uint32_t)(oy0 * a.ow + ox));
+  const int lowest = a.relu ? 0 : (int)0x80000000;
+
   float top[9], mid[9], bot[9];
   convert_row(2 * oy0 - 1, top);
 #pragma unroll 1
@@ -1399,15 +1481,15 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     convert_row(2 * oy + 1, bot);
     mac_row(2, bot);
     if (live) {
-      const int pix = oy * a.ow + ox;
+      uint32_t o = out_off + 4u * (uint32_t)(i * a.ow);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int co = 4 * q + r;
-        if (co < a.cout) {
-          float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-          if (a.relu) o = relu4(o);
-          *reinterpret_cast<float4*>(a.out + (frame * a.out_ctotal + a.out_coff + co) * ohw + pix) = o;
+        if (4 * q + r < cout) {
+          const float4 v4 = make_float4(__int_as_float(max(__float_as_int(acc[0][r]), lowest)), __int_as_float(max(__float_as_int(acc[1][r]), lowest)),
+                                        __int_as_float(max(__float_as_int(acc[2][r]), lowest)), __int_as_float(max(__float_as_int(acc[3][r]), lowest)));
+          *reinterpret_cast<float4*>(out + o) = v4;
         }
+        o += out_step;
       }
     }
 #pragma unroll
@@ -1485,7 +1567,7 @@ void launch_stem_planes_mfma(const StemArgs& sa0, hipStream_t s) {
     if (a.oh % r == 0 && (long)a.B * (a.oh / r) * (a.ow / 4) / 14 >= 8192) band = r;
   a.band = band;
   const long groups = (long)a.B * ((a.oh / band) * a.ow / 4);
-  const size_t shmem = (9 * 64 + 768) * sizeof(float);
+  const size_t shmem = (9 * 64 + 768 + 256) * sizeof(float);  // weights, normalisation table, a row of zeros
   hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
 
@@ -1747,7 +1829,7 @@ const char* conv_dwpw2_instance(const ConvArgs& first, const ConvArgs& second) {
 }
 
 bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
-  return (first.cin == 16 || first.cin == 32) && first.cout == 32 && second.cin == 32 && second.cout <= 64 && first.relu &&
+  return (first.cin == 16 || first.cin == 32) && first.cout == 32 && second.cin == 32 && second.cout <= 64 && second.cout % 32 == 0 && first.relu &&
          first.iw % 8 == 0 && first.iw == first.ow && first.ih == first.oh && second.ow % 4 == 0 && first.ow == 2 * second.ow &&
          first.oh == 2 * second.oh && first.res == nullptr && second.res == nullptr;
 }
