@@ -129,26 +129,35 @@ __device__ __forceinline__ bool remap_block(const ConvArgs& a, int bx, int* tile
   return *tile < a.tiles;
 }
 
+// Bias of the block's cout tiles through LDS: the first 32 * NT threads place bias[co] (0 past cout) in the order the
+// accumulator rows want it -- [tile][half][16 rows] -- beside the weight tables, in front of the barrier those need anyway;
+// a lane then takes its 16 values with four 16-byte LDS reads.  (They used to be 16 conditional global loads per lane,
+// each in a branch of its own: 2.5 k of a wave's 56 k cycles on the 60x80 layers.  Unconditional global loads are no
+// remedy: hipcc then keeps the 64 accumulators in vector registers through the prologue -- 204 VGPRs for 98, one wave
+// per SIMD instead of three.)
+constexpr int kBiasLds = 32;  // floats per cout tile
+template <int NT>
+__device__ __forceinline__ void fill_bias_lds(const ConvArgs& a, float* s_bias, int tile0) {
+  const int t = threadIdx.x;
+  if (t < 32 * NT) {
+    const int r = t & 15;
+    const int co = (tile0 + (t >> 5)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
+    s_bias[t] = co < a.cout ? a.bias[co] : 0.0f;
+  }
+}
 template <int CT>
-__device__ __forceinline__ void init_acc(const ConvArgs& a, floatx16 (&acc)[CT][4], int ct0, int half) {
-  // (pointer and bound pinned in scalar registers: left to itself the compiler re-reads them from the kernel arguments
-  // inside each of the 16 conditional blocks, a scalar-memory round trip apiece.  The loads stay conditional: sixteen
-  // unconditional ones -- clamped, or on a wave-uniform "full tile" path -- make hipcc keep the 64 accumulators in vector
-  // registers through the prologue, 204 VGPRs for 98 and one wave per SIMD instead of three)
-  const float* bias = a.bias;
-  int cout = a.cout;
-  asm volatile("" : "+s"(bias), "+s"(cout));
-  typedef const __attribute__((address_space(1))) float gfloat;  // (global: a pointer that went through the asm above is generic, flat_load)
-  gfloat* gbias = (gfloat*)bias;
+__device__ __forceinline__ void init_acc(const float* s_bias, floatx16 (&acc)[CT][4], int half) {
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
+    const float4* b4 = reinterpret_cast<const float4*>(s_bias + (ct * 2 + half) * 16);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int co = (ct0 + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float b = co < cout ? gbias[co] : 0.0f;
+    for (int q = 0; q < 4; q++) {
+      const float4 b = b4[q];
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[ct][j][r] = b;
+      for (int j = 0; j < 4; j++) acc[ct][j][4 * q] = b.x, acc[ct][j][4 * q + 1] = b.y, acc[ct][j][4 * q + 2] = b.z, acc[ct][j][4 * q + 3] = b.w;
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("" : "+a"(acc[ct][j]));  // (the values are in the accumulation registers from here on)
   }
 }
 
@@ -202,8 +211,9 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   int tile, ctile;
   if (!remap_block(a, bx, &tile, &ctile)) return;
   const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
-  float* s_w = s_mem;
-  float* s_red = s_mem + CT * ksteps * 64;
+  float* s_bias = s_mem;  // [CT][2][16]
+  float* s_w = s_mem + CT * kBiasLds;
+  float* s_red = s_w + CT * ksteps * 64;
   {
     const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
     float4* wdst = reinterpret_cast<float4*>(s_w);
@@ -211,6 +221,7 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
 #pragma unroll 4
     for (int i = threadIdx.x; i < w4; i += 256) wdst[i] = wsrc[i];
   }
+  fill_bias_lds<CT>(a, s_bias, ct0);
   __syncthreads();
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
   // (32-bit index arithmetic: a tensor below 4 GiB has fewer than 2^28 pixel groups; the 64-bit division this used to be
@@ -222,7 +233,7 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   const int pix = live ? (g - (int)frame32 * gpf) * 4 : 0;
 
   floatx16 acc[CT][4];
-  init_acc<CT>(a, acc, ct0, half);
+  init_acc<CT>(s_bias, acc, half);
   const int kper = ksteps / SK, kbeg = (SK == 1) ? 0 : wave * kper, kend = kbeg + kper;
   if (SK > 1 && wave > 0) {
 #pragma unroll
@@ -324,8 +335,9 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
   int tile, ctile;
   if (!remap_block(a, bx, &tile, &ctile)) return;  // whole block, before the barrier
   const int ct0 = ctile * CT, half = lane >> 5, ksteps = a.cin >> 1;
-  float* s_dw = s_mem;
-  float* s_w = s_mem + 3 * a.cin * 12;
+  float* s_bias = s_mem;  // [CT][2][16]
+  float* s_dw = s_mem + CT * kBiasLds;
+  float* s_w = s_dw + 3 * a.cin * 12;
   float* s_red = s_w + CT * ksteps * 64;
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int j32 = lane & 31;
@@ -339,17 +351,7 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
   const int ihw = a.ih * a.iw;
 
-  floatx16 acc[CT][4];
-  init_acc<CT>(a, acc, ct0, half);
   const int kper = ksteps / SK, kbeg = (SK == 1) ? 0 : wave * kper, kend = kbeg + kper;
-  if (SK > 1 && wave > 0) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
-  }
 
   // input window: rows iy0..iy0+2, columns ix0 .. ix0+4*S-1 (ix0 = ox*S, a multiple of 4).
   // Loads are unconditional from clamped (always valid) addresses and zeroed by select; D k-steps
@@ -434,7 +436,18 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
       else wdst[i - n4] = v;
     }
   }
+  fill_bias_lds<CT>(a, s_bias, ct0);
   __syncthreads();
+  floatx16 acc[CT][4];
+  init_acc<CT>(s_bias, acc, half);
+  if (SK > 1 && wave > 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ct][j][r] = 0.0f;
+  }
   float tcur[4];
   dw_compute(ring[0], kbeg, tcur);
   for (int ks0 = kbeg; ks0 < kend; ks0 += D) {
@@ -509,8 +522,9 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   }
   if (tgrp >= a.tiles) return;  // whole block, before any barrier
   const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
-  float* s_dw = s_mem;                                              // [3][cin][12] (fill_dw_variants)
-  float4* s_t = reinterpret_cast<float4*>(s_mem + 3 * a.cin * 12);  // [PT][3][CH][64]
+  float* s_bias = s_mem;                                            // [CTW][2][16]
+  float* s_dw = s_mem + CTW * kBiasLds;                             // [3][cin][12] (fill_dw_variants)
+  float4* s_t = reinterpret_cast<float4*>(s_dw + 3 * a.cin * 12);   // [PT][3][CH][64]
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int total = a.B * gpf;
   const int g = (tgrp * PT + pt) * kDwGroups + j32 - 1;
@@ -523,8 +537,12 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   const int ihw = a.ih * a.iw;
   const int ct = cgrp * CTW + cw;
 
+  // (a barrier of its own for the bias, at the very start where the block's waves are in step anyway: initialising the
+  // accumulators behind the prologue's barrier instead makes hipcc keep two copies of them, 162 + 128 registers)
+  fill_bias_lds<CTW>(a, s_bias, cgrp * CTW);
+  __syncthreads();
   floatx16 acc[1][4];
-  init_acc<1>(a, acc, ct, half);
+  init_acc<1>(s_bias + cw * kBiasLds, acc, half);
 
   // (addressing and border handling as in k_dwpw_mfma: byte offsets from a wave-uniform channel
   // base, tap rows over the image border zeroed in the lane's copy of the LDS table)
@@ -1645,7 +1663,7 @@ static PwConfig pw_config(const ConvArgs* args, int n) {
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
   c.sk = want_splitk(wave_tiles, max_cts * n, c.ksteps);
-  c.lds = (size_t)c.ksteps * 64 * sizeof(float) + (c.sk ? kSplitKBytes : 0);
+  c.lds = ((size_t)kBiasLds + (size_t)c.ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
     c.p.a[i] = args[i];
@@ -1704,7 +1722,7 @@ static DwpwConfig dwpw_config(const ConvArgs* args, int n) {
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
   c.sk = want_splitk(wave_tiles, max_cts * n, ksteps);
   c.deep = ksteps % 4 == 0;
-  c.lds = ((size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
+  c.lds = ((size_t)kBiasLds + (size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
     c.p.a[i] = args[i];
@@ -1734,7 +1752,7 @@ static CoopConfig coop_config(const ConvArgs* args) {
   c.p.a[0].cts = max_cts;
   c.p.a[0].tiles = (int)((wave_tiles + ptiles - 1) / ptiles);  // pixel-tile groups
   c.blocks = (unsigned)((c.p.a[0].tiles + 7) / 8) * 8 * (max_cts / c.ctw);
-  c.lds = (size_t)r.cin * 36 * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
+  c.lds = ((size_t)c.ctw * kBiasLds + (size_t)r.cin * 36) * sizeof(float) + (size_t)ptiles * 3 * 8 * 64 * sizeof(float4);
   return c;
 }
 
