@@ -287,11 +287,13 @@ __device__ __forceinline__ void load_sync_tables(SyncTablesT<kWrite>& T, const H
   uint4* dst = reinterpret_cast<uint4*>(&T);
   if (nthreads == kSyncLaneThreads) {
     constexpr int kPer = (kVec + kSyncLaneThreads - 1) / kSyncLaneThreads;
+    // (unconditional loads from clamped indices, predicated stores: with the load under the predicate as well the array
+    // went to SCRATCH memory and every piece became load -> wait -> scratch store ... scratch load -> wait -> LDS store)
     uint4 r[kPer];
 #pragma unroll
     for (int q = 0; q < kPer; q++) {
-      const int i = tid + q * kSyncLaneThreads;
-      if (i < kVec) r[q] = src[i < kHead ? i : i + kSkip];
+      const int i = min(tid + q * kSyncLaneThreads, kVec - 1);
+      r[q] = src[i < kHead ? i : i + kSkip];
     }
 #pragma unroll
     for (int q = 0; q < kPer; q++)

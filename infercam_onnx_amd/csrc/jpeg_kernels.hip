@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void k_upsample_rgb(const JpegFrameDesc* __res
     o32[1] = w1;
     o32[2] = w2;
   } else {
-    for (int j = 0; j < 4 && x0 + j < d.width; j++) {
+#pragma unroll  // (constant indices: a run-time j sends r / g / b to scratch memory)
+    for (int j = 0; j < 4; j++) {
+      if (x0 + j >= d.width) break;
       o[3 * j] = (uint8_t)r[j];
       o[3 * j + 1] = (uint8_t)g[j];
       o[3 * j + 2] = (uint8_t)b[j];
@@ -286,7 +288,9 @@ __global__ __launch_bounds__(256) void k_upsample_norm(const JpegFrameDesc* __re
     *reinterpret_cast<float4*>(o + 2 * hw) =
         make_float4(lut[512 + b[0]], lut[512 + b[1]], lut[512 + b[2]], lut[512 + b[3]]);
   } else {
-    for (int j = 0; j < 4 && x0 + j < W; j++) {
+#pragma unroll  // (constant indices, as above)
+    for (int j = 0; j < 4; j++) {
+      if (x0 + j >= W) break;
       o[j] = lut[r[j]];
       o[hw + j] = lut[256 + g[j]];
       o[2 * hw + j] = lut[512 + b[j]];
