@@ -547,15 +547,21 @@ __global__ __launch_bounds__(kExtendThreads) void k_huff_extend(const HuffScan* 
   const int k = (int)(lane % kHypSlots);
   const bool in_range = i < fr.nsub;
   const size_t fbase = (size_t)frame * kSyncMaxSub;
-  const uint32_t lim = in_range ? sb.lim[fbase + i] : 0x80000000u;
+  // All five loads of the lane are issued together, from clamped (always allocated) slots, and masked afterwards: as
+  // `x = cond ? load : c` chains they were four dependent memory round trips in a row (limit -> counts -> candidate -> entry).
+  const uint32_t ic = min(i, fr.nsub - 1), ip = ic > 0 ? ic - 1 : 0;  // (fr.nsub >= 1: the block passed the test above)
+  const uint32_t lim_raw = sb.lim[fbase + ic];
+  const int nc_raw = cnt_in[fbase + ic], np_raw = cnt_in[fbase + ip];
+  const uint2 cand_raw = sb.ext[(fbase + ip) * kHypSlots + k];
+  const uint2 mine_raw = sb.ent[(fbase + ic) * kHypSlots + k];
+  const uint32_t lim = in_range ? lim_raw : 0x80000000u;
   const bool seg_start = (lim >> 31) != 0;  // exact entry state: nothing to extend
-  const int n_cur = in_range ? cnt_in[fbase + i] : 0;
-  const int n_prev = (in_range && !seg_start) ? cnt_in[fbase + i - 1] : 0;
+  const int n_cur = in_range ? nc_raw : 0;
+  const int n_prev = (in_range && !seg_start) ? np_raw : 0;
   // lane k holds candidate k (exit state cached in slot k of subsequence i-1) and entry k of
   // subsequence i; the 16 lanes of the group compare through shuffles
-  uint2 cand = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), mine = make_uint2(0xFFFFFFFEu, 0xFFFFFFFEu);
-  if (k < n_prev) cand = sb.ext[(fbase + i - 1) * kHypSlots + k];
-  if (k < n_cur) mine = sb.ent[(fbase + i) * kHypSlots + k];
+  const uint2 cand = k < n_prev ? cand_raw : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  const uint2 mine = k < n_cur ? mine_raw : make_uint2(0xFFFFFFFEu, 0xFFFFFFFEu);
   bool fresh = k < n_prev;
   const int gbase = (tid & 63) & ~(kHypSlots - 1);
 #pragma unroll
@@ -819,17 +825,25 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
   const uint32_t q = (uint32_t)tid % kWriteParts;
   if (i >= fr.nsub) return;
   const size_t fbase = (size_t)frame * kSyncMaxSub;
-  const size_t cpo = ((fbase + i) * kHypSlots + sb.tslot[fbase + i]) * (kWriteParts - 1);
-  const uint2 e = q == 0 ? sb.start[fbase + i] : sb.cp[cpo + q - 1];
-  const int mcu_first = sb.mcu0[fbase + i] + (q == 0 ? 0 : sb.cpn[cpo + q - 1]);
+  // (the independent loads first, all in flight together; then the two that need the true slot / the segment)
+  const uint32_t tslot = sb.tslot[fbase + i];
+  const uint2 e0 = sb.start[fbase + i];
+  const int mcu0 = sb.mcu0[fbase + i];
+  const uint32_t lim_raw = sb.lim[fbase + i];
+  const uint32_t segi = sb.seg[fbase + i];
+  const size_t cpo = ((fbase + i) * kHypSlots + tslot) * (kWriteParts - 1) + (q > 0 ? q - 1 : 0);
+  const uint2 ecp = sb.cp[cpo];  // (q = 0 reads checkpoint 0 and drops it: an unconditional load)
+  const int ncp = sb.cpn[cpo];
+  const HuffInterval& sg = ivs[sc.seg_base + segi];
+  const int mcu_end = (int)(sg.mcu0 + sg.nmcu);  // (a segment never writes into the next one's MCUs)
+  const uint2 e = q == 0 ? e0 : ecp;
+  const int mcu_first = mcu0 + (q == 0 ? 0 : ncp);
   SyncState st;
   st.p = e.x, st.cz = e.y;
   bool bad = false;
   const uint32_t part_bits = fr.sub_bits / kWriteParts;
-  uint32_t limit = sb.lim[fbase + i] & 0x7FFFFFFFu;
+  uint32_t limit = lim_raw & 0x7FFFFFFFu;
   if (q + 1 < kWriteParts) limit = min(limit, i * fr.sub_bits + (q + 1) * part_bits);
-  const HuffInterval& sg = ivs[sc.seg_base + sb.seg[fbase + i]];
-  const int mcu_end = (int)(sg.mcu0 + sg.nmcu);  // (a segment never writes into the next one's MCUs)
   int16_t* fdc = sb.dc + (size_t)frame * sb.dc_stride;
   if (staged)
     write_span(staged, st, limit, T, (int)sc.blocks_per_mcu, coef + (size_t)frame * coef_stride, fdc, mcu_first, mcu_end, &bad);
