@@ -630,8 +630,39 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
       acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.w, acc[0][3], 0, 0, 0);
     }
   };
-  DwWindow<S> winA[NS], winB[NS];
   float wA[CH], wB[CH];
+  if (S == 2) {
+    // Stride 2: a window is 3 rows x 8 floats, two sets of NS of them are 96 registers -- 160 + 64 per wave, two waves per
+    // SIMD.  ONE set: the windows of chunk c+3 are requested right behind the publication of chunk c+2 and land during the
+    // MFMA phase of chunk c and the barrier (a shorter run-ahead than the two-set schedule's whole iteration).
+    DwWindow<S> win[NS];
+    load_windows(0, win);
+    load_weights(0, wA);
+    fill_dw_variants(s_dw, a.w2, a.cin);
+    __syncthreads();
+    publish(0, win);
+    load_windows(1, win);
+    publish(1, win);
+    load_windows(2, win);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < nchunks; c += 2) {
+      load_weights(c + 1, wB);
+      publish(c + 2, win);
+      load_windows(c + 3, win);
+      multiply(c, wA);
+      __syncthreads();
+      if (c + 1 >= nchunks) break;
+      load_weights(c + 2, wA);
+      publish(c + 3, win);
+      load_windows(c + 4, win);
+      multiply(c + 1, wB);
+      __syncthreads();
+    }
+    if (live) store_tiles<1>(a, acc, ct, half, frame, oy * a.ow + ox, ohw);
+    return;
+  }
+  DwWindow<S> winA[NS], winB[NS];
   // prologue: chunks 0 and 1 published, windows of chunk 2 and weights of chunk 0 in flight
   load_windows(0, winA);
   load_windows(1, winB);
