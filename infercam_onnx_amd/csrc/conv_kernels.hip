@@ -598,11 +598,10 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   const int nchunks = ksteps / CH;
   float4* my_t = s_t + (size_t)pt * 3 * CH * 64;  // this pixel tile's three chunk buffers
   const float* __restrict__ wsrc = a.w + (size_t)ct * ksteps * 64 + lane;  // A operand of step ks: wsrc[ks * 64]
-  // Schedule of iteration c (one barrier each): issue the loads of the windows of chunk c+3 and of
-  // the weights of chunk c+1 (a whole iteration before their use), compute this wave's depthwise
-  // steps of chunk c+2 into LDS buffer (c+2)%3, then multiply chunk c out of buffer c%3 -- which
-  // every wave finished writing two iterations ago, so the MFMA phase never waits for a
-  // neighbour's depthwise phase of the same iteration.
+  // Schedule of iteration c (one barrier each): issue the loads of the weights of chunk c+1 (a whole iteration before their
+  // use), compute this wave's depthwise steps of chunk c+2 into LDS buffer (c+2)%3, request the windows of chunk c+3, then
+  // multiply chunk c out of buffer c%3 -- which every wave finished writing two iterations ago, so the MFMA phase never
+  // waits for a neighbour's depthwise phase of the same iteration.
   auto load_windows = [&](int chunk, DwWindow<S> (&w)[NS]) {
     const int cc = min(chunk, nchunks - 1);  // past the end: harmless re-read
 #pragma unroll
@@ -630,62 +629,34 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
       acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kk], b.w, acc[0][3], 0, 0, 0);
     }
   };
+  // ONE set of input windows in flight (round 3; two sets before): the windows of chunk c+3 are requested right behind the
+  // publication of chunk c+2 and land during the MFMA phase of chunk c and the barrier.  A whole iteration more of run-ahead
+  // cost 48 (stride 1) / 96 (stride 2: 3 rows x 8 floats per window) registers and bought nothing: k_dwpw_coop<1, 4> 29.7 ->
+  // 29.0 us, the stride-2 dual launches 41.7 -> 37.5 us alone at three waves per SIMD instead of two.
   float wA[CH], wB[CH];
-  if (S == 2) {
-    // Stride 2: a window is 3 rows x 8 floats, two sets of NS of them are 96 registers -- 160 + 64 per wave, two waves per
-    // SIMD.  ONE set: the windows of chunk c+3 are requested right behind the publication of chunk c+2 and land during the
-    // MFMA phase of chunk c and the barrier (a shorter run-ahead than the two-set schedule's whole iteration).
-    DwWindow<S> win[NS];
-    load_windows(0, win);
-    load_weights(0, wA);
-    fill_dw_variants(s_dw, a.w2, a.cin);
-    __syncthreads();
-    publish(0, win);
-    load_windows(1, win);
-    publish(1, win);
-    load_windows(2, win);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nchunks; c += 2) {
-      load_weights(c + 1, wB);
-      publish(c + 2, win);
-      load_windows(c + 3, win);
-      multiply(c, wA);
-      __syncthreads();
-      if (c + 1 >= nchunks) break;
-      load_weights(c + 2, wA);
-      publish(c + 3, win);
-      load_windows(c + 4, win);
-      multiply(c + 1, wB);
-      __syncthreads();
-    }
-    if (live) store_tiles<1>(a, acc, ct, half, frame, oy * a.ow + ox, ohw);
-    return;
-  }
-  DwWindow<S> winA[NS], winB[NS];
-  // prologue: chunks 0 and 1 published, windows of chunk 2 and weights of chunk 0 in flight
-  load_windows(0, winA);
-  load_windows(1, winB);
+  DwWindow<S> win[NS];
+  load_windows(0, win);
   load_weights(0, wA);
   fill_dw_variants(s_dw, a.w2, a.cin);  // (the first windows are in flight while the table goes to LDS)
   __syncthreads();
-  publish(0, winA);
-  load_windows(2, winA);
-  publish(1, winB);
+  publish(0, win);
+  load_windows(1, win);
+  publish(1, win);
+  load_windows(2, win);
   __syncthreads();
 #pragma unroll 1
   for (int c = 0; c < nchunks; c += 2) {
-    // even iteration: windows of chunk c+2 are in winA, weights of chunk c in wA
-    load_windows(c + 3, winB);
+    // even iteration: weights of chunk c in wA
     load_weights(c + 1, wB);
-    publish(c + 2, winA);
+    publish(c + 2, win);
+    load_windows(c + 3, win);
     multiply(c, wA);
     __syncthreads();
     if (c + 1 >= nchunks) break;
-    // odd iteration: windows of chunk c+3 are in winB, weights of chunk c+1 in wB
-    load_windows(c + 4, winA);
+    // odd iteration: weights of chunk c+1 in wB
     load_weights(c + 2, wA);
-    publish(c + 3, winB);
+    publish(c + 3, win);
+    load_windows(c + 4, win);
     multiply(c + 1, wB);
     __syncthreads();
   }
