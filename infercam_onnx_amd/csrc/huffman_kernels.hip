@@ -412,9 +412,18 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
         } else if (q < nseg && s_beg[q] <= off && off + 16 <= s_end[q]) {
           // the whole piece lies inside one segment: running output pointer
           uint8_t* o = dst + seg[q].first_sub * sub_bytes + (off - s_beg[q]) - (myz - s_zb[q]);
+          if (zmask == 0) {
+            // no stuffed byte in the piece (15 pieces of 16): ONE 16-byte store to the -- arbitrarily aligned -- output
+            // position (gfx950 executes unaligned global stores: tools/ubench/unaligned_store.hip) instead of 16 byte stores
+            struct __attribute__((packed, aligned(1))) Piece { uint4 v; };
+            Piece pc;
+            pc.v = v;
+            *reinterpret_cast<Piece*>(o) = pc;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 16; j++)
-            if (!(zmask & (1u << j))) *o++ = (uint8_t)((w4[j >> 2] >> (8 * (j & 3))) & 0xFF);
+            for (int j = 0; j < 16; j++)
+              if (!(zmask & (1u << j))) *o++ = (uint8_t)((w4[j >> 2] >> (8 * (j & 3))) & 0xFF);
+          }
         } else {
 #pragma unroll 1
           for (int j = 0; j < 16; j++) {  // a piece with a segment boundary (or the edge of the range) in it
