@@ -259,3 +259,25 @@ def test_bench_script_single_and_two_rank_rehearsal():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line["config"]
     assert len(line["config"]["ranks"]) == 2 and line["config"]["global_batch"] == 64
     assert "cpu_baseline" not in line  # N = 1 only
+
+
+def test_rccl_backend_collectives_coexist_with_the_library():
+    """The leg of the N > 1 path the two-rank rehearsal above cannot reach (it exchanges over gloo): torch.distributed's
+    "nccl" backend -- torch's bundled RCCL on torch's bundled HIP runtime -- with device tensors, in ONE process with
+    libufacehip.so (linked against the system ROCm runtime).  tools/nccl_coexist_probe.py runs bench.py's sequence at world
+    size 1 on the box's GPU: init_process_group("nccl", device_id=...), the weight broadcast, a handle created and a
+    batch run, then barrier / all_reduce(MAX) / all_gather.  (The reverse mix does not work -- the system librccl
+    dlopen'ed into a process that has torch's runtime loaded fails in ncclCommInitAll -- which is why
+    ufd_create_replicas is tested from a C++ host: test_gpu_mirrors.py.)  More than one GPU stays the driver's run."""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_coexist_probe.py")], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "nccl coexist ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
