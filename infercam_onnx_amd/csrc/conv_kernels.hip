@@ -56,10 +56,6 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
 }
 __device__ __forceinline__ float relu_acc(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
-__device__ __forceinline__ float4 relu4(float4 v) {
-  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-}
-
 // ------------------------------------------------------------------------------------------------
 // Shared tail of the 32x32x2 kernels.  D layout: reg r, lane l -> cout (r&3) + 8*(r>>2) + 4*(l>>5),
 // pixel column l&31; MFMA j of a k-step used component j of the lane's float4, so register r of

@@ -415,9 +415,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_huff_unstuff(const uint8_t* __
           if (zmask == 0) {
             // no stuffed byte in the piece (15 pieces of 16): ONE 16-byte store to the -- arbitrarily aligned -- output
             // position (gfx950 executes unaligned global stores: tools/ubench/unaligned_store.hip) instead of 16 byte stores
-            struct __attribute__((packed, aligned(1))) Piece { uint4 v; };
-            Piece pc;
-            pc.v = v;
+            struct __attribute__((packed, aligned(1))) Piece { uint32_t w[4]; };
+            const Piece pc = {{v.x, v.y, v.z, v.w}};
             *reinterpret_cast<Piece*>(o) = pc;
           } else {
 #pragma unroll

@@ -5,12 +5,12 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-struct __attribute__((packed, aligned(1))) U16 { uint4 v; };
+struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
 __global__ void k(unsigned char* dst, const uint4* src, int sh, int n) {
   const int t = threadIdx.x + blockIdx.x * blockDim.x;
   if (t >= n) return;
-  U16 u;
-  u.v = src[t];
+  const uint4 v = src[t];
+  const U16 u = {{v.x, v.y, v.z, v.w}};
   *reinterpret_cast<U16*>(dst + (size_t)t * 16 + sh) = u;
 }
 int main() {
