@@ -51,6 +51,28 @@ def synthetic_weights(seed=DEFAULT_WEIGHT_SEED, cls_bias_shift=CLS_BIAS_SHIFT):
     return blob
 
 
+def bn_folded_like_weights(seed=7, spread=4.0, bias_sigma=0.5):
+    """Weights with the dynamic range of a BatchNorm-folded checkpoint (w' = w * gamma / sigma per output channel,
+    b' = beta - mu * gamma / sigma) instead of the uniform He-normal scale of `synthetic_weights`: every output channel
+    gets its own factor, log-uniform over a ratio of spread^2 and normalised to unit mean square per layer (activations
+    neither explode nor die over the 13 blocks), and biases are N(0, bias_sigma^2) -- tens of times the He blob's.  The real zoo file is not
+    available offline (nn.rs:21-22 downloads it); this is the closest the parity tests can get to its value ranges."""
+    blob = np.empty(T.total_weight_floats(), np.float32)
+    for i, (s, (wo, bo)) in enumerate(zip(T.CONVS, T.weight_offsets())):
+        rng = np.random.default_rng([int(seed), i])
+        fan_in = (s.cin // s.groups) * s.k * s.k
+        n = T.weight_count(s)
+        w = (rng.standard_normal(n) * np.sqrt(2.0 / fan_in)).reshape(s.cout, -1)
+        scale = np.exp(rng.uniform(-np.log(spread), np.log(spread), s.cout))
+        scale /= np.sqrt(np.mean(scale * scale))  # (the layer keeps the He blob's mean output power: nothing explodes)
+        is_head = i in T.CLS_LAYERS or i in T.REG_LAYERS
+        if is_head:
+            scale[:] = 1.0  # (the heads feed softmax / exp: keep their logits in a trained model's range)
+        blob[wo:wo + n] = (w * scale[:, None]).astype(np.float32).ravel()
+        blob[bo:bo + s.cout] = (rng.standard_normal(s.cout) * (0.05 if is_head else bias_sigma)).astype(np.float32)
+    return blob
+
+
 def layer_params(blob, i):
     """(w [cout, cin/g, k, k], b [cout]) views into a packed blob."""
     s = T.CONVS[i]

@@ -182,6 +182,45 @@ def test_production_plan_tensors_at_batch32(pool_c3, oracle_lib, weights):
         m.close()
 
 
+@pytest.mark.parametrize("variant,batch", [(640, 32), (320, 5)])
+def test_bn_folded_like_weight_ranges_through_the_product_plan(pool_c3, oracle_lib, variant, batch):
+    """All other CNN parity runs on He-normal weights with one scale per layer.  A BatchNorm-folded checkpoint -- what the
+    reference's zoo file is (nn.rs:21-22, not available offline) -- has a scale of its own per OUTPUT CHANNEL and biases
+    tens of times larger: `synth.bn_folded_like_weights` (per-channel factors log-uniform in [1/4, 4], biases N(0, 0.5^2)).
+    Every tensor of the product plan against the oracle, <= 1e-5 of the tensor's largest value, scores <= 1e-5, boxes
+    <= 1e-5 relative -- at the bench's batch size (non-split-K instances) and at a small batch (split-K instances)."""
+    from infercam_onnx_amd import nn, synth
+
+    W, H = (640, 480) if variant == 640 else (320, 240)
+    weights = synth.bn_folded_like_weights()
+    pri = synth.gen_priors(W, H)
+    jpegs = pool_c3[:batch] if variant == 640 else synth.synth_jpeg_pool(3, batch, W, H, quality=90, subsampling="4:2:0")
+    x = np.stack(oracle_many(lambda j: oracle_lib.normalize_nchw(oracle_lib.jpeg_decode_rgb(j)), jpegs))
+    m = _model(variant, weights, max_batch=batch, max_src=(W, H), tap_layers=True)
+    try:
+        scores, boxes = m.debug_forward(x)
+        checked = 0
+        for f in range(0, batch, max(1, batch // 4)):  # (the oracle's forward is ~1 s per 640 frame)
+            rs, rb, outs = oracle_lib.forward(x[f], weights, pri, layers=True)
+            for li, ref in enumerate(outs):
+                try:
+                    got = m.debug_layer_output(li, f).reshape(ref.shape)
+                except nn.UfdError as e:
+                    assert e.code == nn.UFD_E_STATE  # (a tensor that does not exist in the fused plan)
+                    continue
+                scale = max(np.abs(ref).max(), 1e-6)
+                assert np.isfinite(ref).all() and np.abs(got - ref).max() / scale <= 1e-5, (li, f, np.abs(got - ref).max() / scale)
+                checked += 1
+            assert np.abs(scores[f] - rs).max() <= 1e-5
+            assert (np.abs(boxes[f] - rb) <= 1e-5 * np.maximum(1.0, np.abs(rb))).all()
+        assert checked >= 4 * 30, checked
+        w10, b10 = synth.layer_params(weights, 10)  # the generator's point: one backbone layer's channels differ by > 8x
+        norms = np.sqrt((w10.reshape(w10.shape[0], -1) ** 2).sum(1))
+        assert norms.max() / norms.min() > 8.0 and np.abs(b10).max() > 0.5, (norms.max() / norms.min(), np.abs(b10).max())
+    finally:
+        m.close()
+
+
 # ---------------------------------------------------------------- C1: the reference's own pictures
 def _pics():
     meta = json.load(open(os.path.join(G, "test_pics.json")))
