@@ -45,11 +45,16 @@ def test_forward_matches_torch_golden(oracle_lib, weights):
         assert abs(o.mean() - z["layer_mean"][i]) <= 1e-4 * max(1.0, abs(z["layer_mean"][i])), i
 
 
-def test_forward_per_layer_against_live_torch(oracle_lib, weights):
+@pytest.mark.parametrize("blob", ["he_normal", "bn_folded_like"])
+def test_forward_per_layer_against_live_torch(oracle_lib, weights, blob):
+    """(bn_folded_like: a scale of its own per output channel over a ratio of 16 and large biases -- the value ranges of a
+    BatchNorm-folded checkpoint such as the reference's zoo file, which cannot be had offline: synth.bn_folded_like_weights)"""
     import torch
     import torch.nn.functional as F
     from infercam_onnx_amd import synth, topology as T
 
+    if blob == "bn_folded_like":
+        weights = synth.bn_folded_like_weights()
     torch.set_num_threads(4)
     W, H = 320, 240
     x = oracle_lib.normalize_nchw(synth.synth_frame(5, 5, W, H))
