@@ -1244,42 +1244,52 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
     return o == 0 ? v : __shfl(v, lane + o);
   };
 
-  Rows cur, nxt;
-  load_rows(0, cur);
-  for (int kc = 0; kc < cin4; kc++) {
-    load_rows(min(kc + 1, cin4 - 1), nxt);
+  // The channel loop, once per source of the weights (wave-uniform: a run-time choice between an LDS and a global pointer
+  // inside the loop made every weight read a FLAT load).  A tap row outside the image zeroes the lane's ROW SEGMENT once
+  // (4 selects; the neighbours' halo values come out of their own zeroed segments -- same output row, same tap row --
+  // or are masked by the column tests) instead of each of the 12 operands made from it, and the column tests are compiled
+  // in only where they can fail: left of pixel j < DIL, right of pixel j > 3 - DIL.  54 selects per chunk became 18.
+  auto zero_if = [](bool keep, const float4& m) { return keep ? m : make_float4(0.f, 0.f, 0.f, 0.f); };
+  auto run = [&](auto in_lds) {
+    Rows cur, nxt;
+    load_rows(0, cur);
+    for (int kc = 0; kc < cin4; kc++) {
+      load_rows(min(kc + 1, cin4 - 1), nxt);
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const bool ok = rowok[r];
-      float x[3][4];  // [kx][pixel]
-      if (S == 1) {
-        const float4 m = cur.m0[r];
+      for (int r = 0; r < 3; r++) {
+        const bool ok = rowok[r];
+        float x[3][4];  // [kx][pixel]
+        if (S == 1) {
+          const float4 m = zero_if(ok, cur.m0[r]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          // shuffles first, unconditionally: a cross-lane read inside a divergent branch would
-          // see inactive source lanes
-          const float vl = col(m, j - dil), vc = DIL == 0 ? (j == 0 ? m.x : (j == 1 ? m.y : (j == 2 ? m.z : m.w))) : col(m, j), vr = col(m, j + dil);
-          x[0][j] = (ok && lok[j]) ? vl : 0.0f;
-          x[1][j] = ok ? vc : 0.0f;
-          x[2][j] = (ok && rok[j]) ? vr : 0.0f;
+          for (int j = 0; j < 4; j++) {
+            // shuffles first, unconditionally: a cross-lane read inside a divergent branch would
+            // see inactive source lanes
+            const float vl = col(m, j - dil), vc = DIL == 0 ? (j == 0 ? m.x : (j == 1 ? m.y : (j == 2 ? m.z : m.w))) : col(m, j), vr = col(m, j + dil);
+            x[0][j] = (DIL != 0 && j >= DIL) ? vl : (lok[j] ? vl : 0.0f);
+            x[1][j] = vc;
+            x[2][j] = (DIL != 0 && j + DIL <= 3) ? vr : (rok[j] ? vr : 0.0f);
+          }
+        } else {
+          const float4 m0 = zero_if(ok, cur.m0[r]), m1 = zero_if(ok, cur.m1[r]);
+          const float left = __shfl(m1.w, lane - 1);
+          x[0][0] = lok[0] ? left : 0.0f, x[0][1] = m0.y, x[0][2] = m0.w, x[0][3] = m1.y;
+          x[1][0] = m0.x, x[1][1] = m0.z, x[1][2] = m1.x, x[1][3] = m1.z;
+          x[2][0] = m0.y, x[2][1] = m0.w, x[2][2] = m1.y, x[2][3] = m1.w;
         }
-      } else {
-        const float4 m0 = cur.m0[r], m1 = cur.m1[r];
-        const float left = __shfl(m1.w, lane - 1);
-        x[0][0] = (ok && lok[0]) ? left : 0.0f, x[0][1] = ok ? m0.y : 0.0f, x[0][2] = ok ? m0.w : 0.0f, x[0][3] = ok ? m1.y : 0.0f;
-        x[1][0] = ok ? m0.x : 0.0f, x[1][1] = ok ? m0.z : 0.0f, x[1][2] = ok ? m1.x : 0.0f, x[1][3] = ok ? m1.z : 0.0f;
-        x[2][0] = ok ? m0.y : 0.0f, x[2][1] = ok ? m0.w : 0.0f, x[2][2] = ok ? m1.y : 0.0f, x[2][3] = ok ? m1.w : 0.0f;
-      }
 #pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        const int widx = (kc * 9 + r * 3 + kx) * 64;
-        const float w = w_in_lds ? s_w[widx + lane] : wg[widx];
+        for (int kx = 0; kx < 3; kx++) {
+          const int widx = (kc * 9 + r * 3 + kx) * 64;
+          const float w = decltype(in_lds)::value ? s_w[widx + lane] : wg[widx];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
+          for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
+        }
       }
+      cur = nxt;
     }
-    cur = nxt;
-  }
+  };
+  if (w_in_lds) run(std::true_type{});
+  else run(std::false_type{});
   if (!live) return;
   const int pix = oy * a.ow + ox;
   // byte offset of the lane's first channel from the tensor base, a channel step per store; ReLU as the integer maximum
