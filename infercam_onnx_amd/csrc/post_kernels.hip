@@ -113,7 +113,12 @@ __device__ __forceinline__ float bbox_area(float x0, float y0, float x1, float y
 // workgroup barrier -- only the wave's own LDS accesses in order -- unless the stage before it crossed chunks.  A 2048-key
 // sort has 10 barrier stages instead of 66, the 1024-key blocks of a 4096-key frame 5 (a barrier of 16 waves costs
 // ~0.5-1 us: the sort was most of the kernel).
-__device__ void bitonic_desc(unsigned long long* keys, int n2, int top, int tid, int nthreads, bool in_lds) {
+// (KeyPtr: the keys' address space is part of the type -- LDS or global.  Through a generic pointer every key access was a
+// FLAT instruction, which reaches LDS the long way round: the sort's inner loop is two loads and two stores.)
+typedef __attribute__((address_space(3))) unsigned long long* LdsKeys;
+typedef __attribute__((address_space(1))) unsigned long long* GlobalKeys;
+template <typename KeyPtr>
+__device__ void bitonic_desc_in(KeyPtr keys, int n2, int top, int tid, int nthreads, bool in_lds) {
   const int pairs = n2 >> 1, lane = tid & 63, wave = tid >> 6;
   const int iters = max(1, pairs / nthreads);
   const int chunk = in_lds ? iters * 128 : 0;
@@ -139,6 +144,10 @@ __device__ void bitonic_desc(unsigned long long* keys, int n2, int top, int tid,
     }
   }
   __syncthreads();
+}
+__device__ void bitonic_desc(unsigned long long* keys, int n2, int top, int tid, int nthreads, bool in_lds) {
+  if (in_lds) bitonic_desc_in((LdsKeys)keys, n2, top, tid, nthreads, true);
+  else bitonic_desc_in((GlobalKeys)keys, n2, top, tid, nthreads, false);
 }
 
 // iou(candidate, selected) > max_iou, nn.rs:227-243 operation order
@@ -214,14 +223,15 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
       // binary search -- 30 LDS reads per key instead of 23 more sort stages with 11 barriers.  Padding keys (0) sort
       // last in their block and precede nothing.
       constexpr int CB = kSortLds / 2;  // 1024
+      const LdsKeys lkeys = (LdsKeys)s_keys;  // (a heavy frame's keys are in LDS: the test above)
       for (int e = tid; e < n2; e += nthr) {
-        const unsigned long long key = keys[e];
+        const unsigned long long key = lkeys[e];
         if (!key) continue;
         const int c = e / CB;
         int rank = e - c * CB;
         for (int o = 0; o < n2 / CB; o++) {
           if (o == c) continue;
-          const unsigned long long* blk = keys + o * CB;
+          const LdsKeys blk = lkeys + o * CB;
           int lo = 0, hi = CB;  // first position whose key is smaller = number of keys greater
           while (lo < hi) {
             const int mid = (lo + hi) >> 1;
