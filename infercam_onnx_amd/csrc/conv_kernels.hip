@@ -40,6 +40,12 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lane_prev(float x) {  // value of lane - 1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
 }
+// Shift inside the 16-lane DPP rows (CTRL: 0x110 + n = row_shr:n, the value of lane - n; 0x100 + n = row_shl:n, lane + n);
+// lanes whose source lies outside their row get 0.
+template <int CTRL>
+__device__ __forceinline__ float row_shift(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float lane_next(float x) {  // value of lane + 1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
@@ -1241,7 +1247,17 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
     const int o = (c >= 0) ? (c >> 2) : -((3 - c) >> 2);  // lane offset, floor(c / 4)
     const int k = c - 4 * o;
     const float v = k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w));
-    return o == 0 ? v : __shfl(v, lane + o);
+    // a quad's 16 lanes are one DPP row: the neighbour's value is a row shift on the vector ALU (one instruction; __shfl is
+    // a ds_bpermute -- an LDS-pipe round trip the MFMAs behind it wait for).  Lanes past the row's ends get 0: they are halo
+    // providers, their own outputs are not stored.
+    switch (o) {
+      case 0: return v;
+      case -1: return row_shift<0x111>(v);  // row_shr:1 = the value of lane - 1
+      case -2: return row_shift<0x112>(v);
+      case 1: return row_shift<0x101>(v);   // row_shl:1 = the value of lane + 1
+      case 2: return row_shift<0x102>(v);
+      default: return __shfl(v, lane + o);
+    }
   };
 
   // The channel loop, once per source of the weights (wave-uniform: a run-time choice between an LDS and a global pointer
@@ -1272,7 +1288,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
           }
         } else {
           const float4 m0 = zero_if(ok, cur.m0[r]), m1 = zero_if(ok, cur.m1[r]);
-          const float left = __shfl(m1.w, lane - 1);
+          const float left = row_shift<0x111>(m1.w);
           x[0][0] = lok[0] ? left : 0.0f, x[0][1] = m0.y, x[0][2] = m0.w, x[0][3] = m1.y;
           x[1][0] = m0.x, x[1][1] = m0.z, x[1][2] = m1.x, x[1][3] = m1.z;
           x[2][0] = m0.y, x[2][1] = m0.w, x[2][2] = m1.y, x[2][3] = m1.w;
