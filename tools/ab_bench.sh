@@ -5,7 +5,7 @@
 set -u
 rounds=${1:-3}; shift || true
 lib=infercam_onnx_amd/libufacehip.so
-cp $lib ab/_orig.so
+mkdir -p ab && cp $lib ab/_orig.so  # (ab/base.so and ab/alt.so: the two builds, copied there by hand)
 mkdir -p gpurun_out/ab
 : > gpurun_out/ab/log.txt
 for r in $(seq 1 $rounds); do
