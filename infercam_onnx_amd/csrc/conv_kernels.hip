@@ -1406,7 +1406,8 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   constexpr int HL = 1, NG = 16 - 2 * HL;
   extern __shared__ float s_sh[];
   float* s_w = s_sh;                 // packed weights [1][9][64]
-  float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table, then 256 zeros (the "table" of a padding row / the pad quad)
+  float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table, then 256 zeros (the "table" of a padding row)
+  float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][16 groups][8 columns] of one input row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
@@ -1424,66 +1425,82 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j16 >= HL && j16 < 16 - HL;
   const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpb : 0u;
-  const size_t frame = frame32;
   const int rem = inrange ? g - (int)frame32 * gpb : 0;
   const int band = rem / gpr, ox = (rem - band * gpr) * 4, oy0 = band * R;
-  const JpegFrameDesc& d = sa.descs[frame];
-  const bool frame_ok = d.width == a.iw && d.height == a.ih;  // failed frames: zero input
-  const uint8_t* fp = sa.planes + frame * sa.plane_stride;
-  const int ypitch = d.wblk[0] * 8, cpitch = d.wblk[1] * 8;
-  const int dw = d.dw[1], dh = d.dh[1];
-  const int ix0 = ox * 2;       // first input column of the lane (multiple of 8)
-  const int c0 = ix0 >> 1;      // first chroma column (multiple of 4)
-  // per-channel colour coefficients: out = y + ((ku * (cb - 128) + kv * (cr - 128) + 32768) >> 16)
-  // as ku * cb + kv * cr + kc on the 24-bit multiplier (v_mad_i32_i24, full rate; the 32-bit v_mul_lo_u32 the compiler picks
-  // for the plain expression is a quarter-rate instruction): the same integer, |ku|, |kv| < 2^17 and cb, cr < 2^8
-  const int ku = q == 1 ? -22554 : (q == 2 ? 116130 : 0);
-  const int kv = q == 0 ? 91881 : (q == 1 ? -46802 : 0);
-  const int kc = 32768 - 128 * (ku + kv);
-  const float* lutq = s_lut + min(q, 2) * 256;
-  const float* lut_zero = s_lut + 768;
-  // every lane upsamples ONE chroma plane for its 8 pixels (R: Cr, G and B: Cb); the G lanes
-  // fetch Cr from the R lane of the same pixels (16 lanes down)
-  const int plane = q == 0 || q == 3 ? 2 : 1;
-  const uint8_t* yplane = fp + d.plane_off[0] + ix0;
-  const uint8_t* cplane = fp + d.plane_off[plane] + c0;
+  const int ix0 = ox * 2;       // first input column of the lane's group (multiple of 8)
+  // ---- Conversion, pixel-parallel (round 3; before, every MFMA lane converted the 8 pixels of ITS channel: the chroma
+  // upsampling of a pixel was done three times over and the pad quad converted for nothing).  The wave's 16 groups x 8
+  // input columns are 64 pixel pairs: lane L converts pair cp = L & 3 of group cg = L >> 2 -- two luma samples, ONE chroma
+  // column of both planes, R, G and B of both pixels -- and leaves the six normalised values in the wave's exchange buffer
+  // xb[channel][group][8]; every MFMA lane then reads the 8 values of its (channel, group) and the column to their left
+  // back (two 16-byte LDS reads + one; channel 3 of the buffer stays zero for the pad quad).  Same integer formulas as
+  // jpeg_kernels.hip, hence bit-identical; ~66 vector instructions per lane and input row instead of ~105.
+  // The conversion lane takes its group's coordinates from the MFMA lane that owns the group (lanes 0..15: quad 0).
+  const int cg = lane >> 2, cp = lane & 3;
+  const bool c_inrange = __shfl((int)inrange, cg) != 0;
+  const uint32_t c_frame = (uint32_t)__shfl((int)frame32, cg);
+  const int c_oy0 = __shfl(oy0, cg);
+  const int c_ix = __shfl(ix0, cg) + 2 * cp;  // the lane's two input columns: c_ix, c_ix + 1
+  const int cc = c_ix >> 1;                    // ... and its chroma column
+  const JpegFrameDesc& dcv = sa.descs[c_frame];
+  const bool c_frame_ok = c_inrange && dcv.width == a.iw && dcv.height == a.ih;  // failed frames: zero input
+  const uint8_t* cfp = sa.planes + (size_t)c_frame * sa.plane_stride;
+  const int c_ypitch = dcv.wblk[0] * 8, c_cpitch = dcv.wblk[1] * 8, c_dw = dcv.dw[1], c_dh = dcv.dh[1];
+  const uint8_t* c_y = cfp + dcv.plane_off[0] + c_ix;
+  const uint8_t* c_cb = cfp + dcv.plane_off[1] + cc;
+  const uint8_t* c_cr = cfp + dcv.plane_off[2] + cc;
+  // neighbour chroma columns come from the adjacent lanes; at the image's edges jdsample.c repeats the column itself.
+  // (Lane 0's left and lane 63's right neighbour lie outside the wave: they only enter pixels of the two halo groups
+  // that nobody reads -- group 0 provides its LAST column, group 15 nothing.)
+  const bool has_prev = cc > 0, has_next = cc + 1 <= c_dw - 1;
+  float* xb = s_x + wave * 512;                        // [4][16][8]
+  const float* xr = xb + q * 128 + j16 * 8;            // what this MFMA lane reads back
+  const int xl = max(q * 128 + j16 * 8 - 1, 0);        // the column left of them (group j16 - 1's last)
+  const bool left_ok = j16 > 0 && ix0 > 0;             // else: zero padding at the row start (or a halo lane)
+  *reinterpret_cast<float2*>(xb + 384 + 2 * lane) = make_float2(0.f, 0.f);  // channel 3: zeros, written once
+  auto dpp_prev = [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); };
+  auto dpp_next = [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); };
+  // out = y + ((ku * (cb - 128) + kv * (cr - 128) + 32768) >> 16) as ku * cb + kv * cr + kc on the 24-bit multiplier
+  // (v_mad_i32_i24, full rate): the same integer, |ku|, |kv| < 2^17 and cb, cr < 2^8
+  constexpr int kRv = 91881, kGu = -22554, kGv = -46802, kBu = 116130;
+  constexpr int kRc = 32768 - 128 * kRv, kGc = 32768 - 128 * (kGu + kGv), kBc = 32768 - 128 * kBu;
 
-  // input row iy of the lane's channel: v[0..7] = columns ix0 .. ix0+7, v[8] = column ix0 - 1 (0 at the row start);
-  // a row outside the image is zero padding
-  auto convert_row = [&](int iy, float (&v)[9]) {
-    const bool ok = frame_ok && iy >= 0 && iy < a.ih && q < 3;
+  // input row 2 * oy0 + k of the wave's groups: v[0..7] = columns ix0 .. ix0+7 of the lane's channel, v[8] = column ix0 - 1
+  // (0 at the row start); a row outside the image is zero padding
+  auto convert_row = [&](int k, float (&v)[9]) {
+    const int iy = 2 * c_oy0 + k;
+    const bool ok = c_frame_ok && iy >= 0 && iy < a.ih;
     const int yc = min(max(iy, 0), a.ih - 1);
-    // luma: 8 bytes; chroma: the row pair of h2v2 fancy upsampling, 4 columns of the lane's plane
-    const int cy = yc >> 1, ny = max(0, min(dh - 1, (yc & 1) ? cy + 1 : cy - 1));
-    uint2 yy = make_uint2(0, 0);
-    uint32_t wa = 0, wb = 0;
-    if (frame_ok) {
-      yy = *reinterpret_cast<const uint2*>(yplane + (uint32_t)__mul24(yc, ypitch));  // (rows and pitches < 2^23: full-rate multiplies)
-      wa = *reinterpret_cast<const uint32_t*>(cplane + (uint32_t)__mul24(cy, cpitch));
-      wb = *reinterpret_cast<const uint32_t*>(cplane + (uint32_t)__mul24(ny, cpitch));
+    const int cy = yc >> 1, ny = max(0, min(c_dh - 1, (yc & 1) ? cy + 1 : cy - 1));  // h2v2 fancy upsampling: near / far row
+    uint32_t yy = 0, cbn = 0, cbf = 0, crn = 0, crf = 0;
+    if (c_frame_ok) {
+      const uint32_t ro = (uint32_t)__mul24(cy, c_cpitch), fo = (uint32_t)__mul24(ny, c_cpitch);
+      yy = *reinterpret_cast<const uint16_t*>(c_y + (uint32_t)__mul24(yc, c_ypitch));
+      cbn = c_cb[ro], cbf = c_cb[fo], crn = c_cr[ro], crf = c_cr[fo];
     }
-    const float* lut_row = ok ? lutq : lut_zero;  // (a select per row instead of a branch around each of the 8 table reads)
-    int sc[6];
-#pragma unroll
-    for (int i = 0; i < 4; i++) sc[1 + i] = mad24(3, (int)((wa >> (8 * i)) & 255), (int)((wb >> (8 * i)) & 255));
-    {
-      // neighbour columns c0-1 / c0+4 from the adjacent lanes (same input row when they exist)
-      const int from_prev = __shfl(sc[4], lane - 1), from_next = __shfl(sc[1], lane + 1);
-      sc[0] = c0 > 0 ? from_prev : sc[1];
-      sc[5] = c0 + 4 <= dw - 1 ? from_next : sc[4];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = 1 + (j >> 1);
-      const int mine = (j & 1) ? (mad24(sc[i], 3, sc[i + 1]) + 7) >> 4 : (mad24(sc[i], 3, sc[i - 1]) + 8) >> 4;
-      const int peer = __shfl(mine, lane - 16);  // the R lane's Cr for the G lane
-      const int cbv = mine, crv = q == 1 ? peer : mine;
-      const int yv = (int)(((j < 4 ? yy.x : yy.y) >> (8 * (j & 3))) & 255);
-      const int px = min(255, max(0, yv + (mad24(kv, crv, mad24(ku, cbv, kc)) >> 16)));
-      v[j] = lut_row[px];
-    }
-    const float left_raw = __shfl(v[7], lane - 1);
-    v[8] = (j16 > 0 && ix0 > 0) ? left_raw : 0.0f;  // column ix0 - 1 (zero padding at the row start)
+    const int scb = mad24(3, (int)cbn, (int)cbf), scr = mad24(3, (int)crn, (int)crf);  // column sums 3 * near + far
+    const int pcb = dpp_prev(scb), ncb = dpp_next(scb), pcr = dpp_prev(scr), ncr = dpp_next(scr);
+    const int lcb = has_prev ? pcb : scb, rcb = has_next ? ncb : scb, lcr = has_prev ? pcr : scr, rcr = has_next ? ncr : scr;
+    const int cb0 = (mad24(scb, 3, lcb) + 8) >> 4, cb1 = (mad24(scb, 3, rcb) + 7) >> 4;
+    const int cr0 = (mad24(scr, 3, lcr) + 8) >> 4, cr1 = (mad24(scr, 3, rcr) + 7) >> 4;
+    const int y0 = (int)(yy & 255u), y1 = (int)(yy >> 8);
+    auto clamp255 = [](int x) { return min(255, max(0, x)); };
+    const int r0 = clamp255(y0 + (mad24(kRv, cr0, kRc) >> 16)), r1 = clamp255(y1 + (mad24(kRv, cr1, kRc) >> 16));
+    const int g0 = clamp255(y0 + (mad24(kGv, cr0, mad24(kGu, cb0, kGc)) >> 16)), g1 = clamp255(y1 + (mad24(kGv, cr1, mad24(kGu, cb1, kGc)) >> 16));
+    const int b0 = clamp255(y0 + (mad24(kBu, cb0, kBc) >> 16)), b1 = clamp255(y1 + (mad24(kBu, cb1, kBc) >> 16));
+    // (a padding row reads the table's row of zeros: two selects per row instead of a branch around the six reads)
+    const float* l0 = s_lut + (ok ? 0 : 768);
+    const int lstep = ok ? 256 : 0;
+    float* xw = xb + cg * 8 + 2 * cp;
+    *reinterpret_cast<float2*>(xw) = make_float2(l0[r0], l0[r1]);
+    *reinterpret_cast<float2*>(xw + 128) = make_float2(l0[lstep + g0], l0[lstep + g1]);
+    *reinterpret_cast<float2*>(xw + 256) = make_float2(l0[2 * lstep + b0], l0[2 * lstep + b1]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's stores before the wave's loads (in-order LDS)
+    const float4 va = *reinterpret_cast<const float4*>(xr), vb = *reinterpret_cast<const float4*>(xr + 4);
+    const float left = xb[xl];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and these loads before the next row's stores
+    v[0] = va.x, v[1] = va.y, v[2] = va.z, v[3] = va.w, v[4] = vb.x, v[5] = vb.y, v[6] = vb.z, v[7] = vb.w;
+    v[8] = left_ok ? left : 0.0f;
   };
   floatx4 acc[4];
   // tap row r of the 3x3 kernel applied to a converted input row: output pixel j reads columns 2j-1, 2j, 2j+1
@@ -1509,18 +1526,17 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const int lowest = a.relu ? 0 : (int)0x80000000;
 
   float top[9], mid[9], bot[9];
-  convert_row(2 * oy0 - 1, top);
+  convert_row(-1, top);
 #pragma unroll 1
   for (int i = 0; i < R; i++) {
-    const int oy = oy0 + i;
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[j][r] = bias[r];
     mac_row(0, top);
-    convert_row(2 * oy, mid);
+    convert_row(2 * i, mid);
     mac_row(1, mid);
-    convert_row(2 * oy + 1, bot);
+    convert_row(2 * i + 1, bot);
     mac_row(2, bot);
     if (live) {
       uint32_t o = out_off + 4u * (uint32_t)(i * a.ow);
@@ -1609,7 +1625,7 @@ void launch_stem_planes_mfma(const StemArgs& sa0, hipStream_t s) {
     if (a.oh % r == 0 && (long)a.B * (a.oh / r) * (a.ow / 4) / 14 >= 8192) band = r;
   a.band = band;
   const long groups = (long)a.B * ((a.oh / band) * a.ow / 4);
-  const size_t shmem = (9 * 64 + 768 + 256) * sizeof(float);  // weights, normalisation table, a row of zeros
+  const size_t shmem = (9 * 64 + 768 + 256 + 4 * 512) * sizeof(float);  // weights, normalisation table, a row of zeros, exchange buffers
   hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
 
