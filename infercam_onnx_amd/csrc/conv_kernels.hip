@@ -1394,13 +1394,13 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Stem conv (3 -> 16, 3x3, stride 2) reading the decoder's 4:2:0 sample planes directly: the
 // fancy h2v2 chroma upsampling, the fixed-point YCbCr -> RGB conversion and the (v/255 - mean)/std
-// table of k_upsample_norm_420 run per lane on the 3 x 8 input pixels it needs, so the normalised
-// f32 input tensor (3.7 MB per frame, written by one kernel and read by the next) never exists.
+// table of k_upsample_norm_420 run inside the kernel, so the normalised f32 input tensor (3.7 MB per
+// frame, written by one kernel and read by the next) never exists.
 // Same lane layout and MFMA sequence as k_conv3x3_rows_mfma<2, 1> (quad q = input channel R/G/B,
-// lane = group of 4 output pixels = 8 input columns; the left halo column from the previous lane),
+// lane = group of 4 output pixels = 8 input columns; the left halo column from the previous group),
 // same integer formulas as jpeg_kernels.hip, hence bit-identical to the two-kernel path.
-// Chroma column sums 3*near + far are computed for the lane's 4 chroma columns; the two
-// neighbour columns come from the adjacent lanes (clamped at the row ends as jdsample.c does).
+// The conversion itself is pixel-parallel (one lane = one pixel pair, all three channels) and reaches
+// the MFMA layout through a per-wave LDS buffer: see "Conversion" below.
 __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const ConvArgs& a = sa.a;
   constexpr int HL = 1, NG = 16 - 2 * HL;
