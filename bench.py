@@ -170,11 +170,18 @@ def usable_cpus():
     return max(1, n)
 
 
-def kernel_source_sha():
-    """Hash of the kernel sources: a PMC traffic figure is only reported for the code it was measured on."""
+def kernel_source_sha(root=ROOT):
+    """Hash of the kernel sources' CODE (comments and blank space stripped: rewording a comment is not another kernel): a
+    PMC traffic figure is only reported for the code it was measured on.  tools/finish_profiles.py stamps with the same
+    function."""
+    import re
+
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "infercam_onnx_amd", "csrc", "*.hip"))):
-        h.update(open(f, "rb").read())
+    for f in sorted(glob.glob(os.path.join(root, "infercam_onnx_amd", "csrc", "*.hip"))):
+        text = open(f, "r", encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update("\n".join(" ".join(line.split()) for line in text.splitlines() if line.strip()).encode())
     return h.hexdigest()[:16]
 
 

@@ -34,11 +34,11 @@ shutil.copy(fetch, os.path.join(dst, "pmc_fetch_counter_collection.csv"))
 shutil.copy(write, os.path.join(dst, "pmc_write_counter_collection.csv"))
 out = os.path.join(dst, "pmc_traffic.json")
 print(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), fetch, write, out]).decode())
-h = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(ROOT, "infercam_onnx_amd", "csrc", "*.hip"))):
-    h.update(open(f, "rb").read())
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the same hash bench.py checks: code only, comments stripped)
+
 d = json.load(open(out))
-d["kernel_source_sha"] = h.hexdigest()[:16]
+d["kernel_source_sha"] = bench.kernel_source_sha(ROOT)
 d["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 d["profile"] = name
 json.dump(d, open(out, "w"), indent=1)
