@@ -854,8 +854,9 @@ int alloc_slot(ufd_model* m, Slot& s) {
   HIPC(m, hipHostMalloc(&s.h_dets, sizeof(Det) * kDetCopy * m->B, hipHostMallocDefault));
   HIPC(m, hipMalloc(&s.d_dets, sizeof(Det) * m->K * m->B));
   HIPC(m, hipMemset(s.d_dets, 0, sizeof(Det) * m->K * m->B));
-  HIPC(m, hipHostMalloc(&s.h_ndet, sizeof(uint32_t) * m->B, hipHostMallocDefault));
-  HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * m->B, hipHostMallocDefault));
+  // (decode status and detection counts side by side, as on the device: ONE copy brings both back)
+  HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * 2 * m->B, hipHostMallocDefault));
+  s.h_ndet = s.h_gpu_status + m->B;
   s.plans.resize(m->B);
   HIPC(m, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.st.resize(m->B);
@@ -1156,9 +1157,12 @@ void enqueue_nms(ufd_model* m, Slot& s, uint32_t count) {
 }
 
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
-  HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
+  // [B decode statuses][B detection counts] are one allocation on both sides: one copy of B + count words (statuses past
+  // `count` are stale and never read), or the counts alone when the host decoded the entropy stage
   if (s.gpu_entropy)
-    HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * ((size_t)m->B + count), hipMemcpyDeviceToHost, tl_cur->stream));
+  else
+    HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
   HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, s.d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
                            hipMemcpyDeviceToHost, tl_cur->stream));
   HIPC(m, hipEventRecord(s.done, tl_cur->stream));
@@ -2007,7 +2011,7 @@ void destroy(ufd_model* m) {
       if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
     }
     dfree(c.d_planes), dfree(c.d_rgb), dfree(c.d_sync);
-    dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts), dfree(c.d_ndet);
+    dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts);  // (d_ndet lives behind d_status)
     dfree(c.d_spill);
     dfree(c.d_nms_mat);
     dfree(c.enc.planes), dfree(c.enc.coef), dfree(c.enc.bits), dfree(c.enc.total_bits), dfree(c.enc.words), dfree(c.enc.chunk_ff);
@@ -2023,8 +2027,7 @@ void destroy(ufd_model* m) {
     if (s.h_coef) (void)hipHostFree(s.h_coef);
     if (s.h_dets) (void)hipHostFree(s.h_dets);
     if (s.d_dets) (void)hipFree(s.d_dets);
-    if (s.h_ndet) (void)hipHostFree(s.h_ndet);
-    if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);
+    if (s.h_gpu_status) (void)hipHostFree(s.h_gpu_status);  // (h_ndet lives behind it)
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.d_enc_out) (void)hipFree(s.d_enc_out);
     if (s.d_enc_meta) (void)hipFree(s.d_enc_meta);
@@ -2204,8 +2207,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
   HIPB(hipMalloc(&m->d_sync_luts, sizeof(SyncLutImage) * ufd_model::kMaxLutSets));
   for (int ci = 0; ci < m->num_ctx; ci++) {
     Ctx& c = m->ctx[ci];
-    HIPB(hipMalloc(&c.d_status, sizeof(uint32_t) * B));
-    HIPB(hipMemset(c.d_status, 0, sizeof(uint32_t) * B));
+    HIPB(hipMalloc(&c.d_status, sizeof(uint32_t) * 2 * B));  // [B decode statuses][B detection counts]
+    HIPB(hipMemset(c.d_status, 0, sizeof(uint32_t) * 2 * B));
+    c.d_ndet = c.d_status + B;
     HIPB(hipMalloc(&c.d_arena, std::max<size_t>(m->arena_floats, 64) * sizeof(float)));
     HIPB(hipMalloc(&c.d_input, B * 3 * m->W * m->H * sizeof(float)));
     for (int i = 0; i < 2; i++) {
@@ -2227,7 +2231,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_keys, B * m->key_stride * sizeof(unsigned long long)));
     HIPB(hipMalloc(&c.d_counts, B * sizeof(uint32_t)));
     HIPB(hipMemset(c.d_counts, 0, B * sizeof(uint32_t)));
-    HIPB(hipMalloc(&c.d_ndet, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
     HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B)));
   }
