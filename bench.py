@@ -113,7 +113,15 @@ def parse_args():
     ap.add_argument("--annotate", action="store_true",
                     help="time the whole Inferer::run iteration instead (decode -> infer -> rectangles -> JPEG re-encode, "
                          "ufd_submit_annotate_batch): a side workload for profiling N1, not BASELINE.json's metric")
-    ap.add_argument("--profile-every", type=int, default=10, help="record kernel events for every n-th timed step (0: never)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="record kernel events for every n-th step of the timed region (default 0: never -- the timed region and "
+                         "the steady-state run carry no event packets; the roofline comes from its own fully sampled pass behind them)")
+    ap.add_argument("--cpus", type=int, default=0,
+                    help="restrict this process to its first N usable CPUs before anything touches the GPU (host-scaling sweep: "
+                         "what 8 ranks sharing one host leave each of them)")
+    ap.add_argument("--host-only", action="store_true",
+                    help="timed region + steady state + the `host` object only (no roofline pass, side workloads, verification "
+                         "or CPU baseline): one point of tools/host_scaling.py's sweep")
     return ap.parse_args()
 
 
@@ -193,6 +201,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run --nproc-per-node N"
                          % (args.gpus, world))
+    if args.cpus > 0:  # before torch / HIP start their threads: they inherit the mask
+        cur = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, cur[:max(1, min(args.cpus, len(cur)))])
     import torch
 
     dist = None
@@ -286,6 +297,9 @@ def main():
 
     primary_staged = args.input == "hbm"
     get_batches(primary_staged)
+    # (UFD_FLAG_PROFILE only ARMS the per-kernel events; a batch records them when the sampling counter says so, and in
+    # the timed region and the steady-state run it never does unless --profile-every asks)
+    model.profile_sampling(1 << 30)
     run_steps(args.warmup, primary_staged)
     model.profile_reset()
     model.profile_sampling(args.profile_every if args.profile_every > 0 else 1 << 30)
@@ -338,16 +352,31 @@ def main():
     extras = {}
     if args.annotate:
         args.no_extras = True
+    host_only = args.host_only
     if not args.no_extras:
         # ---- steady state: the same workload, >= 200 more steps behind the timed region (a 20-step sample holds one
         # pipeline fill and one drain in 15 ms; this figure does not)
         k_ss = max(200, args.steps)
+        model.profile_sampling(1 << 30)
         torch.cuda.synchronize()
+        model.host_stats_reset()
         t1 = time.perf_counter()
         run_steps(k_ss, primary_staged)
         torch.cuda.synchronize()
-        extras["steady_state"] = {"fps": round(B * k_ss / (time.perf_counter() - t1), 1), "steps": k_ss,
+        el_ss = time.perf_counter() - t1
+        extras["steady_state"] = {"fps": round(B * k_ss / el_ss, 1), "steps": k_ss,
                                   "what": "this rank, same submit/wait loop as the timed region, run right behind it"}
+        # ---- the host side of that run (ufd_host_stats: always-on counters of the library, no kernel events recorded)
+        hs = model.host_stats()
+        hs["usable_cpus"] = usable_cpus()
+        hs["host_threads"] = host_threads
+        hs["ms_per_batch"] = round(el_ss / k_ss * 1e3, 4)
+        hs["what"] = ("steady-state run, kernel profiling off: wall microseconds per batch on the issuing worker (header scan, "
+                      "staging memcpy, launch issue) and in the caller's ufd_wait; busy share of each context's issue worker; "
+                      "per context the share of wall time its stream had a batch running and the idle gap between the end of one "
+                      "batch and the first kernel of the next (HIP events on the stream)")
+        extras["host"] = hs
+    if not args.no_extras and not host_only:
         # ---- roofline pass: the pipeline loaded exactly as in the timed region (depth batches in flight over the
         # contexts), EVERY launch of every kernel timed with HIP events on the library's own streams
         model.profile_sampling(1)
@@ -356,7 +385,7 @@ def main():
         run_steps(ROOF_STEPS, primary_staged)
         extras["kernel_stats_loaded"] = model.profile_read()
         model.profile_sampling(1 << 30)
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not host_only:
         # ---- the same workload over the other boundary
         if device_entropy:
             other = not primary_staged
@@ -418,7 +447,7 @@ def main():
                                        "what": "ufd_infer_jpeg, one %dx%d frame at a time, host bytes -> host detections" % (SW, SH)}
 
     verified = None
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not host_only:
         # ---- after the clock: detections of the batches just timed vs the CPU oracle
         from concurrent.futures import ThreadPoolExecutor
 
@@ -548,6 +577,8 @@ def main():
         if "steady_state" in extras:
             out["steady_state_fps"] = extras["steady_state"]["fps"]
             out["steady_state"] = extras["steady_state"]
+        if "host" in extras:
+            out["host"] = extras["host"]
         if "stages" in extras:
             out["stages"] = extras["stages"]
         if "latency_ms_batch1" in extras:
@@ -566,7 +597,7 @@ def main():
             with open(dump, "w") as f:
                 json.dump({"steps": prof_steps, "batch": B, "stats": stats, "roof_steps": ROOF_STEPS,
                            "stats_loaded": extras.get("kernel_stats_loaded"), "stats_alone": extras.get("kernel_stats_alone")}, f, indent=1)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not host_only:
             out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H)
         print(json.dumps(out), flush=True)
     if staged_batches:

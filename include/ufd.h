@@ -346,6 +346,37 @@ int ufd_profile_reset(ufd_model* m);
 int ufd_profile_sampling(ufd_model* m, uint32_t every_n);
 int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n);
 
+/* ---- measurement (bench.py `host` object): what the HOST side of the asynchronous pipeline costs, always on (a handful
+ * of clock reads and two event records per batch; no UFD_FLAG_PROFILE needed).  The reference has one blocking task
+ * (inferer.rs:29-50); here each of the handle's contexts has an issue worker, and SURVEY 8(e) names the host as the
+ * limiter of eight GPUs on one box -- these counters say how far from that a run is.
+ *   per batch (sums over the batches issued since the last reset, milliseconds of wall time on the issuing worker):
+ *     plan_ms   header + marker scan of the batch's JPEGs, Huffman table-set lookup, scan layouts
+ *     copy_ms   the JPEG bytes into the pinned staging block
+ *     issue_ms  every hipMemcpyAsync / kernel launch / event of the batch (the worker's time minus the two above)
+ *   wait_ms     time callers spent blocked inside ufd_wait (worker not done issuing, or the GPU not done)
+ *   per context c < num_ctx:
+ *     worker_busy_ms[c]  time the context's issue worker was working (share = / wall_ms)
+ *     gpu_span_ms[c]     device time from the first kernel of a batch to its result copy, summed (HIP events)
+ *     gpu_gap_ms[c]      device time the context's stream sat between the end of one batch and the first kernel of the
+ *                        next (nothing issued yet, or its H2D not there yet), summed over gpu_batches[c] - 1 gaps */
+#define UFD_MAX_CTX 8
+typedef struct ufd_host_stats {
+  uint32_t struct_size; /* = sizeof(ufd_host_stats) */
+  uint32_t num_ctx;
+  uint64_t batches, launches; /* batches issued; kernel launches + copies enqueued for them */
+  double wall_ms;             /* since the last reset */
+  double plan_ms, copy_ms, issue_ms;
+  uint64_t waits;
+  double wait_ms;
+  double worker_busy_ms[UFD_MAX_CTX];
+  uint64_t gpu_batches[UFD_MAX_CTX];
+  double gpu_span_ms[UFD_MAX_CTX];
+  double gpu_gap_ms[UFD_MAX_CTX];
+} ufd_host_stats;
+int ufd_host_stats_reset(ufd_model* m);
+int ufd_host_stats_read(ufd_model* m, ufd_host_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

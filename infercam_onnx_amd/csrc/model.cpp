@@ -49,6 +49,13 @@ thread_local Ctx* tl_cur = nullptr;
 thread_local ThreadPool* tl_pool = nullptr;
 thread_local bool tl_prof = true;  // record kernel events for the batch being issued by this thread
 thread_local bool tl_force_rider = false;  // enqueue_layer_launch: issue a riding layer on its own (its host could not take it)
+struct Worker;
+thread_local Worker* tl_worker = nullptr;  // issue worker this thread is (host statistics go to it), or null on API threads
+thread_local uint64_t tl_launches = 0;     // launches + copies enqueued by this thread (ProfScope counts them)
+
+inline uint64_t now_ns() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct Tensor {
   size_t off = 0;  // float offset in the activation arena (for the whole batch)
@@ -138,6 +145,9 @@ struct Slot {
   uint32_t* d_enc_meta = nullptr;  // [B] length, [B] offset, [1] total
   uint32_t* h_enc_meta = nullptr;  // pinned copy
   hipEvent_t enc_copied = nullptr;
+  // host statistics: which pair of the context's span events this batch recorded (-1: none, e.g. nothing decodable)
+  int span_idx = -1;
+  uint64_t span_seq = 0;
   int issue_rc = 0;          // result of the worker's entropy stage + enqueue
   std::string issue_err;
   int state = 0;             // 0 free, 1 queued for the worker, 2 issued to the GPU (guarded by Worker::mu)
@@ -152,6 +162,8 @@ struct Worker {
   Ctx* ctx = nullptr;
   std::unique_ptr<ThreadPool> pool;
   unsigned host_threads = 1;
+  // host statistics (ufd_host_stats_read): written by the worker thread only
+  std::atomic<uint64_t> ns_busy{0}, ns_plan{0}, ns_copy{0}, batches{0}, launches{0};
 };
 
 // Device-side working set of one in-flight batch.  A handle owns kNumCtx of them and alternates
@@ -183,6 +195,14 @@ struct Ctx {
   float4* d_spill = nullptr;
   unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
   uint32_t last_forward_count = 0;
+  // host statistics: begin / end events of the last kSpanRing batches of this context (timing enabled).  Batch j uses pair
+  // j % kSpanRing; at most UFD_MAX_SLOTS batches are in flight, so pair j - 1 is still intact when batch j is finished.
+  static constexpr int kSpanRing = 2 * UFD_MAX_SLOTS;
+  hipEvent_t ev_span[kSpanRing][2] = {};
+  uint64_t span_issued = 0;    // batches that recorded a span (issue worker / API thread under the handle lock)
+  uint64_t span_last_done = 0; // 1 + sequence number of the last batch folded into the sums below (shared_mu)
+  uint64_t gpu_batches = 0;
+  double gpu_span_ms = 0, gpu_gap_ms = 0;
   // N1 encoder scratch, sized for the largest frame an annotate batch of this context has had (regrown when a larger
   // one arrives), and the (quality, framing) set-ups seen: quantiser + marker segments, each with its own device header,
   // so that streams of one model that differ in quality or framing alternate without a stream drain
@@ -232,6 +252,8 @@ struct ufd_model {
   uint32_t max_w = 0, max_h = 0;
   Ctx ctx[kMaxCtx];
   Worker workers[kMaxCtx];
+  std::atomic<uint64_t> ns_wait{0}, waits{0};
+  uint64_t stats_t0 = 0;  // now_ns() of the last ufd_host_stats_reset (or of ufd_create)
   int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s; each has its own stream pair
   int next_ctx = 0;
   std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
@@ -369,6 +391,7 @@ struct ProfScope {
   hipStream_t st;
   ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
       : m(mm), on(mm->profile && tl_prof), st(stream ? stream : tl_cur->stream) {
+    tl_launches++;
     if (!on) return;
     {
       std::lock_guard<std::mutex> lk(m->shared_mu);
@@ -1126,6 +1149,39 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
 }
 
 // [count][3][H][W] in d_input (or the sample planes, fused stem) -> every conv output the heads need.
+// Host statistics: the batch's first kernel is about to be enqueued on the context's stream (its H2D, if any, is already
+// waited for on that stream) -- the time between the previous batch's end event and this one is time the stream had
+// nothing to run.
+void span_begin(Slot& s) {
+  Ctx& c = *tl_cur;
+  if (s.span_idx >= 0 || !c.ev_span[0][0]) return;
+  s.span_seq = c.span_issued++;
+  s.span_idx = (int)(s.span_seq % Ctx::kSpanRing);
+  (void)hipEventRecord(c.ev_span[s.span_idx][0], c.stream);
+}
+
+// ... and its last operation has been enqueued
+void span_end(Slot& s) {
+  if (s.span_idx >= 0) (void)hipEventRecord(tl_cur->ev_span[s.span_idx][1], tl_cur->stream);
+}
+
+// The slot's batch is complete: fold its span (and the gap in front of it) into the context's sums.
+void span_fold(ufd_model* m, Slot& s) {
+  if (s.span_idx < 0 || !s.ctx) return;
+  Ctx& c = *s.ctx;
+  float span = 0, gap = 0;
+  const int prev = (int)((s.span_seq + Ctx::kSpanRing - 1) % Ctx::kSpanRing);
+  const bool ok = hipEventElapsedTime(&span, c.ev_span[s.span_idx][0], c.ev_span[s.span_idx][1]) == hipSuccess;
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  // (a gap only between consecutive batches of the context, both since the last reset)
+  const bool have_prev = s.span_seq > 0 && c.span_last_done == s.span_seq &&
+                         hipEventElapsedTime(&gap, c.ev_span[prev][1], c.ev_span[s.span_idx][0]) == hipSuccess;
+  if (ok) c.gpu_batches++, c.gpu_span_ms += span;
+  if (ok && have_prev && c.gpu_batches > 1) c.gpu_gap_ms += std::max(gap, 0.0f);
+  c.span_last_done = s.span_seq + 1;
+  s.span_idx = -1;
+}
+
 void enqueue_forward(ufd_model* m, uint32_t count) {
   for (int i = 0; i < kNumConv; i++) enqueue_layer(m, i, count);
   tl_cur->last_forward_count = count;
@@ -1165,6 +1221,7 @@ int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
     HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
   HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, s.d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
                            hipMemcpyDeviceToHost, tl_cur->stream));
+  span_end(s);
   HIPC(m, hipEventRecord(s.done, tl_cur->stream));
   s.ctx = tl_cur;
   return UFD_OK;
@@ -1230,7 +1287,12 @@ int finish_slot(ufd_model* m, Slot& s, bool locked = true) {
     m->fail(rc, s.issue_err);
     return rc;
   }
-  HIPC(m, hipEventSynchronize(s.done));
+  {
+    const uint64_t t0 = now_ns();
+    HIPC(m, hipEventSynchronize(s.done));
+    m->ns_wait.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+  }
+  span_fold(m, s);
   // timing events are resolved lazily (ufd_profile_read): querying ~100 events per batch here
   // would stall the submit/wait pipeline
   bool flush = false;
@@ -1278,6 +1340,7 @@ Slot* find_free_slot(ufd_model* m) {
       s.job_jpegs = nullptr, s.job_lens = nullptr, s.job_staged = nullptr;
       s.annot = false, s.annot_ran = false;
       s.state = 0;
+      s.span_idx = -1;
       return &s;
     }
   return nullptr;
@@ -1358,6 +1421,7 @@ void pin_lut_sets(ufd_model* m, const HuffScan* scans, uint32_t count, int delta
 DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count) {
   DevicePlan p;
   HostScope hs(m, "host_plan");
+  const uint64_t t_plan0 = now_ns();
   tl_pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
@@ -1418,9 +1482,15 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
     s.h_scans[i] = sc;
   }
   if (p.blob_base + blob_fill > m->stage_cap) return p;
+  const uint64_t t_copy0 = now_ns();
   tl_pool->parallel_for(count, [&](unsigned i) {
     if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + s.h_scans[i].blob_off, jpegs[i], lens[i]);
   });
+  if (tl_worker) {
+    const uint64_t t_copy1 = now_ns();
+    tl_worker->ns_plan.fetch_add(t_copy0 - t_plan0, std::memory_order_relaxed);
+    tl_worker->ns_copy.fetch_add(t_copy1 - t_copy0, std::memory_order_relaxed);
+  }
   p.used_blob = blob_fill;
   p.stage_bytes = p.blob_base + blob_fill;
   for (uint32_t i = 0; i < count; i++) {
@@ -1483,6 +1553,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
       }
       HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+      span_begin(s);
       uint8_t* ds = c.d_stage_buf[buf];
       return enqueue_device_entropy(m, c, p, count, ds + p.blob_base, c.d_descs_buf[buf], reinterpret_cast<const HuffScan*>(ds + m->scans_off),
                                     reinterpret_cast<const HuffInterval*>(ds + m->ivs_off), c.d_coef_buf[buf]);
@@ -1525,6 +1596,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   }
   HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
   HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+  span_begin(s);
   return UFD_OK;
 }
 
@@ -1690,6 +1762,7 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
     c.flip ^= 1;
     // the slab is written on the context's own stream: ordered behind its previous readers; a
     // host-path batch that reuses it later waits for ev_consumed as usual
+    span_begin(s);
     rc = enqueue_device_entropy(m, c, g.plan, count, g.d_blob, g.d_descs, g.d_scans, g.d_ivs, c.d_coef_buf[buf]);
     if (rc) return rc;
   }
@@ -1823,6 +1896,7 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
 
 // `count` same-size RGB frames already in d_rgb (tight pitch) -> pipeline
 int run_rgb_on_device(ufd_model* m, Slot& s, uint32_t w, uint32_t h, uint32_t count) {
+  span_begin(s);
   {
     ProfScope ps(m, "resize_norm", 0, 0);
     if ((int)w == m->W && (int)h == m->H) {
@@ -1925,6 +1999,7 @@ void worker_main(ufd_model* m, Worker* w) {
   (void)hipSetDevice(m->cfg.device_id);
   tl_cur = w->ctx;
   tl_pool = w->pool.get();
+  tl_worker = w;
   for (;;) {
     Slot* s = nullptr;
     {
@@ -1935,6 +2010,8 @@ void worker_main(ufd_model* m, Worker* w) {
     }
     tl_prof = s->job_prof;
     int rc = UFD_OK;
+    const uint64_t t_busy0 = now_ns();
+    const uint64_t launches0 = tl_launches;
     try {
       HostScope hs(m, "host_issue");  // everything the worker does for one batch (host_plan included)
       rc = s->job_staged ? submit_staged(m, *s, *s->job_staged) : submit_jpegs(m, *s, s->job_jpegs, s->job_lens, s->count);
@@ -1943,6 +2020,9 @@ void worker_main(ufd_model* m, Worker* w) {
     } catch (...) {
       rc = m->fail(UFD_E_DEVICE, "unknown exception");
     }
+    w->ns_busy.fetch_add(now_ns() - t_busy0, std::memory_order_relaxed);
+    w->launches.fetch_add(tl_launches - launches0, std::memory_order_relaxed);
+    w->batches.fetch_add(1, std::memory_order_relaxed);
     {
       std::lock_guard<std::mutex> lk(w->mu);
       s->issue_rc = rc;
@@ -2009,6 +2089,10 @@ void destroy(ufd_model* m) {
       dfree(c.d_stage_buf[i]), dfree(c.d_coef_buf[i]);
       if (c.ev_copied[i]) (void)hipEventDestroy(c.ev_copied[i]);
       if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
+    }
+    for (auto& pair : c.ev_span) {
+      for (auto& e : pair)
+        if (e) (void)hipEventDestroy(e);
     }
     dfree(c.d_planes), dfree(c.d_rgb), dfree(c.d_sync);
     dfree(c.d_scores), dfree(c.d_boxes), dfree(c.d_keys), dfree(c.d_counts);  // (d_ndet lives behind d_status)
@@ -2219,6 +2303,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
       HIPB(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
       HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
     }
+    for (auto& pair : c.ev_span)
+      for (auto& e : pair) HIPB(hipEventCreate(&e));
     if (m->gpu_entropy_enabled) {
       HIPB(hipMalloc(&c.d_sync, sync_buffers_bytes((uint32_t)B, m->blob_stride, m->coef_stride / 64, nullptr)));
       c.sync.stream = c.d_sync;
@@ -2257,6 +2343,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
       return rc;
     }
   }
+  m->stats_t0 = now_ns();
   *out = m;
   return UFD_OK;
 }
@@ -2518,7 +2605,12 @@ int ufd_wait(ufd_model* m, uint32_t ticket) {
     s->waiting = true;
   }
   // not holding the handle lock while the worker and the GPU finish: other threads may submit
-  wait_issued(m, *s);
+  {
+    const uint64_t t0 = now_ns();
+    wait_issued(m, *s);
+    m->ns_wait.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    m->waits.fetch_add(1, std::memory_order_relaxed);
+  }
   try {
     (void)hipSetDevice(m->cfg.device_id);  // (a failure shows up in the event wait below, which also releases the slot)
     tl_cur = s->ctx;
@@ -2800,6 +2892,42 @@ int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size
   } catch (...) {
     return UFD_E_DEVICE;
   }
+}
+
+int ufd_host_stats_reset(ufd_model* m) {
+  if (!m) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  for (int c = 0; c < m->num_ctx; c++) {
+    Worker& w = m->workers[c];
+    w.ns_busy = 0, w.ns_plan = 0, w.ns_copy = 0, w.batches = 0, w.launches = 0;
+    m->ctx[c].gpu_batches = 0, m->ctx[c].gpu_span_ms = 0, m->ctx[c].gpu_gap_ms = 0;
+  }
+  m->ns_wait = 0, m->waits = 0;
+  m->stats_t0 = now_ns();
+  return UFD_OK;
+}
+
+int ufd_host_stats_read(ufd_model* m, ufd_host_stats* out) {
+  if (!m || !out || out->struct_size != sizeof(ufd_host_stats)) return UFD_E_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->struct_size = sizeof(*out);
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  out->num_ctx = (uint32_t)m->num_ctx;
+  out->wall_ms = (double)(now_ns() - m->stats_t0) * 1e-6;
+  uint64_t busy = 0, plan = 0, copy = 0;
+  for (int c = 0; c < m->num_ctx; c++) {
+    const Worker& w = m->workers[c];
+    busy += w.ns_busy, plan += w.ns_plan, copy += w.ns_copy;
+    out->batches += w.batches, out->launches += w.launches;
+    out->worker_busy_ms[c] = (double)w.ns_busy * 1e-6;
+    out->gpu_batches[c] = m->ctx[c].gpu_batches;
+    out->gpu_span_ms[c] = m->ctx[c].gpu_span_ms;
+    out->gpu_gap_ms[c] = m->ctx[c].gpu_gap_ms;
+  }
+  out->plan_ms = (double)plan * 1e-6, out->copy_ms = (double)copy * 1e-6;
+  out->issue_ms = (double)(busy - std::min(busy, plan + copy)) * 1e-6;
+  out->waits = m->waits, out->wait_ms = (double)m->ns_wait * 1e-6;
+  return UFD_OK;
 }
 
 int ufd_profile_reset(ufd_model* m) {

@@ -87,6 +87,14 @@ class UfdKernelStat(ctypes.Structure):
                 ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
 
 
+class UfdHostStats(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("num_ctx", ctypes.c_uint32), ("batches", ctypes.c_uint64),
+                ("launches", ctypes.c_uint64), ("wall_ms", ctypes.c_double), ("plan_ms", ctypes.c_double),
+                ("copy_ms", ctypes.c_double), ("issue_ms", ctypes.c_double), ("waits", ctypes.c_uint64),
+                ("wait_ms", ctypes.c_double), ("worker_busy_ms", ctypes.c_double * 8), ("gpu_batches", ctypes.c_uint64 * 8),
+                ("gpu_span_ms", ctypes.c_double * 8), ("gpu_gap_ms", ctypes.c_double * 8)]
+
+
 # every symbol include/ufd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
@@ -99,6 +107,7 @@ ABI_SYMBOLS = (
     "ufd_sched_create", "ufd_sched_destroy", "ufd_sched_add_stream", "ufd_sched_remove_stream", "ufd_sched_push",
     "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
     "ufd_create_replicas", "ufd_model_placement", "ufd_annotate_parity", "ufd_model_host_alloc", "ufd_sched_debug_table",
+    "ufd_host_stats_reset", "ufd_host_stats_read",
 )
 
 _lib = None
@@ -174,6 +183,8 @@ def load_library():
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
+    L.ufd_host_stats_reset.argtypes = [vp]
+    L.ufd_host_stats_read.argtypes = [vp, ctypes.POINTER(UfdHostStats)]
     _lib = L
     return L
 
@@ -591,6 +602,32 @@ class UltrafaceModel(InferModel):
     def profile_sampling(self, every_n):
         """Record kernel events only for every `every_n`-th batch."""
         self._check(self._lib.ufd_profile_sampling(self._h, int(every_n)))
+
+    def host_stats_reset(self):
+        self._check(self._lib.ufd_host_stats_reset(self._h))
+
+    def host_stats(self):
+        """What the host side of the asynchronous pipeline cost since the last reset (ufd_host_stats, include/ufd.h):
+        per-batch microseconds of header scan / staging copy / launch issue / caller wait, the busy share of every
+        issue worker, and per context the device-time span of its batches and the idle gaps between them."""
+        st = UfdHostStats()
+        st.struct_size = ctypes.sizeof(UfdHostStats)
+        self._check(self._lib.ufd_host_stats_read(self._h, ctypes.byref(st)))
+        nb = max(int(st.batches), 1)
+        nc = int(st.num_ctx)
+        wall = max(st.wall_ms, 1e-9)
+        gaps = [max(int(st.gpu_batches[c]) - 1, 1) for c in range(nc)]
+        return {
+            "batches": int(st.batches), "wall_ms": round(st.wall_ms, 3),
+            "launches_per_batch": round(st.launches / nb, 1),
+            "per_batch_us": {"header_scan": round(st.plan_ms / nb * 1e3, 1), "staging_memcpy": round(st.copy_ms / nb * 1e3, 1),
+                             "launch_issue": round(st.issue_ms / nb * 1e3, 1),
+                             "wait": round(st.wait_ms / max(int(st.waits), 1) * 1e3, 1)},
+            "worker_busy_share": [round(st.worker_busy_ms[c] / wall, 4) for c in range(nc)],
+            "gpu_span_share": [round(st.gpu_span_ms[c] / wall, 4) for c in range(nc)],
+            "gpu_span_ms_per_batch": [round(st.gpu_span_ms[c] / max(int(st.gpu_batches[c]), 1), 4) for c in range(nc)],
+            "gpu_idle_gap_us_per_batch": [round(st.gpu_gap_ms[c] / gaps[c] * 1e3, 1) for c in range(nc)],
+        }
 
     def profile_read(self):
         """-> [dict(name, launches, total_ms, bytes, flops)] per kernel since the last reset."""

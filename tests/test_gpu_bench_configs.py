@@ -114,6 +114,34 @@ def test_c3_batch32_bench_handle_det_cap_256(pool_c3, refs_c3, weights):
         m.close()
 
 
+def test_host_stats_account_for_every_batch(pool_c3, weights):
+    """ufd_host_stats (bench.py's `host` object): 24 batches through the bench's submit / wait loop are all counted, each
+    with its launches, a device-time span on its context and (between consecutive batches of a context) a gap; a reset
+    zeroes the sums."""
+    m = _model(640, weights, max_batch=32, max_src=(640, 480), det_cap=256)
+    try:
+        batches = [m._prep_batch(pool_c3[i * 32:(i + 1) * 32]) for i in range(6)]
+        _pipeline(m, batches, m.submit_jpeg_batch, 1, 6)  # warm
+        m.host_stats_reset()
+        _pipeline(m, batches, m.submit_jpeg_batch, 4, 6)
+        hs = m.host_stats()
+        assert hs["batches"] == 24, hs
+        assert 15 <= hs["launches_per_batch"] <= 80, hs
+        pb = hs["per_batch_us"]
+        assert pb["header_scan"] > 0 and pb["staging_memcpy"] > 0 and pb["launch_issue"] > 0 and pb["wait"] >= 0, hs
+        assert len(hs["worker_busy_share"]) == len(hs["gpu_span_share"]) >= 2, hs
+        assert all(0 < v < 1.0 for v in hs["worker_busy_share"]), hs
+        assert all(0 < v <= 1.02 for v in hs["gpu_span_share"]), hs
+        assert all(0.05 < v < 50 for v in hs["gpu_span_ms_per_batch"]), hs
+        assert all(v >= 0 for v in hs["gpu_idle_gap_us_per_batch"]), hs
+        m.host_stats_reset()
+        z = m.host_stats()
+        assert z["batches"] == 0 and z["per_batch_us"]["launch_issue"] == 0, z
+        print("host stats:", hs)
+    finally:
+        m.close()
+
+
 def test_c5_batch16_1280x720_matches_oracle(oracle_lib, weights):
     """BASELINE C5: 1280x720 frames -> UltraFace-640 (Triangle resize 2.0 x 1.5 on the GPU), batch 16."""
     from infercam_onnx_amd import synth
