@@ -50,10 +50,11 @@ KERNEL_FUNCS = {
     "huff_unstuff": "k_huff_unstuff", "huff_seed": "k_huff_seed", "huff_extend": "k_huff_extend", "huff_link": "k_huff_link",
     "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
     "conv_dwpw_coop": "k_dwpw_coop", "stem_planes_mfma": "k_stem_planes_mfma",
-    "sort_nms": "k_sort_nms", "conv_dual": "k_dual_dwpw",
+    "sort_nms": "k_sort_nms", "conv_dual_coop": "k_dual_dwpw_coop", "conv_dual_pw": "k_dual_dwpw_pw",
+    "nms_matrix": "k_nms_matrix", "nms_scan": "k_nms_scan",
 }
-MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual", "stem_planes_mfma", "conv3x3_mfma",
-                "conv3x3_rows_mfma")
+MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual_coop", "conv_dual_pw",
+                "stem_planes_mfma", "conv3x3_mfma", "conv3x3_rows_mfma")
 
 
 def base_label(key):
@@ -119,6 +120,11 @@ def parse_args():
     ap.add_argument("--cpus", type=int, default=0,
                     help="restrict this process to its first N usable CPUs before anything touches the GPU (host-scaling sweep: "
                          "what 8 ranks sharing one host leave each of them)")
+    ap.add_argument("--one-process", action="store_true",
+                    help="config C4 in ONE process (the reference server is one process, infer_server.rs:39-68): "
+                         "ufd_create_replicas over --gpus devices (RCCL broadcast of the weights) and ONE ufd_sched over the "
+                         "replicas, one producer thread per camera stream; no torch.distributed launcher")
+    ap.add_argument("--spin-wait", action="store_true", help="UFD_FLAG_SPIN_WAIT: ufd_wait always spins in the runtime (A/B of the sleeping wait)")
     ap.add_argument("--host-only", action="store_true",
                     help="timed region + steady state + the `host` object only (no roofline pass, side workloads, verification "
                          "or CPU baseline): one point of tools/host_scaling.py's sweep")
@@ -193,8 +199,107 @@ def kernel_source_sha(root=ROOT):
     return h.hexdigest()[:16]
 
 
+def main_one_process(args):
+    """C4 as the reference's process model has it: one server process, N GPUs.  ufd_create_replicas reads the weights once
+    and broadcasts the packed image over RCCL; ONE scheduler (ufd_sched over models_640[N]) places stream i on GPU i mod N;
+    one producer thread per camera stream pushes its frames (ufd_sched_push_batch, drop-on-full retried by the producer so
+    that every step's frames do run); the clock runs from the first push to ufd_sched_flush."""
+    import threading
+
+    import torch
+
+    from infercam_onnx_amd import nn, scheduler, synth
+
+    N, B, K, Wm = args.gpus, args.batch, args.steps, args.warmup
+    Wd, Hd = (640, 480) if args.variant == 640 else (320, 240)
+    variant = nn.UltrafaceVariant.W640H480 if args.variant == 640 else nn.UltrafaceVariant.W320H240
+    weights = synth.synthetic_weights()
+    priors = synth.gen_priors(Wd, Hd)
+    SW, SH = (int(v) for v in args.src.lower().split("x")) if args.src else (Wd, Hd)
+    host_threads = args.host_threads or max(2, min(32, usable_cpus() // N))
+    kw = dict(max_batch=B, weights=weights, priors=priors, max_src=(SW, SH), host_threads=host_threads, det_cap=256)
+    if args.rehearse_one_gpu:  # N handles on cuda:0: the script path on a one-GPU box, not a measurement
+        models = [nn.UltrafaceModel(variant, 0.5, 0.5, device_id=0, **kw) for _ in range(N)]
+    else:
+        if torch.cuda.device_count() < N:
+            raise SystemExit("bench.py --one-process --gpus %d: only %d devices visible" % (N, torch.cuda.device_count()))
+        models = nn.UltrafaceModel.create_replicas(variant, 0.5, 0.5, list(range(N)), **kw)
+    pools = [synth.synth_jpeg_pool(r, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows) for r in range(N)]
+    nb = max(1, args.pool // B)
+    batches = [[models[0]._prep_batch(pools[r][i * B:(i + 1) * B]) for i in range(nb)] for r in range(N)]
+    sch = scheduler.Scheduler(models_640=models if args.variant == 640 else None, models_320=models if args.variant == 320 else None,
+                              on_result=False, ring_slots=8 * B, max_wait_us=2000, max_inflight=args.depth, det_cap=256)
+    hs = [sch.add_stream(1000 + r, args.variant) for r in range(N)]
+    where = [sch.stream_replica(h) for h in hs]
+
+    def produce(r, steps):
+        for s_ in range(steps):
+            b, first = batches[r][s_ % nb], 0
+            while first < B:
+                first += sch.push_batch(hs[r], b, first)
+                if first < B:
+                    time.sleep(0.0002)  # ring full: the router would drop (router.rs:65); the bench wants every frame run
+
+    def run(steps):
+        th = [threading.Thread(target=produce, args=(r, steps)) for r in range(N)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        sch.flush()
+
+    def sync_all():
+        for d in range(1 if args.rehearse_one_gpu else N):
+            torch.cuda.synchronize(d)
+
+    run(Wm)
+    sync_all()
+    for m in models:
+        m.host_stats_reset()
+    before = sch.replica_stats(args.variant)
+    t0 = time.perf_counter()
+    run(K)
+    sync_all()
+    el = time.perf_counter() - t0
+    after = sch.replica_stats(args.variant)
+    frames = sum(a["frames"] - b_["frames"] for a, b_ in zip(after, before))
+    dets = sum(a["detections"] - b_["detections"] for a, b_ in zip(after, before))
+    assert frames == N * B * K, (frames, N * B * K)
+    hstats = [m.host_stats() for m in models]
+    flops_frame = 798315520 if args.variant == 640 else 200837120
+    out = {
+        "metric": "frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, Wd, Hd),
+        "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": Wm,
+        "ms_per_step": round(el / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "UltraFace-%d, one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct frames), batch=%d, seeded "
+                               "synthetic weights" % (args.variant, SW, SH, args.pool, B),
+                   "global_batch": N * B,
+                   "parallelism": "ONE process: ufd_create_replicas x%d (RCCL weight broadcast) + one ufd_sched over the replicas, "
+                                  "stream i -> GPU i mod %d" % (N, N),
+                   "timed_region": "host JPEG bytes pushed by one producer thread per stream -> detections delivered (ufd_sched_flush)",
+                   "stream_to_replica": where, "async_depth": args.depth, "host_threads_per_replica": host_threads,
+                   "replica_frames": [a["frames"] - b_["frames"] for a, b_ in zip(after, before)]},
+        "roofline": None, "cpu_baseline": None,
+        "whole_net_mfma_frac": round(frames / el * flops_frame / 1e12 / MFMA_F32_PEAK_TFLOPS / N, 4),
+        "detections_per_frame": round(dets / max(frames, 1), 2),
+        "host": {"per_replica": hstats, "usable_cpus": usable_cpus()},
+    }
+    if args.rehearse_one_gpu:
+        out["config"]["rehearsal"] = "all %d replicas are handles on cuda:0: a run of the one-process script path, NOT a measurement" % N
+    print(json.dumps(out), flush=True)
+    sch.close()
+    for m in models:
+        m.close()
+
+
 def main():
     args = parse_args()
+    if args.one_process:
+        if args.cpus > 0:
+            cur = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, cur[:max(1, min(args.cpus, len(cur)))])
+        return main_one_process(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,7 +348,7 @@ def main():
     host_threads = args.host_threads or max(2, min(32, usable_cpus() // world))
     model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights, priors=priors,
                               max_src=(SW, SH), host_threads=host_threads, profile=True, det_cap=256,
-                              host_entropy=not device_entropy)
+                              host_entropy=not device_entropy, extra_flags=nn.UFD_FLAG_SPIN_WAIT if args.spin_wait else 0)
     nb = max(1, args.pool // B)
     host_batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
     staged_batches = None

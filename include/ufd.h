@@ -90,6 +90,10 @@ typedef struct ufd_config {
  * box then stage their JPEG bytes and issue their launches from the socket next to their GPU (ufd_model_placement
  * reports what was resolved).  Nothing is pinned when the node is unknown or with this flag. */
 #define UFD_FLAG_NO_NUMA_PIN 256u
+/* ufd_wait with other batches of the handle still in flight sleeps between polls of the batch's event (a pipelined
+ * caller loses nothing by waking a few tens of microseconds late, and a spinning waiter would hold a CPU of the shared
+ * host); with this flag it always spins in the runtime.  A lone batch (the latency form) always spins. */
+#define UFD_FLAG_SPIN_WAIT 1024u
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
@@ -231,7 +235,8 @@ void* ufd_model_host_alloc(ufd_model* m, size_t bytes);
  *   - a batch leaves when it is full, when its oldest frame has waited max_wait_us, or at once when the model has
  *     nothing in flight (a lone frame never waits for company);
  *   - up to max_inflight batches per model in flight (the handle overlaps them on its three device contexts).
- * Results are delivered on a completion thread through on_result, per frame, in dispatch order per stream. */
+ * Results are delivered through on_result, per frame, in dispatch order per stream, on the completion thread of the
+ * stream's replica: with several replicas on_result is called from several threads at once (never for one stream). */
 #define UFD_E_FULL (-9) /* ufd_sched_push: the stream's ring is full, the frame was dropped (router.rs:65) */
 #define UFD_SCHED_NO_WAIT 0xFFFFFFFFu
 typedef struct ufd_sched ufd_sched;
@@ -247,15 +252,26 @@ typedef struct ufd_frame_result {
   size_t jpeg_len;
   double queue_ms;     /* push -> batch dispatched */
   double total_ms;     /* push -> this callback */
+  uint32_t replica;    /* replica of the variant (= position in ufd_sched_config.models_*) the frame ran on */
 } ufd_frame_result;
 typedef void (*ufd_result_fn)(void* user, const ufd_frame_result* result);
+#define UFD_SCHED_PLACE_ROUND_ROBIN 0u  /* stream i (in order of arrival, per variant) -> replica i mod n */
+#define UFD_SCHED_PLACE_LEAST_LOADED 1u /* -> the replica with the fewest live streams */
 typedef struct ufd_sched_config {
   uint32_t struct_size;      /* = sizeof(ufd_sched_config) */
-  ufd_model* model_320;      /* handles the scheduler submits to (not owned; either may be NULL) */
+  ufd_model* model_320;      /* handles the scheduler submits to (not owned; either may be NULL): the one-GPU shorthand */
   ufd_model* model_640;
+  /* The N-GPU form -- ONE scheduler over the handles ufd_create_replicas returns, one per GPU: a stream is placed on a
+   * replica when it is added and lives there; batches are formed per replica, each replica keeps up to max_inflight of
+   * them in flight and has its own completion thread.  A variant takes either its model_* or its models_* (not both). */
+  ufd_model* const* models_320;
+  uint32_t n_320;
+  ufd_model* const* models_640;
+  uint32_t n_640;
+  uint32_t placement;        /* UFD_SCHED_PLACE_* */
   uint32_t ring_slots;       /* frames a stream may have queued; 0 -> 10 (INFER_IMAGES_CHANNEL, lib.rs:37) */
   uint32_t max_wait_us;      /* 0 -> 2000; UFD_SCHED_NO_WAIT: a batch leaves as soon as the model has a slot for it */
-  uint32_t max_inflight;     /* per model; 0 -> 6 */
+  uint32_t max_inflight;     /* per replica; 0 -> 6 */
   uint32_t det_cap;          /* 0 -> 256 */
   uint32_t jpeg_bytes_per_frame; /* output reserved per annotated frame; 0 -> 524288 (larger streams: UFD_E_TRUNCATED) */
   ufd_result_fn on_result;
@@ -270,6 +286,7 @@ typedef struct ufd_stream_config {
   float label_height;
   uint32_t quality;      /* annotate; 0 -> 95 */
   uint32_t flags;        /* annotate: UFD_ANNOT_* */
+  uint32_t replica;      /* 0: placed by the scheduler (ufd_sched_config.placement); r + 1: replica r of the variant */
 } ufd_stream_config;
 typedef struct ufd_sched_stats {
   uint64_t pushed, dropped, delivered, batches, frames_in_batches;
@@ -288,9 +305,23 @@ int ufd_sched_debug_table(ufd_sched* s, uint32_t* live, uint32_t* allocated);
 /* router.rs:64-71: copies the JPEG into a free slot of the stream's ring (the caller's buffer is free on return);
  * UFD_E_FULL when there is none. */
 int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag);
+/* The same for `count` frames of one stream in one call (a router thread that drained several frames off its socket):
+ * they are taken in order while the ring has free slots, *accepted (optional) = how many were queued, the rest are
+ * dropped exactly as single pushes would be (UFD_E_FULL unless all were accepted).  tags may be NULL (all 0). */
+int ufd_sched_push_batch(ufd_sched* s, uint32_t stream, const uint8_t* const* jpegs, const size_t* lens, const uint64_t* tags,
+                         uint32_t count, uint32_t* accepted);
 /* Blocks until every frame pushed before the call has been delivered. */
 int ufd_sched_flush(ufd_sched* s);
 int ufd_sched_get_stats(ufd_sched* s, ufd_sched_stats* out);
+/* Where a stream lives, and what every replica of a variant has delivered (*n = replicas of the variant; min(*n, cap)
+ * entries written). */
+typedef struct ufd_sched_replica_stats {
+  uint32_t replica, streams, inflight, pad;
+  uint64_t batches, frames; /* delivered */
+  uint64_t detections;      /* found in the delivered frames */
+} ufd_sched_replica_stats;
+int ufd_sched_stream_replica(ufd_sched* s, uint32_t stream, uint32_t* replica);
+int ufd_sched_get_replica_stats(ufd_sched* s, uint32_t variant, ufd_sched_replica_stats* out, uint32_t cap, uint32_t* n);
 /* The batching rule alone (no GPU, no threads): queued[i] frames wait in stream i (streams of one batch class);
  * starting after stream `last`, one frame per stream per pass until max_batch: take[i] = frames taken from stream i.
  * Returns the batch size. */

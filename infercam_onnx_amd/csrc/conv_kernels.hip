@@ -1831,40 +1831,71 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
 // Dual launch (k_dual_*): conv group A = a merged cls/reg head pair on k_dwpw_mfma<1, 1, 2, SK>, conv B = one dw->pw block
 // on k_dwpw_coop<S, 4> (b_stride > 0) or one 1x1 conv on k_pw_mfma<1, 4, SK> (b_stride == 0).  False: this combination
 // of instances is not compiled -- the caller issues the two launches one after the other.
-bool launch_conv_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride, hipStream_t s) {
+namespace {
+struct DualChoice {
+  void (*kernel)(DualArgs) = nullptr;
+  const char* label = nullptr;  // profile label: device function (as bench.py's KERNEL_FUNCS maps it) + template instance
+  DualArgs q{};
+  unsigned blocks = 0;
+  size_t lds = 0;
+};
+bool choose_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride, DualChoice* out) {
   if (std::getenv("UFD_NO_DUAL")) return false;
   if (na < 1 || na > 3 || a_stride != 1 || dwpw_uses_coop(a, na)) return false;
   const DwpwConfig ca = dwpw_config(a, na);
   if (!ca.deep) return false;
-  DualArgs q{};
-  q.a = ca.p;
-  q.ax = (int)ca.gx, q.ay = (int)ca.gy;
+  DualChoice& c = *out;
+  c.q.a = ca.p;
+  c.q.ax = (int)ca.gx, c.q.ay = (int)ca.gy;
   const unsigned blocks_a = ca.gx * ca.gy;
-  void (*kernel)(DualArgs) = nullptr;
-  size_t lds = ca.lds;
+  c.lds = ca.lds;
   unsigned blocks_b = 0;
   if (b_stride > 0) {
     if (!dwpw_uses_coop(b, 1)) return false;
     const CoopConfig cb = coop_config(b);
     if (cb.ctw != 4) return false;
-    q.b = cb.p;
+    c.q.b = cb.p;
     blocks_b = cb.blocks;
-    lds = std::max(lds, cb.lds);
-    if (b_stride == 2) kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 2> : k_dual_dwpw_coop<1, 1, 2>;
-    else kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 1> : k_dual_dwpw_coop<1, 1, 1>;
+    c.lds = std::max(c.lds, cb.lds);
+    if (b_stride == 2) {
+      c.kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 2> : k_dual_dwpw_coop<1, 1, 2>;
+      c.label = ca.sk ? "conv_dual_coop<1, 4, 2>" : "conv_dual_coop<1, 1, 2>";
+    } else {
+      c.kernel = ca.sk ? k_dual_dwpw_coop<1, 4, 1> : k_dual_dwpw_coop<1, 1, 1>;
+      c.label = ca.sk ? "conv_dual_coop<1, 4, 1>" : "conv_dual_coop<1, 1, 1>";
+    }
   } else {
     if (b[0].in2 || b[0].res) return false;
     const PwConfig cb = pw_config(b, 1);
     if (cb.ksteps % 4 != 0) return false;
-    q.b = cb.p;
+    c.q.b = cb.p;
     blocks_b = cb.gx;
-    lds = std::max(lds, cb.lds);
-    if (cb.sk) kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 4> : k_dual_dwpw_pw<1, 1, 4>;
-    else kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 1> : k_dual_dwpw_pw<1, 1, 1>;
+    c.lds = std::max(c.lds, cb.lds);
+    if (cb.sk) {
+      c.kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 4> : k_dual_dwpw_pw<1, 1, 4>;
+      c.label = ca.sk ? "conv_dual_pw<1, 4, 4>" : "conv_dual_pw<1, 1, 4>";
+    } else {
+      c.kernel = ca.sk ? k_dual_dwpw_pw<1, 4, 1> : k_dual_dwpw_pw<1, 1, 1>;
+      c.label = ca.sk ? "conv_dual_pw<1, 4, 1>" : "conv_dual_pw<1, 1, 1>";
+    }
   }
-  if (lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-  hipLaunchKernelGGL(kernel, dim3(blocks_a + blocks_b), dim3(256), lds, s, q);
+  c.blocks = blocks_a + blocks_b;
   return true;
+}
+}  // namespace
+
+bool launch_conv_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride, hipStream_t s) {
+  DualChoice c;
+  if (!choose_dual(a, na, a_stride, b, b_stride, &c)) return false;
+  if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(c.kernel));
+  hipLaunchKernelGGL(c.kernel, dim3(c.blocks), dim3(256), c.lds, s, c.q);
+  return true;
+}
+
+// Profile label of the dual launch these arguments would get, or nullptr when launch_conv_dual would decline them.
+const char* conv_dual_instance(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride) {
+  DualChoice c;
+  return choose_dual(a, na, a_stride, b, b_stride, &c) ? c.label : nullptr;
 }
 
 const char* conv_dwpw_instance(const ConvArgs* args, int n, int stride) {

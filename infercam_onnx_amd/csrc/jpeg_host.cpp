@@ -58,6 +58,19 @@ struct HuffTable {
   int32_t delta[17];
   uint8_t sym[256];
 
+  // The checks of build() without building: a table that passes is `present` but must not be used for decoding.
+  bool check(const uint8_t* counts /*[16]*/, int nsym) {
+    int total = 0, code = 0;
+    for (int i = 0; i < 16; i++) total += counts[i];
+    if (total > 256 || total != nsym) return false;
+    for (int l = 1; l <= 16; l++) {
+      const int cnt = counts[l - 1];
+      if (code + cnt > (1 << l)) return false;
+      code = (code + cnt) << 1;
+    }
+    present = true;
+    return true;
+  }
   bool build(const uint8_t* counts /*[16]*/, const uint8_t* symbols, int nsym) {
     int total = 0;
     for (int i = 0; i < 16; i++) total += counts[i];
@@ -202,6 +215,9 @@ struct Decoder {
   JpegFrameDesc* d;
   int16_t* coef;
   GpuScanPlan* plan = nullptr;  // non-null: plan a device decode instead of decoding
+  bool build_luts = true;       // plan mode: false = check + hash the DHT segments, build no table
+  uint32_t key_len = 0;         // plan mode: DHT payload bytes collected into plan->key_bytes so far
+  bool key_overflow = false;
   HuffTable dc[4], ac[4];
   uint16_t qtab[4][64];
   bool qt_present[4] = {false, false, false, false};
@@ -230,7 +246,13 @@ struct Decoder {
       int total = 0;
       for (int i = 0; i < 16; i++) total += s[1 + i];
       if (total > 256 || len < 17 + total) return kJpegCorrupt;
-      if (!(tc ? ac[th] : dc[th]).build(s + 1, s + 17, total)) return kJpegCorrupt;
+      HuffTable& t = tc ? ac[th] : dc[th];
+      if (!(plan && !build_luts ? t.check(s + 1, total) : t.build(s + 1, s + 17, total))) return kJpegCorrupt;
+      if (plan) {
+        const uint32_t nb = 17 + (uint32_t)total;
+        if (key_len + nb + 8 > GpuScanPlan::kMaxKeyBytes) key_overflow = true;
+        else std::memcpy(plan->key_bytes + key_len, s, nb), key_len += nb;
+      }
       s += 17 + total;
       len -= 17 + total;
     }
@@ -281,6 +303,10 @@ struct Decoder {
     return kJpegOk;
   }
   void install_defaults() {
+    if (plan && !build_luts) {  // (which defaults get installed follows from the DHT bytes already in the key)
+      dc[0].present = dc[1].present = ac[0].present = ac[1].present = true;
+      return;
+    }
     if (!dc[0].present) dc[0].build(kStdDcLumCnt, kStdDcSym, 12);
     if (!dc[1].present) dc[1].build(kStdDcChrCnt, kStdDcSym, 12);
     if (!ac[0].present) ac[0].build(kStdAcLumCnt, kStdAcLumSym, 162);
@@ -512,10 +538,24 @@ struct Decoder {
         }
     }
     plan->scan.blocks_per_mcu = nb;
-    std::memset(plan->luts, 0, sizeof(plan->luts));
-    for (int i = 0; i < 2; i++) {
-      if (dc_ids[i] >= 0) export_lut(dc[dc_ids[i]], &plan->luts[i]);
-      if (ac_ids[i] >= 0) export_lut(ac[ac_ids[i]], &plan->luts[2 + i]);
+    if (build_luts) {
+      std::memset(plan->luts, 0, sizeof(plan->luts));
+      for (int i = 0; i < 2; i++) {
+        if (dc_ids[i] >= 0) export_lut(dc[dc_ids[i]], &plan->luts[i]);
+        if (ac_ids[i] >= 0) export_lut(ac[ac_ids[i]], &plan->luts[2 + i]);
+      }
+    }
+    // key of the table set: DHT payloads so far + the scan's selectors
+    plan->key_hash = 0, plan->key_len = 0;
+    if (!key_overflow) {
+      uint8_t* kb = plan->key_bytes;
+      kb[key_len++] = 0xFF;
+      kb[key_len++] = (uint8_t)sc.ns;
+      for (int i = 0; i < sc.ns; i++) kb[key_len++] = (uint8_t)((sc.td[i] << 4) | sc.ta[i]);
+      uint64_t h = 1469598103934665603ull;
+      for (uint32_t i = 0; i < key_len; i++) h = (h ^ kb[i]) * 1099511628211ull;
+      plan->key_hash = h ? h : 1;
+      plan->key_len = key_len;
     }
     const long n_iv = (total_mcus + ri - 1) / ri;
     if (n_iv > GpuScanPlan::kMaxIntervals) return kJpegNotEligible;
@@ -682,12 +722,14 @@ int jpeg_parse_header(const uint8_t* data, size_t len, JpegFrameDesc* d) {
   return dec.run(data, len, 0, true);
 }
 
-int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan) {
+int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan, bool build_luts) {
   Decoder dec;
   dec.d = d;
   dec.coef = nullptr;
   dec.plan = plan;
+  dec.build_luts = build_luts;
   plan->n_intervals = 0;
+  plan->key_hash = 0, plan->key_len = 0;
   return dec.run(data, len, 0, false);
 }
 

@@ -71,7 +71,14 @@ struct HuffInterval {
 
 struct GpuScanPlan {
   HuffScan scan;
-  HuffLut luts[4];
+  HuffLut luts[4];   // (only with build_luts)
+  // What determines `luts`: the payload of every DHT segment in front of the scan, in stream order, then the scan's
+  // component count and table selectors.  A camera stream repeats the same bytes in every frame, so the caller keeps
+  // the table sets it has seen keyed by them and asks for the tables to be built only for a key it has not seen.
+  static constexpr uint32_t kMaxKeyBytes = 1200;  // (the four Annex-K tables: 416 + 7 bytes)
+  uint64_t key_hash;         // FNV-1a of key_bytes; 0 = no key (DHT payload longer than kMaxKeyBytes)
+  uint32_t key_len;
+  uint8_t key_bytes[kMaxKeyBytes];
   static constexpr int kMaxIntervals = 1024;
   uint32_t n_intervals;
   HuffInterval iv[kMaxIntervals];
@@ -80,6 +87,8 @@ struct GpuScanPlan {
 // Header + marker scan only (no entropy decoding): fills the frame geometry and the interval
 // list for the device decoder.  kJpegNotEligible when the stream is not a single interleaved
 // baseline scan with restart intervals (the caller then decodes on the host).
-int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan);
+// build_luts = false: the DHT segments are checked (structure, code space) and hashed into the plan's key but no lookup
+// table is built -- about a quarter of the work; the result code is the same as with build_luts = true.
+int jpeg_plan_gpu_scan(const uint8_t* data, size_t len, JpegFrameDesc* d, GpuScanPlan* plan, bool build_luts = true);
 
 }  // namespace ufd

@@ -176,6 +176,7 @@ void launch_conv_dwpw_mfma(const ConvArgs* a, int n, int stride, hipStream_t s);
 // kernel instances is not compiled (the caller then issues the two launches one after the other).
 bool launch_conv_dual(const ConvArgs* a, int n_a, int a_stride, const ConvArgs* b, int b_stride, hipStream_t s);
 // Template arguments of the kernel instance those launchers pick, as rocprofv3 prints them ("<16, 1, true>"): profiling labels.
+const char* conv_dual_instance(const ConvArgs* a, int n_a, int a_stride, const ConvArgs* b, int b_stride);
 const char* conv_pointwise_instance(const ConvArgs* a, int n);
 const char* conv_dwpw_instance(const ConvArgs* a, int n, int stride);
 const char* conv_dwpw2_instance(const ConvArgs& first, const ConvArgs& second);

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include <pthread.h>
+#include <time.h>
 #include <sched.h>
 
 #include <fstream>
@@ -108,6 +109,7 @@ struct ProfEntry {
 struct Slot {
   bool busy = false;
   bool waiting = false;  // a ufd_wait is finishing this slot outside the handle lock (guarded by ufd_model::mu)
+  bool relaxed_wait = false;  // ufd_wait found other batches in flight behind this one: sleep between polls instead of spinning
   uint32_t ticket = 0, count = 0, cap = 0;
   JpegFrameDesc* h_descs = nullptr;
   int16_t* h_coef = nullptr;
@@ -291,8 +293,20 @@ struct ufd_model {
   struct LutMeta {
     uint64_t hash = 0, last_use = 0;  // content hash; plan sequence number of the last batch that used the set
     uint32_t pins = 0;                // staged batches holding the set
+    uint32_t gen = 0;                 // bumped when the slot gets another set (stale key-cache entries then miss)
   };
   std::vector<LutMeta> lut_meta;
+  // Front cache of lut_sets keyed by what DETERMINES a table set -- the frame's DHT payload bytes + scan selectors
+  // (GpuScanPlan::key_bytes): a camera stream repeats them in every frame, and a hit means the frame's lookup tables
+  // are never built on the host at all (jpeg_plan_gpu_scan(build_luts = false), a quarter of the planning work).
+  struct LutKey {
+    uint64_t hash = 0;
+    std::vector<uint8_t> bytes;
+    int set = -1;
+    uint32_t gen = 0;
+  };
+  std::vector<LutKey> lut_keys;  // <= 2 * kMaxLutSets entries, replaced round-robin
+  size_t lut_key_next = 0;
   uint64_t plan_seq = 0;
   static constexpr size_t kMaxTapSets = 32;  // resize-tap tables kept (one per distinct source size)
   std::map<std::pair<int, int>, uint64_t> taps_used;
@@ -1113,14 +1127,14 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
     const Layer& R = m->layers[L.rider];
     int r_stride = 1;
     const ConvArgs rb = layer_args(m, L.rider, f0, count, &r_stride);
-    bool done;
-    {
-      ProfScope ps(m, std::string("conv_dual:") + names + "|" + R.spec.name, bytes + R.bytes_per_frame * count + R.weight_bytes,
+    const int rb_stride = R.kind == kKindDwPw ? r_stride : 0;
+    // (labelled with the device function and its template instance, like every other launch: "conv_dual_coop<1, 1, 2>")
+    if (const char* label = conv_dual_instance(args, n, dw_stride, &rb, rb_stride)) {
+      ProfScope ps(m, std::string(label) + ":" + names + "|" + R.spec.name, bytes + R.bytes_per_frame * count + R.weight_bytes,
                    flops + R.flops_per_frame * count, st);
-      done = launch_conv_dual(args, n, dw_stride, &rb, R.kind == kKindDwPw ? r_stride : 0, st);
-      if (!done) ps.cancel();
+      if (launch_conv_dual(args, n, dw_stride, &rb, rb_stride, st)) return;
+      ps.cancel();
     }
-    if (done) return;
   }
   const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n) : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : "");
   {
@@ -1289,7 +1303,20 @@ int finish_slot(ufd_model* m, Slot& s, bool locked = true) {
   }
   {
     const uint64_t t0 = now_ns();
-    HIPC(m, hipEventSynchronize(s.done));
+    if (s.relaxed_wait) {
+      // A pipelined caller (other batches of the handle are queued behind this one): the GPU has work whatever happens
+      // here, so waking up some tens of microseconds after the event costs no throughput -- and a waiter spinning inside
+      // hipEventSynchronize would keep one CPU of a host that eight ranks share busy for nothing.
+      for (;;) {
+        const hipError_t q = hipEventQuery(s.done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return m->fail(UFD_E_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        timespec ts{0, 20000};
+        nanosleep(&ts, nullptr);
+      }
+    } else {
+      HIPC(m, hipEventSynchronize(s.done));  // one batch at a time: the latency form, the runtime spins on the signal
+    }
     m->ns_wait.fetch_add(now_ns() - t0, std::memory_order_relaxed);
   }
   span_fold(m, s);
@@ -1341,6 +1368,7 @@ Slot* find_free_slot(ufd_model* m) {
       s.annot = false, s.annot_ran = false;
       s.state = 0;
       s.span_idx = -1;
+      s.relaxed_wait = false;
       return &s;
     }
   return nullptr;
@@ -1396,6 +1424,7 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4], uint64_t seq) {
   }
   ufd_model::LutMeta meta;
   meta.hash = h, meta.last_use = seq;
+  if (idx < m->lut_meta.size()) meta.gen = m->lut_meta[idx].gen + 1;
   if (idx == m->lut_sets.size()) {
     m->lut_sets.push_back(set);
     m->lut_meta.push_back(meta);
@@ -1404,6 +1433,38 @@ int lut_set_for(ufd_model* m, const HuffLut (&luts)[4], uint64_t seq) {
     m->lut_meta[idx] = meta;
   }
   return (int)idx;
+}
+
+// The table set of a frame planned WITHOUT its lookup tables, by the key of its DHT bytes: index in d_sync_luts, or -1 when
+// this key has not been seen (or its set has been evicted since).
+int lut_set_by_key(ufd_model* m, const GpuScanPlan& p, uint64_t seq) {
+  if (!p.key_hash) return -1;
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  for (const auto& k : m->lut_keys) {
+    if (k.hash != p.key_hash || k.bytes.size() != p.key_len || std::memcmp(k.bytes.data(), p.key_bytes, p.key_len)) continue;
+    if (k.set < 0 || (size_t)k.set >= m->lut_meta.size() || m->lut_meta[k.set].gen != k.gen) return -1;
+    m->lut_meta[k.set].last_use = seq;
+    return k.set;
+  }
+  return -1;
+}
+
+void remember_lut_key(ufd_model* m, const GpuScanPlan& p, int set) {
+  if (!p.key_hash || set < 0) return;
+  std::lock_guard<std::mutex> lk(m->shared_mu);
+  ufd_model::LutKey k;
+  k.hash = p.key_hash, k.bytes.assign(p.key_bytes, p.key_bytes + p.key_len), k.set = set, k.gen = m->lut_meta[set].gen;
+  for (auto& e : m->lut_keys)
+    if (e.hash == k.hash && e.bytes == k.bytes) {
+      e = std::move(k);
+      return;
+    }
+  if (m->lut_keys.size() < 2 * (size_t)ufd_model::kMaxLutSets) {
+    m->lut_keys.push_back(std::move(k));
+  } else {
+    m->lut_keys[m->lut_key_next] = std::move(k);
+    m->lut_key_next = (m->lut_key_next + 1) % m->lut_keys.size();
+  }
 }
 
 // staged batches keep their table sets resident (ufd_stage_jpeg_batch / ufd_staged_free)
@@ -1424,7 +1485,8 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   const uint64_t t_plan0 = now_ns();
   tl_pool->parallel_for(count, [&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
-    int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i]) : kJpegCorrupt;
+    // (no lookup tables yet: frames of a camera stream share their DHT bytes, found below by key)
+    int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i], /*build_luts=*/false) : kJpegCorrupt;
     if (st == kJpegOk && ((uint32_t)d->width > m->max_w || (uint32_t)d->height > m->max_h)) st = UFD_E_TOO_LARGE;
     if (st == kJpegOk && (lens[i] + 64 > m->blob_stride || d->coef_total > m->coef_stride)) st = kJpegNotEligible;
     s.st[i] = st;
@@ -1449,8 +1511,14 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   for (uint32_t i = 0; i < count; i++) {
     std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
     if (s.st[i] != kJpegOk) continue;
-    const int set = lut_set_for(m, s.plans[i].luts, seq);
-    if (set < 0) return p;
+    int set = lut_set_by_key(m, s.plans[i], seq);
+    if (set < 0) {  // first frame with these tables (once per camera stream): build them, upload the set, remember the key
+      JpegFrameDesc again;
+      if (jpeg_plan_gpu_scan(jpegs[i], lens[i], &again, &s.plans[i], /*build_luts=*/true) != kJpegOk) return p;
+      set = lut_set_for(m, s.plans[i].luts, seq);
+      if (set < 0) return p;
+      remember_lut_key(m, s.plans[i], set);
+    }
     HuffScan sc = s.plans[i].scan;
     sc.lut_base = (uint32_t)set * 4;
     sc.seg_base = sc.nseg = sc.sub_bytes = sc.nsub = sc.pad = 0;
@@ -2528,9 +2596,13 @@ void* ufd_host_alloc(size_t bytes) {
   return p;
 }
 void* ufd_model_host_alloc(ufd_model* m, size_t bytes) {
-  if (!m || hipSetDevice(m->cfg.device_id) != hipSuccess) return nullptr;
+  if (!m) return nullptr;
+  int saved = -1;  // the caller's current device is put back (the scheduler calls this on its caller's thread)
+  if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+  if (hipSetDevice(m->cfg.device_id) != hipSuccess) return nullptr;
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) p = nullptr;
+  if (saved >= 0 && saved != m->cfg.device_id) (void)hipSetDevice(saved);
   return p;
 }
 void ufd_host_free(void* p) {
@@ -2603,6 +2675,9 @@ int ufd_wait(ufd_model* m, uint32_t ticket) {
     if (!s) return m->fail(UFD_E_STATE, "unknown ticket");
     if (s->waiting) return m->fail(UFD_E_STATE, "another thread is already waiting for this ticket");
     s->waiting = true;
+    uint32_t inflight = 0;
+    for (auto& c : m->slots) inflight += c.busy ? 1u : 0u;
+    s->relaxed_wait = inflight > 1 && !(m->cfg.flags & UFD_FLAG_SPIN_WAIT);
   }
   // not holding the handle lock while the worker and the GPU finish: other threads may submit
   {

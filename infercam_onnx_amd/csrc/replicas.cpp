@@ -54,12 +54,16 @@ Rccl* load_rccl() {
       if (slash != std::string::npos) names.push_back(hip.substr(0, slash) + "/librccl.so.1");
     }
     names.insert(names.end(), {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"});
+    std::string last_error;
     for (const std::string& name : names) {
       r.so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (r.so) break;
+      // (dlerror() hands its message out ONCE and clears it: read it once, right behind the failed dlopen)
+      const char* e = dlerror();
+      if (e) last_error = e;
     }
     if (!r.so) {
-      r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+      r.why = "cannot load librccl: " + (last_error.empty() ? std::string("not found") : last_error);
       return;
     }
     auto sym = [&](const char* n) {
@@ -109,6 +113,16 @@ int replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_m
       set_create_error("ufd_create_replicas: device id " + std::to_string(device_ids[i]) + " out of range (" + std::to_string(ndev) + " devices)");
       return UFD_E_ARG;
     }
+  // the caller's current device is left as it was found (every step below selects the device it works on)
+  struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+      if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+    }
+    ~DeviceGuard() {
+      if (saved >= 0) (void)hipSetDevice(saved);
+    }
+  } device_guard;
   Rccl* r = load_rccl();
   if (!r->why.empty()) {
     set_create_error(r->why);
@@ -166,7 +180,8 @@ int replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_m
     ok = hip_ok(hipSetDevice(devs[i]), "hipSetDevice") && hip_ok(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking), "hipStreamCreate");
   if (ok) {
     size_t wf0 = 0, pf0 = 0;
-    ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
+    const bool group_open = nccl_ok(r->GroupStart(), "ncclGroupStart");
+    ok = group_open;
     for (uint32_t i = 0; ok && i < n; i++) {
       float *dw = nullptr, *dp = nullptr;
       size_t wf = 0, pf = 0;
@@ -181,7 +196,7 @@ int replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_m
            nccl_ok(r->Broadcast(dw, dw, wf, ncclFloat, 0, comms[i], streams[i]), "ncclBroadcast(weights)") &&
            nccl_ok(r->Broadcast(dp, dp, pf, ncclFloat, 0, comms[i], streams[i]), "ncclBroadcast(priors)");
     }
-    const bool ended = nccl_ok(r->GroupEnd(), "ncclGroupEnd");
+    const bool ended = !group_open || nccl_ok(r->GroupEnd(), "ncclGroupEnd");  // (only a group that was opened is closed)
     ok = ok && ended;
     for (uint32_t i = 0; i < n; i++)
       if (streams[i]) ok = hip_ok(hipSetDevice(devs[i]), "hipSetDevice") && hip_ok(hipStreamSynchronize(streams[i]), "hipStreamSynchronize") && ok;

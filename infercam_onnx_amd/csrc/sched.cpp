@@ -4,7 +4,11 @@
 //   INFER_IMAGES_CHANNEL: StaticChannel<StaticImage, 10>                     infer_server/src/lib.rs:32-37
 //   Inferer::run: one task, one fixed model, one slot at a time              infer_server/src/inferer.rs:23,29-50
 // with per-stream rings, per-stream model variant / output kind, round-robin batch formation under a deadline, and
-// several batches in flight per model.  Pure host code over the public entry points of ufd.h (no HIP calls here).
+// several batches in flight per model.  ONE scheduler serves every GPU of the node: each variant may have several
+// replicas (the handles ufd_create_replicas returns, one per GPU); a stream is placed on one replica when it is added
+// (stream i -> replica i mod n, or the least loaded one) and stays there, batches are formed per (replica, output kind),
+// and every replica has its own completion thread -- a slow GPU never holds back another one's results.
+// Pure host code over the public entry points of ufd.h (no HIP calls here).
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -32,6 +36,7 @@ struct Stream {
   ufd_stream_config cfg{};
   bool alive = false;
   int klass = -1;
+  uint32_t replica = 0;  // index (within its variant) of the replica the stream lives on
   std::deque<Frame*> queued;   // waiting for a batch, oldest first
   std::vector<Frame*> free_;   // ring slots not in use
   std::vector<std::unique_ptr<Frame>> slots;
@@ -41,13 +46,29 @@ struct Stream {
 
 // A stream handle = table index (low kIndexBits) | generation of that table entry: an index is reused once its stream has
 // been removed and has drained, and a stale handle of the old stream then fails instead of reaching the new one.
-constexpr uint32_t kIndexBits = 20, kIndexMask = (1u << kIndexBits) - 1;
+// (16 + 16 bits, indices reused first-in first-out: a stale handle can only alias a newer stream after 65 536 reuses of ONE
+// index, which the FIFO spreads over the whole free list)
+constexpr uint32_t kIndexBits = 16, kIndexMask = (1u << kIndexBits) - 1;
 
-// Streams that can share a batch: same model and same kind of output.
+struct Batch;
+
+// One handle = one GPU's replica of one variant: its batches in flight (dispatch order) and its completion thread.
+struct Replica {
+  ufd_model* model = nullptr;
+  uint32_t variant = 0, index = 0, max_batch = 0;
+  uint32_t inflight = 0;      // batches dispatched and not yet delivered
+  uint32_t streams = 0;       // live streams placed here
+  uint64_t batches = 0, frames = 0, detections = 0;  // delivered
+  std::deque<Batch*> q;
+  std::condition_variable cv;  // (waits on ufd_sched::mu)
+  std::thread completer;
+};
+
+// Streams that can share a batch: same replica (model + GPU) and same kind of output.
 struct Klass {
   uint32_t variant = 0, annotate = 0, quality = 95, flags = 0;
   float label_w = 0, label_h = 0;
-  ufd_model* model = nullptr;
+  Replica* rep = nullptr;
   std::vector<uint32_t> streams;
   uint32_t last = 0;  // position (in streams) of the stream served last
 };
@@ -73,22 +94,22 @@ struct Batch {
 
 struct ufd_sched {
   ufd_sched_config cfg{};
-  uint32_t max_batch[2] = {0, 0};
+  uint32_t max_batch[2] = {0, 0};  // largest max_batch over the replicas of each variant (pinned-output sizing)
+  std::vector<std::unique_ptr<Replica>> replicas[2];  // [variant index][replica]
+  uint64_t placed[2] = {0, 0};     // streams ever added per variant (round-robin placement)
   std::mutex mu;
-  std::condition_variable cv_dispatch, cv_complete, cv_flush;
+  std::condition_variable cv_dispatch, cv_flush;
   // stream table: entry i is a live (or draining) stream, or null with i on free_ids.  Always accessed with the lock held.
   std::vector<std::unique_ptr<Stream>> streams;
   std::vector<uint32_t> gen;       // generation of every table entry
-  std::vector<uint32_t> free_ids;  // reclaimed entries, reused by ufd_sched_add_stream
+  std::deque<uint32_t> free_ids;   // reclaimed entries, reused (oldest first) by ufd_sched_add_stream
   std::vector<Klass> klasses;
-  std::deque<Batch*> inflight;             // dispatch order
   std::vector<std::unique_ptr<Batch>> pool;
   std::vector<Batch*> free_batches;
-  uint32_t inflight_of[2] = {0, 0};
   bool stop = false, dispatcher_done = false;
-  ufd_sched_stats stats{};
-  uint64_t flush_target = 0;
-  std::thread dispatcher, completer;
+  ufd_sched_stats stats{};   // (stats.pushed is derived: accepted + dropped)
+  uint64_t accepted = 0;     // frames queued by ufd_sched_push (counted when they ARE queued, under the lock)
+  std::thread dispatcher;
 };
 
 extern "C" uint32_t ufd_sched_debug_plan(const uint32_t* queued, uint32_t n_streams, uint32_t last, uint32_t max_batch, uint32_t* take) {
@@ -113,8 +134,8 @@ int variant_index(uint32_t v) { return v == 320 ? 0 : (v == 640 ? 1 : -1); }
 // With the lock held: the next batch of class k if one should leave now, else nullptr; *wake = when to look again.
 Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point* wake) {
   Klass& kl = s->klasses[k];
-  const int vi = variant_index(kl.variant);
-  if (kl.streams.empty() || s->inflight_of[vi] >= s->cfg.max_inflight) return nullptr;
+  Replica& rep = *kl.rep;
+  if (kl.streams.empty() || rep.inflight >= s->cfg.max_inflight) return nullptr;
   std::vector<uint32_t> queued(kl.streams.size()), take(kl.streams.size());
   uint32_t waiting = 0;
   Clock::time_point oldest = Clock::time_point::max();
@@ -127,9 +148,9 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
   if (!waiting) return nullptr;
   const auto deadline = oldest + std::chrono::microseconds(s->cfg.max_wait_us);
   int why;
-  if (waiting >= s->max_batch[vi]) why = 0;
+  if (waiting >= rep.max_batch) why = 0;
   else if (now >= deadline) why = 1;
-  else if (s->inflight_of[vi] == 0) why = 2;  // the model is idle: a lone frame does not wait for company
+  else if (rep.inflight == 0) why = 2;  // the replica is idle: a lone frame does not wait for company
   else {
     *wake = std::min(*wake, deadline);
     return nullptr;
@@ -144,7 +165,7 @@ Batch* form_batch(ufd_sched* s, int k, Clock::time_point now, Clock::time_point*
     if ((s->free_batches[i]->jpeg_cap != 0) == (kl.annotate != 0)) pick = i;
   Batch* b = s->free_batches[pick];
   s->free_batches.erase(s->free_batches.begin() + (long)pick);
-  const uint32_t count = ufd_sched_debug_plan(queued.data(), (uint32_t)queued.size(), kl.last, s->max_batch[vi], take.data());
+  const uint32_t count = ufd_sched_debug_plan(queued.data(), (uint32_t)queued.size(), kl.last, rep.max_batch, take.data());
   b->klass = k, b->count = count, b->why = why;
   b->stream.clear(), b->stream_id.clear(), b->frame.clear(), b->ptrs.clear(), b->lens.clear();
   // frames in round-robin order too, so that a stream's frames keep their order and streams share the head of the batch
@@ -215,9 +236,9 @@ void dispatcher_main(ufd_sched* s) {
       Batch* b = form_batch(s, k, now, &wake);
       if (!b) continue;
       Klass& kl = s->klasses[k];
-      const int vi = variant_index(kl.variant);
+      Replica* rep = kl.rep;
       b->dispatched = now;
-      s->inflight_of[vi]++;
+      rep->inflight++;
       s->stats.batches++, s->stats.frames_in_batches += b->count;
       (b->why == 0 ? s->stats.sent_full : (b->why == 1 ? s->stats.sent_deadline : s->stats.sent_idle))++;
       // The batch is detached from the stream queues: submit WITHOUT the scheduler lock (ufd_submit_* takes the handle's
@@ -227,16 +248,22 @@ void dispatcher_main(ufd_sched* s) {
         ufd_model* model;
         uint32_t annotate, quality, flags;
         float label_w, label_h;
-      } kc = {kl.model, kl.annotate, kl.quality, kl.flags, kl.label_w, kl.label_h};
+      } kc = {rep->model, kl.annotate, kl.quality, kl.flags, kl.label_w, kl.label_h};
       const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * std::max(s->max_batch[0], s->max_batch[1]);
+      const bool grow = kc.annotate && b->jpeg_cap < need;
+      uint8_t* old_out = b->jpeg_out;
       lk.unlock();
+      if (grow) {
+        // (the batch's buffer fields are read by ufd_sched_add_stream under the lock: allocate into locals out here,
+        // publish under the lock)
+        if (old_out) ufd_host_free(old_out);
+        uint8_t* fresh = static_cast<uint8_t*>(ufd_model_host_alloc(kc.model, need));
+        lk.lock();
+        b->jpeg_out = fresh, b->jpeg_cap = fresh ? need : 0;
+        lk.unlock();
+      }
       int rc;
       if (kc.annotate) {
-        if (b->jpeg_cap < need) {
-          if (b->jpeg_out) ufd_host_free(b->jpeg_out);
-          b->jpeg_out = static_cast<uint8_t*>(ufd_model_host_alloc(kc.model, need));
-          b->jpeg_cap = b->jpeg_out ? need : 0;
-        }
         ufd_annotate a;
         std::memset(&a, 0, sizeof(a));
         a.struct_size = sizeof(a);
@@ -255,13 +282,11 @@ void dispatcher_main(ufd_sched* s) {
         b->ticket = 0;
       }
       lk.lock();
-      s->inflight.push_back(b);
+      rep->q.push_back(b);
+      rep->cv.notify_all();
       sent = true;
     }
-    if (sent) {
-      s->cv_complete.notify_all();
-      continue;
-    }
+    if (sent) continue;
     if (s->stop) {  // destroy: leave once everything queued has been dispatched
       bool empty = true;
       for (const auto& st : s->streams) empty = empty && (!st || st->queued.empty());
@@ -271,19 +296,21 @@ void dispatcher_main(ufd_sched* s) {
     else s->cv_dispatch.wait_until(lk, wake);
   }
   s->dispatcher_done = true;
-  s->cv_complete.notify_all();
+  for (auto& v : s->replicas)
+    for (auto& r : v) r->cv.notify_all();
 }
 
-void completer_main(ufd_sched* s) {
+// Completion thread of ONE replica: waits for its batches in dispatch order and hands the results out.
+void completer_main(ufd_sched* s, Replica* rep) {
   std::unique_lock<std::mutex> lk(s->mu);
   for (;;) {
-    s->cv_complete.wait(lk, [&] { return !s->inflight.empty() || s->dispatcher_done; });
-    if (s->inflight.empty()) break;  // the dispatcher has left and nothing is in flight
-    Batch* b = s->inflight.front();
+    rep->cv.wait(lk, [&] { return !rep->q.empty() || s->dispatcher_done; });
+    if (rep->q.empty()) break;  // the dispatcher has left and nothing is in flight here
+    Batch* b = rep->q.front();
     struct {
       ufd_model* model;
       uint32_t variant, annotate;
-    } kl = {s->klasses[b->klass].model, s->klasses[b->klass].variant, s->klasses[b->klass].annotate};
+    } kl = {rep->model, rep->variant, s->klasses[b->klass].annotate};
     lk.unlock();
     if (b->ticket) {
       const int rc = ufd_wait(kl.model, b->ticket);
@@ -300,6 +327,7 @@ void completer_main(ufd_sched* s) {
         r.tag = b->frame[i]->tag;
         r.status = b->status[i];
         r.variant = kl.variant;
+        r.replica = rep->index;
         const bool ok = r.status == UFD_OK || r.status == UFD_E_TRUNCATED;
         r.n = ok ? b->n[i] : 0;
         r.batch_fill = b->count;
@@ -311,8 +339,11 @@ void completer_main(ufd_sched* s) {
       }
     }
     lk.lock();
-    s->inflight.pop_front();
-    s->inflight_of[variant_index(kl.variant)]--;
+    rep->q.pop_front();
+    rep->inflight--;
+    rep->batches++, rep->frames += b->count;
+    for (uint32_t i = 0; i < b->count; i++)
+      if (b->status[i] == UFD_OK || b->status[i] == UFD_E_TRUNCATED) rep->detections += b->n[i];
     for (uint32_t i = 0; i < b->count; i++) {
       Stream& st = *s->streams[b->stream[i]];  // (alive or draining: an entry with frames in a batch is never reclaimed)
       st.free_.push_back(b->frame[i]);
@@ -332,7 +363,25 @@ extern "C" {
 
 int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(ufd_sched_config)) return UFD_E_ARG;
-  if (!cfg->model_320 && !cfg->model_640) return UFD_E_ARG;
+  // handles per variant: the replica arrays (one per GPU, ufd_create_replicas), or the single-handle shorthand
+  std::vector<ufd_model*> models[2];
+  const struct {
+    ufd_model* one;
+    ufd_model* const* many;
+    uint32_t n;
+  } src[2] = {{cfg->model_320, cfg->models_320, cfg->n_320}, {cfg->model_640, cfg->models_640, cfg->n_640}};
+  for (int i = 0; i < 2; i++) {
+    if (src[i].n > UFD_MAX_REPLICAS || (src[i].n && !src[i].many) || (src[i].n && src[i].one)) return UFD_E_ARG;
+    for (uint32_t r = 0; r < src[i].n; r++) {
+      if (!src[i].many[r]) return UFD_E_ARG;
+      for (ufd_model* seen : models[i])
+        if (seen == src[i].many[r]) return UFD_E_ARG;  // a handle listed twice
+      models[i].push_back(src[i].many[r]);
+    }
+    if (src[i].one) models[i].push_back(src[i].one);
+  }
+  if (models[0].empty() && models[1].empty()) return UFD_E_ARG;
+  if (cfg->placement != UFD_SCHED_PLACE_ROUND_ROBIN && cfg->placement != UFD_SCHED_PLACE_LEAST_LOADED) return UFD_E_ARG;
   std::unique_ptr<ufd_sched> s(new ufd_sched);
   s->cfg = *cfg;
   if (!s->cfg.ring_slots) s->cfg.ring_slots = 10;
@@ -342,17 +391,21 @@ int ufd_sched_create(const ufd_sched_config* cfg, ufd_sched** out) {
   s->cfg.max_inflight = std::min<uint32_t>(s->cfg.max_inflight, UFD_MAX_SLOTS);
   if (!s->cfg.det_cap) s->cfg.det_cap = 256;
   if (!s->cfg.jpeg_bytes_per_frame) s->cfg.jpeg_bytes_per_frame = 512 * 1024;
-  ufd_model* models[2] = {cfg->model_320, cfg->model_640};
   for (int i = 0; i < 2; i++) {
-    if (!models[i]) continue;
-    uint32_t w = 0, mb = 0;
-    if (ufd_model_info(models[i], &w, nullptr, nullptr) != UFD_OK || w != (i ? 640u : 320u)) return UFD_E_ARG;
-    if (ufd_model_limits(models[i], &mb, nullptr, nullptr) != UFD_OK || !mb) return UFD_E_ARG;
-    s->max_batch[i] = mb;
+    for (size_t r = 0; r < models[i].size(); r++) {
+      uint32_t w = 0, mb = 0;
+      if (ufd_model_info(models[i][r], &w, nullptr, nullptr) != UFD_OK || w != (i ? 640u : 320u)) return UFD_E_ARG;
+      if (ufd_model_limits(models[i][r], &mb, nullptr, nullptr) != UFD_OK || !mb) return UFD_E_ARG;
+      std::unique_ptr<Replica> rep(new Replica);
+      rep->model = models[i][r], rep->variant = i ? 640u : 320u, rep->index = (uint32_t)r, rep->max_batch = mb;
+      s->max_batch[i] = std::max(s->max_batch[i], mb);
+      s->replicas[i].push_back(std::move(rep));
+    }
   }
   ufd_sched* p = s.release();
   p->dispatcher = std::thread(dispatcher_main, p);
-  p->completer = std::thread(completer_main, p);
+  for (auto& v : p->replicas)
+    for (auto& r : v) r->completer = std::thread(completer_main, p, r.get());
   *out = p;
   return UFD_OK;
 }
@@ -365,8 +418,11 @@ void ufd_sched_destroy(ufd_sched* s) {
   }
   s->cv_dispatch.notify_all();
   if (s->dispatcher.joinable()) s->dispatcher.join();
-  s->cv_complete.notify_all();
-  if (s->completer.joinable()) s->completer.join();
+  for (auto& v : s->replicas)
+    for (auto& r : v) {
+      r->cv.notify_all();
+      if (r->completer.joinable()) r->completer.join();
+    }
   for (auto& b : s->pool)
     if (b->jpeg_out) ufd_host_free(b->jpeg_out);
   delete s;
@@ -375,23 +431,25 @@ void ufd_sched_destroy(ufd_sched* s) {
 int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* stream) {
   if (!s || !cfg || !stream || cfg->struct_size != sizeof(ufd_stream_config)) return UFD_E_ARG;
   const int vi = variant_index(cfg->variant);
-  if (vi < 0 || !(vi ? s->cfg.model_640 : s->cfg.model_320)) return UFD_E_ARG;
+  if (vi < 0 || s->replicas[vi].empty()) return UFD_E_ARG;
+  if (cfg->replica > s->replicas[vi].size()) return UFD_E_ARG;  // (r + 1 of a replica that does not exist)
   const uint32_t quality = cfg->quality ? cfg->quality : 95;
   if (cfg->annotate && (quality < 1 || quality > 100)) return UFD_E_ARG;
-  // Pinned output of the batches an annotate class can have in flight: allocated now, on the model's device and without
-  // the scheduler lock -- not by the dispatcher in the middle of the stream (a first-use hipHostMalloc of tens of MB
-  // used to stall every push behind it).
+  // Pinned output of the batches the annotate classes can have in flight (max_inflight per replica): allocated now and
+  // without the scheduler lock -- not by the dispatcher in the middle of the stream (a first-use hipHostMalloc of tens of
+  // MB used to stall every push behind it).  Portable memory (ufd_model_host_alloc): a batch object serves any replica.
   std::vector<std::unique_ptr<Batch>> fresh;
   if (cfg->annotate) {
     const size_t need = (size_t)s->cfg.jpeg_bytes_per_frame * std::max(s->max_batch[0], s->max_batch[1]);
-    uint32_t have = 0;
+    const size_t want = (size_t)s->cfg.max_inflight * s->replicas[vi].size();
+    size_t have = 0;
     {
       std::lock_guard<std::mutex> lk(s->mu);
       for (auto& b : s->pool)
         if (b->jpeg_cap >= need) have++;
     }
-    ufd_model* model = vi ? s->cfg.model_640 : s->cfg.model_320;
-    for (; have < s->cfg.max_inflight; have++) {
+    ufd_model* model = s->replicas[vi][0]->model;
+    for (; have < want; have++) {
       std::unique_ptr<Batch> b(new Batch);
       b->jpeg_out = static_cast<uint8_t*>(ufd_model_host_alloc(model, need));
       if (!b->jpeg_out) break;  // (the dispatcher tries again for the batch that needs it)
@@ -404,10 +462,25 @@ int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* s
     s->free_batches.push_back(b.get());
     s->pool.push_back(std::move(b));
   }
+  // placement (stream i -> GPU i mod G): the caller's choice, else round-robin in order of arrival, else the
+  // replica with the fewest live streams (ties: the lowest index)
+  auto& reps = s->replicas[vi];
+  uint32_t r;
+  if (cfg->replica) {
+    r = cfg->replica - 1;
+  } else if (s->cfg.placement == UFD_SCHED_PLACE_LEAST_LOADED) {
+    r = 0;
+    for (uint32_t i = 1; i < reps.size(); i++)
+      if (reps[i]->streams < reps[r]->streams) r = i;
+  } else {
+    r = (uint32_t)(s->placed[vi] % reps.size());
+  }
+  s->placed[vi]++;
+  Replica* rep = reps[r].get();
   int k = -1;
   for (size_t i = 0; i < s->klasses.size(); i++) {
     const Klass& c = s->klasses[i];
-    if (c.variant == cfg->variant && c.annotate == (cfg->annotate ? 1u : 0u) &&
+    if (c.rep == rep && c.annotate == (cfg->annotate ? 1u : 0u) &&
         (!cfg->annotate || (c.quality == quality && c.flags == cfg->flags && c.label_w == cfg->label_width && c.label_h == cfg->label_height)))
       k = (int)i;
   }
@@ -415,14 +488,14 @@ int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* s
     Klass c;
     c.variant = cfg->variant, c.annotate = cfg->annotate ? 1 : 0, c.quality = quality, c.flags = cfg->flags;
     c.label_w = cfg->label_width, c.label_h = cfg->label_height;
-    c.model = vi ? s->cfg.model_640 : s->cfg.model_320;
+    c.rep = rep;
     s->klasses.push_back(c);
     k = (int)s->klasses.size() - 1;
   }
   uint32_t idx;
   if (!s->free_ids.empty()) {
-    idx = s->free_ids.back();
-    s->free_ids.pop_back();
+    idx = s->free_ids.front();
+    s->free_ids.pop_front();
   } else {
     if (s->streams.size() > kIndexMask) return UFD_E_TOO_LARGE;
     idx = (uint32_t)s->streams.size();
@@ -431,11 +504,12 @@ int ufd_sched_add_stream(ufd_sched* s, const ufd_stream_config* cfg, uint32_t* s
   }
   s->streams[idx].reset(new Stream);
   Stream& st = *s->streams[idx];
-  st.cfg = *cfg, st.alive = true, st.klass = k;
+  st.cfg = *cfg, st.alive = true, st.klass = k, st.replica = r;
   for (uint32_t i = 0; i < s->cfg.ring_slots; i++) {
     st.slots.emplace_back(new Frame);
     st.free_.push_back(st.slots.back().get());
   }
+  rep->streams++;
   *stream = idx | (s->gen[idx] << kIndexBits);
   s->klasses[k].streams.push_back(idx);
   return UFD_OK;
@@ -447,6 +521,7 @@ int ufd_sched_remove_stream(ufd_sched* s, uint32_t stream) {
   const long idx = stream_index(s, stream);
   if (idx < 0 || !s->streams[idx]->alive) return UFD_E_ARG;
   s->streams[idx]->alive = false;  // frames already queued are still delivered; nothing new is accepted
+  s->klasses[s->streams[idx]->klass].rep->streams--;  // (placement counts live streams)
   reclaim_if_drained(s, (uint32_t)idx);  // (otherwise the completion thread reclaims it behind its last frame)
   return UFD_OK;
 }
@@ -460,7 +535,6 @@ int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t le
     idx = stream_index(s, stream);
     if (s->stop || idx < 0 || !s->streams[idx]->alive) return UFD_E_STATE;
     Stream& st = *s->streams[idx];
-    s->stats.pushed++;
     if (st.free_.empty()) {  // router.rs:65: `if let Ok(mut frame) = self.infer_tx.try_send_ref()` -- else the frame is dropped
       s->stats.dropped++;
       return UFD_E_FULL;
@@ -477,21 +551,66 @@ int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t le
     st.filling--;
     if (!st.alive || s->stop) {  // removed (or the scheduler stopped) during the copy: as if the push had come too late
       st.free_.push_back(f);
-      s->stats.pushed--;
       reclaim_if_drained(s, (uint32_t)idx);
-      return UFD_E_STATE;
+      return UFD_E_STATE;  // (never counted: a ufd_sched_flush that ran meanwhile does not wait for this frame)
     }
     f->pushed = Clock::now();
     st.queued.push_back(f);
+    s->accepted++;  // counted only now that the frame IS queued: ufd_sched_flush's target never includes a frame that is withdrawn
   }
   s->cv_dispatch.notify_all();
   return UFD_OK;
 }
 
+int ufd_sched_push_batch(ufd_sched* s, uint32_t stream, const uint8_t* const* jpegs, const size_t* lens, const uint64_t* tags,
+                         uint32_t count, uint32_t* accepted) {
+  if (accepted) *accepted = 0;
+  if (!s || !jpegs || !lens || !count) return UFD_E_ARG;
+  for (uint32_t i = 0; i < count; i++)
+    if (!jpegs[i] || !lens[i]) return UFD_E_ARG;
+  std::vector<Frame*> got;
+  long idx;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    idx = stream_index(s, stream);
+    if (s->stop || idx < 0 || !s->streams[idx]->alive) return UFD_E_STATE;
+    Stream& st = *s->streams[idx];
+    const uint32_t k = std::min<uint32_t>(count, (uint32_t)st.free_.size());
+    s->stats.dropped += count - k;  // router.rs:65, frame by frame: the ones that find no slot are dropped
+    if (!k) return UFD_E_FULL;
+    got.assign(st.free_.end() - k, st.free_.end());
+    st.free_.resize(st.free_.size() - k);
+    st.filling += k;
+  }
+  for (size_t i = 0; i < got.size(); i++) {
+    got[i]->jpeg.assign(jpegs[i], jpegs[i] + lens[i]);
+    got[i]->tag = tags ? tags[i] : 0;
+  }
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    Stream& st = *s->streams[idx];
+    st.filling -= (uint32_t)got.size();
+    if (!st.alive || s->stop) {
+      for (Frame* f : got) st.free_.push_back(f);
+      reclaim_if_drained(s, (uint32_t)idx);
+      return UFD_E_STATE;
+    }
+    const auto now = Clock::now();
+    for (Frame* f : got) {
+      f->pushed = now;
+      st.queued.push_back(f);
+    }
+    s->accepted += got.size();
+  }
+  s->cv_dispatch.notify_all();
+  if (accepted) *accepted = (uint32_t)got.size();
+  return got.size() == count ? UFD_OK : UFD_E_FULL;
+}
+
 int ufd_sched_flush(ufd_sched* s) {
   if (!s) return UFD_E_ARG;
   std::unique_lock<std::mutex> lk(s->mu);
-  const uint64_t target = s->stats.pushed - s->stats.dropped;
+  const uint64_t target = s->accepted;  // every frame a returned ufd_sched_push has queued
   s->cv_flush.wait(lk, [&] { return s->stats.delivered >= target; });
   return UFD_OK;
 }
@@ -510,6 +629,29 @@ int ufd_sched_get_stats(ufd_sched* s, ufd_sched_stats* out) {
   if (!s || !out) return UFD_E_ARG;
   std::lock_guard<std::mutex> lk(s->mu);
   *out = s->stats;
+  out->pushed = s->accepted + s->stats.dropped;
+  return UFD_OK;
+}
+
+int ufd_sched_stream_replica(ufd_sched* s, uint32_t stream, uint32_t* replica) {
+  if (!s || !replica) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  const long idx = stream_index(s, stream);
+  if (idx < 0) return UFD_E_ARG;
+  *replica = s->streams[idx]->replica;
+  return UFD_OK;
+}
+
+int ufd_sched_get_replica_stats(ufd_sched* s, uint32_t variant, ufd_sched_replica_stats* out, uint32_t cap, uint32_t* n) {
+  const int vi = variant_index(variant);
+  if (!s || vi < 0 || !n || (cap && !out)) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(s->mu);
+  *n = (uint32_t)s->replicas[vi].size();
+  for (uint32_t i = 0; i < *n && i < cap; i++) {
+    const Replica& r = *s->replicas[vi][i];
+    out[i].replica = r.index, out[i].streams = r.streams, out[i].inflight = r.inflight;
+    out[i].batches = r.batches, out[i].frames = r.frames, out[i].detections = r.detections;
+  }
   return UFD_OK;
 }
 

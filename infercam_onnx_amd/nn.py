@@ -21,6 +21,7 @@ UFD_E_DEVICE, UFD_E_WEIGHTS, UFD_E_STATE, UFD_E_TOO_LARGE = -5, -6, -7, -8
 UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_ENTROPY = 1, 2, 4, 8
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_FLAG_NO_NUMA_PIN = 256
+UFD_FLAG_SPIN_WAIT = 1024
 UFD_FLAG_NO_DUAL = 512
 UFD_MAX_REPLICAS = 64
 UFD_SCHED_NO_WAIT = 0xFFFFFFFF
@@ -58,14 +59,19 @@ class UfdFrameResult(ctypes.Structure):
     _fields_ = [("stream_id", ctypes.c_uint64), ("tag", ctypes.c_uint64), ("status", ctypes.c_int32), ("variant", ctypes.c_uint32),
                 ("n", ctypes.c_uint32), ("batch_fill", ctypes.c_uint32), ("dets", ctypes.POINTER(UfdDet)),
                 ("jpeg", ctypes.POINTER(ctypes.c_ubyte)), ("jpeg_len", ctypes.c_size_t), ("queue_ms", ctypes.c_double),
-                ("total_ms", ctypes.c_double)]
+                ("total_ms", ctypes.c_double), ("replica", ctypes.c_uint32)]
 
 
 UFD_RESULT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(UfdFrameResult))
 
 
+UFD_SCHED_PLACE_ROUND_ROBIN, UFD_SCHED_PLACE_LEAST_LOADED = 0, 1
+
+
 class UfdSchedConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("model_320", ctypes.c_void_p), ("model_640", ctypes.c_void_p),
+                ("models_320", ctypes.POINTER(ctypes.c_void_p)), ("n_320", ctypes.c_uint32),
+                ("models_640", ctypes.POINTER(ctypes.c_void_p)), ("n_640", ctypes.c_uint32), ("placement", ctypes.c_uint32),
                 ("ring_slots", ctypes.c_uint32), ("max_wait_us", ctypes.c_uint32), ("max_inflight", ctypes.c_uint32),
                 ("det_cap", ctypes.c_uint32), ("jpeg_bytes_per_frame", ctypes.c_uint32), ("on_result", UFD_RESULT_FN),
                 ("user", ctypes.c_void_p)]
@@ -74,7 +80,12 @@ class UfdSchedConfig(ctypes.Structure):
 class UfdStreamConfig(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("stream_id", ctypes.c_uint64), ("variant", ctypes.c_uint32),
                 ("annotate", ctypes.c_uint32), ("label_width", ctypes.c_float), ("label_height", ctypes.c_float),
-                ("quality", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+                ("quality", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("replica", ctypes.c_uint32)]
+
+
+class UfdSchedReplicaStats(ctypes.Structure):
+    _fields_ = [("replica", ctypes.c_uint32), ("streams", ctypes.c_uint32), ("inflight", ctypes.c_uint32), ("pad", ctypes.c_uint32),
+                ("batches", ctypes.c_uint64), ("frames", ctypes.c_uint64), ("detections", ctypes.c_uint64)]
 
 
 class UfdSchedStats(ctypes.Structure):
@@ -107,7 +118,8 @@ ABI_SYMBOLS = (
     "ufd_sched_create", "ufd_sched_destroy", "ufd_sched_add_stream", "ufd_sched_remove_stream", "ufd_sched_push",
     "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
     "ufd_create_replicas", "ufd_model_placement", "ufd_annotate_parity", "ufd_model_host_alloc", "ufd_sched_debug_table",
-    "ufd_host_stats_reset", "ufd_host_stats_read",
+    "ufd_host_stats_reset", "ufd_host_stats_read", "ufd_sched_stream_replica", "ufd_sched_get_replica_stats",
+    "ufd_sched_push_batch",
 )
 
 _lib = None
@@ -178,6 +190,9 @@ def load_library():
     L.ufd_sched_push.argtypes = [vp, u32, vp, sz, ctypes.c_uint64]
     L.ufd_sched_flush.argtypes = [vp]
     L.ufd_sched_get_stats.argtypes = [vp, ctypes.POINTER(UfdSchedStats)]
+    L.ufd_sched_push_batch.argtypes = [vp, u32, vp, vp, vp, u32, pu32]
+    L.ufd_sched_stream_replica.argtypes = [vp, u32, pu32]
+    L.ufd_sched_get_replica_stats.argtypes = [vp, u32, ctypes.POINTER(UfdSchedReplicaStats), u32, pu32]
     L.ufd_sched_debug_plan.argtypes = [pu32, u32, u32, u32, pu32]
     L.ufd_sched_debug_plan.restype = u32
     L.ufd_profile_reset.argtypes = [vp]
@@ -260,7 +275,7 @@ class UltrafaceModel(InferModel):
     def __init__(self, variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None,
                  weights_path=None, max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, det_cap=1024,
                  device_entropy=False, host_entropy=False, tap_layers=False, no_chain=False, no_rfb_sum=False,
-                 no_stem_fuse=False, no_numa_pin=False, no_dual=False, _handle=None):
+                 no_stem_fuse=False, no_numa_pin=False, no_dual=False, extra_flags=0, _handle=None):
         self._h = None
         self._lib = load_library()
         self.variant = variant
@@ -275,7 +290,7 @@ class UltrafaceModel(InferModel):
                                       priors=priors, weights_path=weights_path, max_src=max_src, host_threads=host_threads,
                                       keep_layers=keep_layers, profile=profile, device_entropy=device_entropy,
                                       host_entropy=host_entropy, tap_layers=tap_layers, no_chain=no_chain, no_rfb_sum=no_rfb_sum,
-                                      no_stem_fuse=no_stem_fuse, no_numa_pin=no_numa_pin, no_dual=no_dual)
+                                      no_stem_fuse=no_stem_fuse, no_numa_pin=no_numa_pin, no_dual=no_dual, extra_flags=extra_flags)
             h = ctypes.c_void_p()
             rc = self._lib.ufd_create(ctypes.byref(cfg), ctypes.byref(h))
             if rc != UFD_OK:
@@ -289,7 +304,8 @@ class UltrafaceModel(InferModel):
     @staticmethod
     def _config(variant, max_iou, min_confidence, *, device_id=0, max_batch=1, weights=None, priors=None, weights_path=None,
                 max_src=(0, 0), host_threads=0, keep_layers=False, profile=False, device_entropy=False, host_entropy=False,
-                tap_layers=False, no_chain=False, no_rfb_sum=False, no_stem_fuse=False, no_numa_pin=False, no_dual=False):
+                tap_layers=False, no_chain=False, no_rfb_sum=False, no_stem_fuse=False, no_numa_pin=False, no_dual=False,
+                extra_flags=0):
         """ufd_config of UltrafaceModel::new's arguments; returns (cfg, arrays the cfg points into)."""
         cfg = UfdConfig()
         cfg.struct_size = ctypes.sizeof(UfdConfig)
@@ -302,7 +318,7 @@ class UltrafaceModel(InferModel):
                      (UFD_FLAG_DEVICE_ENTROPY if device_entropy else 0) | (UFD_FLAG_HOST_ENTROPY if host_entropy else 0) |
                      (UFD_FLAG_TAP_LAYERS if tap_layers else 0) | (UFD_FLAG_NO_CHAIN if no_chain else 0) |
                      (UFD_FLAG_NO_RFB_SUM if no_rfb_sum else 0) | (UFD_FLAG_NO_STEM_FUSE if no_stem_fuse else 0) |
-                     (UFD_FLAG_NO_NUMA_PIN if no_numa_pin else 0) | (UFD_FLAG_NO_DUAL if no_dual else 0))
+                     (UFD_FLAG_NO_NUMA_PIN if no_numa_pin else 0) | (UFD_FLAG_NO_DUAL if no_dual else 0) | int(extra_flags))
         keep = []
         if weights is not None:
             w = np.ascontiguousarray(weights, np.float32).ravel()

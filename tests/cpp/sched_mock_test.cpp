@@ -5,7 +5,9 @@
 // detections derived from the JPEG bytes, so every delivered frame can be checked without a GPU:
 //   n = jpeg[0] % 4 detections, dets[k].conf = jpeg[1] / 255, x_tl = len / 1e6.
 // Scenarios: concurrent producers on their own streams, streams that come and go meanwhile (removal with frames queued /
-// in flight / being copied), stale handles, drop-on-full, flush, destroy with work queued.
+// in flight / being copied), stale handles, drop-on-full, flush, destroy with work queued; ufd_sched_flush racing pushes
+// and removals (a withdrawn push must not leave a flush waiting); ONE scheduler over eight mock replicas (round-robin and
+// least-loaded placement, pinned streams, per-replica completion threads delivering concurrently).
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -53,6 +55,7 @@ struct ufd_model {
   std::map<uint32_t, Job> jobs;
   uint32_t next = 1;
   std::atomic<uint64_t> frames{0};
+  uint32_t wait_us = 200;  // "the GPU": how long ufd_wait takes
 };
 
 extern "C" {
@@ -93,7 +96,7 @@ int ufd_wait(ufd_model* m, uint32_t ticket) {
     if (it == m->jobs.end()) return UFD_E_STATE;
     j = it->second;
   }
-  std::this_thread::sleep_for(std::chrono::microseconds(200));  // "the GPU"
+  std::this_thread::sleep_for(std::chrono::microseconds(m->wait_us));  // "the GPU"
   size_t off = 0;
   for (uint32_t i = 0; i < j.count; i++) {  // reads the borrowed JPEG bytes: a slot recycled too early is caught here
     const uint8_t* p = j.jpegs[i];
@@ -155,6 +158,201 @@ static std::vector<uint8_t> frame_bytes(uint64_t stream_id, uint64_t tag, size_t
   std::vector<uint8_t> v(len, 0x5A);
   v[0] = (uint8_t)(tag % 251), v[1] = (uint8_t)stream_id;
   return v;
+}
+
+// ufd_sched_flush called WHILE pushes race a removal: a push that is withdrawn (its stream was removed during the copy)
+// must not be part of any flush's target -- the advisor's round-3 finding: flush used to hang on exactly that frame.
+static void flush_races_withdrawn_pushes() {
+  ufd_model m;
+  m.width = 320, m.max_batch = 8, m.wait_us = 50;
+  Sink sink;
+  ufd_sched_config cfg{};
+  cfg.struct_size = sizeof(cfg);
+  cfg.model_320 = &m;
+  cfg.ring_slots = 8, cfg.max_wait_us = 200, cfg.max_inflight = 2, cfg.det_cap = 8;
+  cfg.on_result = on_result, cfg.user = &sink;
+  ufd_sched* s = nullptr;
+  CHECK(ufd_sched_create(&cfg, &s) == UFD_OK);
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> flushes{0};
+  std::thread flusher([&] {
+    while (!stop.load()) {
+      CHECK(ufd_sched_flush(s) == UFD_OK);  // must always return
+      flushes++;
+      std::this_thread::sleep_for(std::chrono::microseconds(5));  // (leave the lock to the pushers between two flushes)
+    }
+  });
+  uint64_t accepted = 0;
+  for (int rnd = 0; rnd < 400; rnd++) {
+    ufd_stream_config sc{};
+    sc.struct_size = sizeof(sc), sc.stream_id = (uint64_t)(rnd % 200), sc.variant = 320;
+    uint32_t hs = 0;
+    CHECK(ufd_sched_add_stream(s, &sc, &hs) == UFD_OK);
+    std::atomic<uint64_t> ok{0};
+    std::thread racer([&, hs] {
+      for (int t = 0; t < 4; t++) {
+        const auto f = frame_bytes(sc.stream_id, (uint64_t)(1000 * rnd + t), 65536);  // a copy long enough to be caught mid-way
+        if (ufd_sched_push(s, hs, f.data(), f.size(), (uint64_t)(1000 * rnd + t)) == UFD_OK) ok++;
+      }
+    });
+    if (rnd % 3) std::this_thread::sleep_for(std::chrono::microseconds(30 + rnd % 50));
+    CHECK(ufd_sched_remove_stream(s, hs) == UFD_OK);
+    racer.join();
+    accepted += ok.load();
+  }
+  CHECK(ufd_sched_flush(s) == UFD_OK);
+  stop = true;
+  flusher.join();
+  ufd_sched_stats st{};
+  CHECK(ufd_sched_get_stats(s, &st) == UFD_OK);
+  CHECK(st.delivered == accepted && st.pushed - st.dropped == accepted);
+  ufd_sched_destroy(s);
+  CHECK(sink.bad == 0 && sink.frames == accepted && flushes.load() > 0);
+  std::printf("flush race: %llu frames, %llu concurrent flushes returned\n", (unsigned long long)accepted, (unsigned long long)flushes.load());
+}
+
+// One scheduler over eight replicas (N4 and row (e) composed): placement, per-replica completion threads.
+struct ReplicaSink {
+  std::mutex mu;
+  std::map<uint64_t, std::vector<uint64_t>> tags;  // stream_id -> tags in delivery order
+  std::map<uint64_t, uint32_t> where;              // stream_id -> replica its frames came back from
+  uint64_t frames = 0, bad = 0;
+  std::atomic<int> inside{0}, max_inside{0};
+};
+static void on_replica_result(void* user, const ufd_frame_result* r) {
+  ReplicaSink* s = static_cast<ReplicaSink*>(user);
+  const int now = ++s->inside;
+  int prev = s->max_inside.load();
+  while (now > prev && !s->max_inside.compare_exchange_weak(prev, now)) {
+  }
+  std::this_thread::sleep_for(std::chrono::microseconds(20));  // (long enough for two completion threads to overlap)
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->tags[r->stream_id].push_back(r->tag);
+    auto it = s->where.find(r->stream_id);
+    if (it == s->where.end()) s->where[r->stream_id] = r->replica;
+    else if (it->second != r->replica) s->bad++;  // a stream never changes replica
+    const bool corrupt = (uint8_t)(r->tag % 251) == 0xEE;  // (the mock's "corrupt JPEG" byte)
+    if (r->status != (corrupt ? UFD_E_DECODE : UFD_OK) || r->variant != 640) s->bad++;
+    s->frames++;
+  }
+  --s->inside;
+}
+static void one_scheduler_over_replicas(uint32_t placement) {
+  constexpr int kRep = 8, kStreams = 20, kFrames = 300;
+  ufd_model reps[kRep];
+  ufd_model* handles[kRep];
+  for (int i = 0; i < kRep; i++) reps[i].width = 640, reps[i].max_batch = 4, reps[i].wait_us = 100 + 40 * (uint32_t)i, handles[i] = &reps[i];
+  ReplicaSink sink;
+  ufd_sched_config cfg{};
+  cfg.struct_size = sizeof(cfg);
+  cfg.models_640 = handles, cfg.n_640 = kRep, cfg.placement = placement;
+  cfg.ring_slots = 6, cfg.max_wait_us = 300, cfg.max_inflight = 3, cfg.det_cap = 8;
+  cfg.on_result = on_replica_result, cfg.user = &sink;
+  ufd_sched* s = nullptr;
+  // argument paths of the N-GPU form
+  {
+    ufd_sched_config bad = cfg;
+    bad.model_640 = &reps[0];  // a variant takes its handle OR its array
+    CHECK(ufd_sched_create(&bad, &s) == UFD_E_ARG);
+    bad = cfg;
+    ufd_model* twice[2] = {&reps[0], &reps[0]};
+    bad.models_640 = twice, bad.n_640 = 2;
+    CHECK(ufd_sched_create(&bad, &s) == UFD_E_ARG);
+    bad = cfg;
+    bad.placement = 7;
+    CHECK(ufd_sched_create(&bad, &s) == UFD_E_ARG);
+  }
+  CHECK(ufd_sched_create(&cfg, &s) == UFD_OK);
+  std::vector<uint32_t> hs(kStreams);
+  std::vector<uint32_t> expect(kStreams);
+  uint32_t load[kRep] = {0};
+  for (int i = 0; i < kStreams; i++) {
+    ufd_stream_config sc{};
+    sc.struct_size = sizeof(sc), sc.stream_id = (uint64_t)(500 + i), sc.variant = 640;
+    sc.replica = i == 17 ? 5u + 1u : 0u;  // stream 17 is pinned to replica 5 by the caller
+    if (i == 3) {
+      ufd_stream_config oob = sc;
+      oob.replica = kRep + 1;
+      uint32_t dummy = 0;
+      CHECK(ufd_sched_add_stream(s, &oob, &dummy) == UFD_E_ARG);
+      oob.variant = 320;  // no replica of that variant
+      oob.replica = 0;
+      CHECK(ufd_sched_add_stream(s, &oob, &dummy) == UFD_E_ARG);
+    }
+    CHECK(ufd_sched_add_stream(s, &sc, &hs[i]) == UFD_OK);
+    uint32_t r = 99;
+    CHECK(ufd_sched_stream_replica(s, hs[i], &r) == UFD_OK && r < (uint32_t)kRep);
+    if (i == 17) {
+      CHECK(r == 5);
+    } else if (placement == UFD_SCHED_PLACE_ROUND_ROBIN) {
+      CHECK(r == (uint32_t)(i % kRep));  // stream i -> GPU i mod G
+    } else {
+      for (int q = 0; q < kRep; q++) CHECK(load[r] <= load[q]);  // the least loaded one at the time
+    }
+    load[r]++;
+    expect[i] = r;
+  }
+  std::vector<std::thread> producers;
+  std::vector<std::vector<uint64_t>> accepted(kStreams);
+  for (int i = 0; i < kStreams; i++)
+    producers.emplace_back([&, i] {
+      if (i % 2) {  // odd streams: three frames per call (ufd_sched_push_batch), taken in order while the ring has room
+        for (int t = 0; t < kFrames; t += 3) {
+          std::vector<uint8_t> f[3];
+          const uint8_t* ptrs[3];
+          size_t lens[3];
+          uint64_t tags[3];
+          for (int q = 0; q < 3; q++) {
+            f[q] = frame_bytes((uint64_t)(500 + i), (uint64_t)(t + q), 64 + (size_t)((t + q) % 100));
+            ptrs[q] = f[q].data(), lens[q] = f[q].size(), tags[q] = (uint64_t)(t + q);
+          }
+          uint32_t acc = 99;
+          const int rc = ufd_sched_push_batch(s, hs[i], ptrs, lens, tags, 3, &acc);
+          CHECK((rc == UFD_OK && acc == 3) || (rc == UFD_E_FULL && acc < 3));
+          for (uint32_t q = 0; q < acc; q++) accepted[i].push_back((uint64_t)(t + (int)q));
+          std::this_thread::sleep_for(std::chrono::microseconds(45));
+        }
+        return;
+      }
+      for (int t = 0; t < kFrames; t++) {
+        const auto f = frame_bytes((uint64_t)(500 + i), (uint64_t)t, 64 + (size_t)(t % 100));
+        const int rc = ufd_sched_push(s, hs[i], f.data(), f.size(), (uint64_t)t);
+        CHECK(rc == UFD_OK || rc == UFD_E_FULL);
+        if (rc == UFD_OK) accepted[i].push_back((uint64_t)t);
+        if (t % 4 == 3) std::this_thread::sleep_for(std::chrono::microseconds(60));
+      }
+    });
+  for (auto& t : producers) t.join();
+  CHECK(ufd_sched_flush(s) == UFD_OK);
+  ufd_sched_replica_stats rs[kRep];
+  uint32_t n = 0;
+  CHECK(ufd_sched_get_replica_stats(s, 640, rs, kRep, &n) == UFD_OK && n == (uint32_t)kRep);
+  CHECK(ufd_sched_get_replica_stats(s, 320, rs, kRep, &n) == UFD_OK && n == 0);
+  CHECK(ufd_sched_get_replica_stats(s, 640, rs, kRep, &n) == UFD_OK);
+  uint64_t total = 0, per_rep[kRep] = {0};
+  for (int i = 0; i < kStreams; i++) total += accepted[i].size(), per_rep[expect[i]] += accepted[i].size();
+  for (int r = 0; r < kRep; r++) {
+    CHECK(rs[r].replica == (uint32_t)r && rs[r].streams == load[r] && rs[r].inflight == 0);
+    CHECK(rs[r].frames == per_rep[r]);            // every frame ran on its stream's replica
+    CHECK(reps[r].frames.load() == per_rep[r]);   // ... as the mock handles saw it
+  }
+  {
+    std::lock_guard<std::mutex> lk(sink.mu);
+    CHECK(sink.bad == 0 && sink.frames == total);
+    for (int i = 0; i < kStreams; i++) {
+      CHECK(sink.tags[(uint64_t)(500 + i)] == accepted[i]);  // per stream: nothing lost, push order
+      CHECK(accepted[i].empty() || sink.where[(uint64_t)(500 + i)] == expect[i]);
+    }
+  }
+  // a removed stream gives its place back to the least-loaded count
+  CHECK(ufd_sched_remove_stream(s, hs[0]) == UFD_OK);
+  CHECK(ufd_sched_get_replica_stats(s, 640, rs, kRep, &n) == UFD_OK && rs[expect[0]].streams == load[expect[0]] - 1);
+  ufd_sched_destroy(s);
+  std::printf("replicas (%s): %llu frames over %d replicas, up to %d completion threads delivering at once\n",
+              placement == UFD_SCHED_PLACE_ROUND_ROBIN ? "round robin" : "least loaded", (unsigned long long)total, kRep,
+              sink.max_inside.load());
+  CHECK(sink.max_inside.load() >= 2);  // the replicas' completion threads do run concurrently
 }
 
 int main() {
@@ -256,5 +454,8 @@ int main() {
   CHECK(sink.bad == 0 && sink.tags[77].size() == 4);
   std::printf("ok: %llu frames delivered, %llu dropped on full rings, %d pushes refused behind a removal, table %u entries\n",
               (unsigned long long)sink.frames, (unsigned long long)st.dropped, refused.load(), allocated);
+  flush_races_withdrawn_pushes();
+  one_scheduler_over_replicas(UFD_SCHED_PLACE_ROUND_ROBIN);
+  one_scheduler_over_replicas(UFD_SCHED_PLACE_LEAST_LOADED);
   return 0;
 }

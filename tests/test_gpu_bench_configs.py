@@ -326,6 +326,15 @@ def test_bench_script_single_and_two_rank_rehearsal():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line["config"]
     assert len(line["config"]["ranks"]) == 2 and line["config"]["global_batch"] == 64
     assert "cpu_baseline" not in line  # N = 1 only
+    assert "host" in json.loads(r.stdout.strip().splitlines()[-1])  # every rank-0 line carries the host object
+
+    # C4's other form: ONE process, one scheduler over the replicas (two handles on cuda:0 here)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--pool", "64", "--rehearse-one-gpu"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["stream_to_replica"] == [0, 1] and line["config"]["replica_frames"] == [192, 192]
+    assert line["value"] > 1000 and line["detections_per_frame"] > 0 and "rehearsal" in line["config"]
 
 
 def test_rccl_backend_collectives_coexist_with_the_library():

@@ -139,6 +139,54 @@ def test_streams_of_both_variants_and_output_kinds(weights):
 
 
 @gpu
+def test_one_scheduler_over_two_replicas_matches_oracle(weights):
+    """N4 and row (e) composed (router.rs:64-71 + infer_server.rs:48-50 for a node): ONE scheduler over the handle array of
+    a variant.  On a one-GPU box the two replicas are two handles on the one device (what ufd_create_replicas returns has
+    one per GPU); five streams are placed stream i -> replica i mod 2, one is pinned by the caller; every frame comes back
+    from its stream's replica with the oracle's detections, in push order, and the per-replica counts add up."""
+    import oracle
+    from helpers import assert_dets_match, dets_array
+    from infercam_onnx_amd import nn, synth
+
+    pri = synth.gen_priors(640, 480)
+    reps = [nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=pri, max_batch=8,
+                              max_src=(640, 480), det_cap=256) for _ in range(2)]
+    try:
+        with scheduler.Scheduler(models_640=reps, ring_slots=16, max_wait_us=1000, det_cap=17640) as sch:
+            with pytest.raises(nn.UfdError):
+                sch.add_stream(1, 640, replica=2)  # there is no replica 2
+            hs = [sch.add_stream(2000 + i, 640) for i in range(5)] + [sch.add_stream(2005, 640, annotate=True, replica=1)]
+            where = [sch.stream_replica(h) for h in hs]
+            assert where == [0, 1, 0, 1, 0, 1], where
+            frames = {}
+            for k in range(10):
+                for i, h in enumerate(hs):
+                    j = synth.encode_jpeg(synth.synth_frame(60 + i, k, 640, 480))
+                    frames[(2000 + i, k)] = j
+                    while not sch.push(h, j, tag=k):
+                        time.sleep(0.0005)
+            sch.flush()
+            res = list(sch.results)
+            rs = sch.replica_stats(640)
+            assert sch.replica_stats(320) == []
+        assert len(res) == len(frames) == 60
+        assert [r["streams"] for r in rs] == [3, 3] and [r["frames"] for r in rs] == [30, 30] and all(r["inflight"] == 0 for r in rs)
+        by_stream = {}
+        for r in res:
+            by_stream.setdefault(r["stream_id"], []).append(r["tag"])
+            assert r["status"] == 0 and r["replica"] == where[r["stream_id"] - 2000]
+            j = frames[(r["stream_id"], r["tag"])]
+            assert_dets_match(dets_array(r["dets"]), oracle.infer_jpeg(j, 640, 480, weights, pri), what="sched over replicas")
+            if r["stream_id"] == 2005:
+                frame = oracle.draw_labels(oracle.jpeg_decode_rgb(j), dets_array(r["dets"]), 1280, 720)
+                assert r["jpeg"] == oracle.jpeg_encode_rgb(frame, 95)
+        assert all(tags == list(range(10)) for tags in by_stream.values())
+    finally:
+        for m in reps:
+            m.close()
+
+
+@gpu
 def test_full_ring_drops_the_new_frame_and_lone_frames_do_not_wait(weights):
     """router.rs:65: a frame that finds no free slot is dropped (push reports it); what was accepted is delivered in
     order.  A single frame pushed to an idle scheduler leaves at once in a batch of one."""

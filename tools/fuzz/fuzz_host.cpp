@@ -76,10 +76,22 @@ static void run_jpeg(const std::vector<uint8_t>& d) {
   std::memset(&d2, 0, sizeof(d2));
   const int st = jpeg_decode_coefficients(d.data(), d.size(), &d2, coef.data(), coef.size());
   (st == kJpegOk ? g_ok : g_rejected)++;
-  static GpuScanPlan plan;  // (large: not on the stack)
-  JpegFrameDesc d3;
+  static GpuScanPlan plan, light;  // (large: not on the stack)
+  JpegFrameDesc d3, d4;
   std::memset(&d3, 0, sizeof(d3));
-  (void)jpeg_plan_gpu_scan(d.data(), d.size(), &d3, &plan);
+  std::memset(&d4, 0, sizeof(d4));
+  const int full = jpeg_plan_gpu_scan(d.data(), d.size(), &d3, &plan);
+  // the check-and-hash form (no lookup tables built) must agree with the full one on everything but the tables
+  const int lite = jpeg_plan_gpu_scan(d.data(), d.size(), &d4, &light, /*build_luts=*/false);
+  bool same = full == lite;
+  if (same && full == kJpegOk)
+    same = !std::memcmp(&d3, &d4, sizeof(d3)) && !std::memcmp(&plan.scan, &light.scan, sizeof(plan.scan)) &&
+           plan.n_intervals == light.n_intervals && !std::memcmp(plan.iv, light.iv, sizeof(HuffInterval) * plan.n_intervals) &&
+           plan.key_hash == light.key_hash && plan.key_len == light.key_len && !std::memcmp(plan.key_bytes, light.key_bytes, plan.key_len);
+  if (!same) {
+    fprintf(stderr, "jpeg_plan_gpu_scan: build_luts=false disagrees with the full plan (rc %d vs %d)\n", lite, full);
+    abort();
+  }
 }
 
 int main(int argc, char** argv) {
