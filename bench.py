@@ -153,11 +153,64 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
     t1 = time.perf_counter()
     done, _ = oracle.infer_jpeg_many_threads(jpegs, 1 << 30, cores, W, H, weights, priors, 0.5, 0.5, budget_s=budget_s)
     el_all = time.perf_counter() - t1
+    try:
+        torch_1 = torch_cnn_baseline(min(budget_s, 6.0), W, H)
+    except Exception as e:  # (a second opinion: its absence must not take the line down)
+        torch_1 = {"error": repr(e)[:200]}
     return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d of the bench's JPEG frames, full path decode->NMS at %dx%d, 1 thread, %.1f s" % (n, W, H, el),
+            "torch_1thread": torch_1,
             "all_cores": {"value": round(done / el_all, 2), "unit": "frames/s", "cores": cores,
                           "sample": "%d frames, one worker thread per usable hardware thread (affinity mask / cgroup quota; "
                                     "the machine reports %d), %.1f s" % (done, os.cpu_count() or 1, el_all)}}
+
+
+def torch_cnn_baseline(budget_s, W=640, H=480):
+    """SURVEY 8(d)'s second opinion on the CPU side: the UltraFace-RFB forward ALONE (no JPEG decode, resize or NMS)
+    through torch.nn.functional.conv2d -- oneDNN's packed-GEMM convolutions, the class of kernel tract-linalg's would be --
+    on ONE thread (the reference runs tract's single-threaded SimplePlan inside its single Inferer task), BatchNorm folded
+    into the convolutions as the zoo file has it.  The module is the upstream network definition restated in
+    tools/ultraface_torch.py (test infrastructure); weights are seeded: a convolution's time does not depend on them."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ultraface_torch as ut
+
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+
+    def fold(mod):  # Conv2d followed by BatchNorm2d -> one Conv2d (what tract's declutter and the zoo export do)
+        for name, child in list(mod.named_children()):
+            if isinstance(child, ut.BasicConv) and child.bn is not None:
+                child.conv, child.bn = fuse_conv_bn_eval(child.conv, child.bn), None
+            elif isinstance(child, torch.nn.Sequential):
+                kids = list(child.children())
+                for i in range(len(kids) - 1):
+                    if isinstance(kids[i], torch.nn.Conv2d) and isinstance(kids[i + 1], torch.nn.BatchNorm2d):
+                        child[i] = fuse_conv_bn_eval(kids[i], kids[i + 1])
+                        child[i + 1] = torch.nn.Identity()
+            fold(child)
+
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        model = ut.build_seeded((W, H)).eval()
+        fold(model)
+        x = torch.randn(1, 3, H, W)
+        with torch.no_grad():
+            model(x)  # warm (oneDNN primitive creation)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                model(x)
+                n += 1
+                el = time.perf_counter() - t0
+                if el >= budget_s or n >= 400:
+                    break
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1,
+            "sample": "%d forwards of the UltraFace-RFB network alone at %dx%d (52 convolutions, BatchNorm folded, softmax + box "
+                      "decode), torch %s conv2d on 1 thread, %.1f s -- CNN only: the JPEG decode, resize and NMS of the full path "
+                      "are not in this figure" % (n, W, H, torch.__version__.split("+")[0], el)}
 
 
 def usable_cpus():

@@ -122,14 +122,20 @@ __device__ __forceinline__ void store_tiles(const ConvArgs& a, floatx16 (&acc)[C
 // XCD-aware block order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
 // (each with a private L2).  Blocks that read the same activation tile but produce different
 // 32-cout tiles get ids 8 apart inside a group of 8*cts ids, so they run on the same XCD close in
-// time and the second..cts-th read of the tile hits that XCD's L2.  Placement only changes speed.
+// time and the second..cts-th read of the tile hits that XCD's L2.  And every XCD gets a CONTIGUOUS range of pixel tiles
+// (round 4): neighbouring tiles of the kernels with a halo (depthwise windows, 3x3 rows) share input rows, and dealt
+// round-robin they sat on different XCDs, each fetching the shared rows from memory for itself -- rocprofv3 FETCH_SIZE
+// 1.4x (k_dwpw_mfma, 60x80 maps) to 2.1x (k_dwpw_coop, 30x40 maps) and 3.1x (the dilated 3x3 launch) of the input.
+// Grids are padded to 8 * ceil(tiles / 8) * cts blocks by the launchers.  Placement only changes speed.
 __device__ __forceinline__ bool remap_block(const ConvArgs& a, int bx, int* tile, int* ct) {
   const int per = 8 * a.cts;
   const int grp = bx / per, r = bx - grp * per;
   *ct = r >> 3;
-  *tile = grp * 8 + (r & 7);
+  *tile = (r & 7) * ((a.tiles + 7) >> 3) + grp;
   return *tile < a.tiles;
 }
+// The same for a grid along x that is a multiple of 8 blocks with no cout tiles: XCD x takes blocks [x * n/8, (x+1) * n/8).
+__device__ __forceinline__ int xcd_contiguous(int bx, int grid_x) { return (bx & 7) * (grid_x >> 3) + (bx >> 3); }
 
 // Bias of the block's cout tiles through LDS: the first 32 * NT threads place bias[co] (0 past cout) in the order the
 // accumulator rows want it -- [tile][half][16 rows] -- beside the weight tables, in front of the barrier those need anyway;
@@ -520,7 +526,7 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
     const int per = 8 * cgroups;
     const int grp = bx / per, r = bx - grp * per;
     cgrp = r >> 3;
-    tgrp = grp * 8 + (r & 7);
+    tgrp = (r & 7) * ((a.tiles + 7) >> 3) + grp;  // a contiguous range of pixel tiles per XCD: remap_block
   }
   if (tgrp >= a.tiles) return;  // whole block, before any barrier
   const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
@@ -1164,7 +1170,10 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   extern __shared__ float s_w[];                    // packed weights when they fit (a.dbg = 1)
   // (a merged launch is sized for the widest halo among its convs: blocks past this conv's last tile leave, whole
   // blocks and before the barrier)
-  if ((long)blockIdx.x * 4 * NG - HL >= (long)a.B * ((a.oh * a.ow) >> 2)) return;
+  // (a contiguous range of tiles per XCD -- remap_block: the tiles above and below a tile share its input rows, three
+  // dilations deep in the RFB's merged launch; the grid is a multiple of 8 along x)
+  const int bx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  if ((long)bx * 4 * NG - HL >= (long)a.B * ((a.oh * a.ow) >> 2)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   const int cin4 = (a.cin + 3) >> 2;
@@ -1183,7 +1192,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   // offsets from one 32-bit base, below.)
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int total = a.B * gpf;
-  const int g = ((int)blockIdx.x * 4 + wave) * NG + j16 - HL;
+  const int g = (bx * 4 + wave) * NG + j16 - HL;
   const bool inrange = g >= 0 && g < total;
   const bool live = inrange && j16 >= HL && j16 < 16 - HL;
   const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
@@ -1640,7 +1649,8 @@ void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
     p.a[i].dbg = lds ? 1 : 0;  // weights staged in LDS
   }
   const size_t shmem = lds ? wbytes : 0;
-  auto grid = [&](int hl) { return dim3((unsigned)((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl))), (unsigned)n); };
+  // (a multiple of 8 blocks along x: the kernel gives every XCD a contiguous range of them)
+  auto grid = [&](int hl) { return dim3((unsigned)(((groups + 4L * (16 - 2 * hl) - 1) / (4L * (16 - 2 * hl)) + 7) / 8 * 8), (unsigned)n); };
   bool mixed = false;
   for (int i = 1; i < n; i++) mixed = mixed || args[i].dil != a.dil;
   if (mixed) {  // (stride 1, dilations <= 8: conv3x3_rows_supported)

@@ -50,6 +50,10 @@ for k in sorted(f, key=lambda k: -(f[k][1] * 2 + w[k][1])):
     out[k] = {"launches": n, "fetch_bytes_per_launch": fe, "write_bytes_per_launch": wr,
               "hbm_bytes_per_launch": fe + wr}
     print("%-22s %8d %14.2f %14.2f %14.2f" % (k, n, fe / 1e6, wr / 1e6, (fe + wr) / 1e6))
+print()
+for k in sorted(inst, key=lambda k: -inst[k]["hbm_bytes_per_launch"] * inst[k]["launches"]):
+    v = inst[k]
+    print("%-34s %6d fetch %8.1f MB  write %8.1f MB" % (k[:34], v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
 if len(sys.argv) > 3:
     json.dump({"note": "FETCH_SIZE x2 (gfx950 calibration), WRITE_SIZE exact, KiB units; separate --pmc passes",
                "kernels": out, "instances": inst}, open(sys.argv[3], "w"), indent=1)
