@@ -654,6 +654,13 @@ def main():
         except Exception:
             pass
 
+        sq, sq_ok = {}, False
+        try:  # rocprofv3 --pmc SQ passes summarised by tools/sq_table.py (tools/pmc_kernel.sh), stamped like the traffic
+            sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")))
+            sq_ok = sq.get("kernel_source_sha") == kernel_source_sha()
+        except Exception:
+            pass
+
         def roof_of(key, d):
             """Roofline figures of one kernel instance from its aggregated launches."""
             sec = d["ms"] * 1e-3
@@ -677,6 +684,11 @@ def main():
                     t = round(e["hbm_bytes_per_launch"])
             r["traffic"] = t
             r["traffic_ratio"] = round(t / (d["bytes"] / n), 3) if t and d["bytes"] else None
+            # matrix-pipe / vector-pipe busy shares and resident waves per SIMD of this instance ALONE on the GPU (SQ counters,
+            # one rocprofv3 --pmc pass per counter group at --depth 1; null when not collected for this build of the kernels)
+            e = sq.get("instances", {}).get(device_name(key)) if sq_ok else None
+            for f in ("mfma_busy", "valu_busy", "waves_per_simd", "wait_share"):
+                r[f] = e.get(f) if e else None
             return r
 
         roof = None
@@ -691,6 +703,9 @@ def main():
             roof["source"] = ("loaded pass: %d steps behind the timed region, %d batches in flight, every launch timed (HIP events on "
                               "the library's streams)" % (ROOF_STEPS, min(args.depth, nb))) if loaded else \
                              "timed region, every %d-th step sampled" % args.profile_every
+            roof["sq_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY at commit %s, same "
+                                 "kernel sources, kernels alone (tools/pmc_kernel.sh, tools/sq_table.py)" % sq.get("commit", "?")) if sq_ok else \
+                                "not collected for this build of the kernels"
             roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, FETCH x2 on gfx950) at commit %s, "
                                       "same kernel sources, per template instance" % pmc.get("commit", "?")) if pmc_ok else \
                                      "not measured for this build of the kernels (tools/collect_profiles.sh refreshes it)"

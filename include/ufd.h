@@ -162,7 +162,8 @@ int ufd_wait(ufd_model* m, uint32_t ticket);
  * normalisation, the network, NMS -- from those HBM buffers: no input crosses PCIe, only the
  * detections come back.  Same ticket / ufd_wait protocol and outputs as ufd_submit_jpeg_batch
  * (the reference has no such call: its ring slots are host Vec<u8>, lib.rs:32; this is the form a
- * capture card or NIC writing straight into GPU memory would use, and the one bench.py times).
+ * capture card or NIC writing straight into GPU memory would use; bench.py times the host-bytes form above by
+ * default and reports this one beside it, `--input hbm` / `config.hbm_resident_fps`).
  * A staged batch may be submitted any number of times; free it after its last ufd_wait. */
 typedef struct ufd_staged ufd_staged;
 int ufd_stage_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, ufd_staged** staged);

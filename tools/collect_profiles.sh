@@ -6,6 +6,7 @@ name=${1:-prof}
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+python3 -c "import bench; print(bench.kernel_source_sha())" > $out/source_sha.txt  # what THIS run measures (finish_profiles.py stamps with it)
 timeout 600 python3 bench.py --steps 80 --warmup 8 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-200
 cd /tmp && export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 """After tools/collect_profiles.sh <name> has run on the GPU box and gpurun merged gpurun_out/<name>/ back:
 copies the summaries the judge reads into profiles/<name>/ and refreshes profiles/pmc_traffic_latest.json, stamped
 with the commit and the hash of the kernel sources it was measured on (bench.py reports roofline.traffic only while
-that hash matches).  Usage: python tools/finish_profiles.py <name>"""
+that hash matches).  Usage: python tools/finish_profiles.py <name> [--keep-stale]"""
 import glob
 import hashlib
 import json
@@ -38,9 +38,39 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (the same hash bench.py checks: code only, comments stripped)
 
 d = json.load(open(out))
-d["kernel_source_sha"] = bench.kernel_source_sha(ROOT)
-d["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+# The stamp is the hash of the kernel sources THE BOX RAN (tools/collect_profiles.sh writes it beside the counters, from the
+# snapshot it measured), never one derived here after the fact: a figure is not carried across a code change by hand.  If
+# this tree's kernels differ from what was measured, say so and stop; --keep-stale files the figures under the measured
+# hash anyway (bench.py then reports roofline.traffic = null for this tree, which is the truth).
+sha_file = os.path.join(src, "source_sha.txt")
+if not os.path.exists(sha_file):
+    raise SystemExit("missing %s: collect with tools/collect_profiles.sh (it records the hash of the sources it measured)" % sha_file)
+measured = open(sha_file).read().split()[0]
+current = bench.kernel_source_sha(ROOT)
+if measured != current:
+    print("kernel sources changed since gpurun_out/%s was collected: measured %s, this tree %s" % (name, measured, current))
+    print(subprocess.run(["git", "-C", ROOT, "status", "--short", "infercam_onnx_amd/csrc"], capture_output=True, text=True).stdout)
+    if "--keep-stale" not in sys.argv:
+        raise SystemExit("refusing to stamp: re-collect on the GPU box, or pass --keep-stale to file the figures under the hash they were measured on")
+d["kernel_source_sha"] = measured
+d["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip() + ("" if measured == current else " (stale: sources differ)")
 d["profile"] = name
 json.dump(d, open(out, "w"), indent=1)
 json.dump(d, open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json"), "w"), indent=1)
+# SQ-counter table (tools/pmc_kernel.sh <pattern> collected into gpurun_out/pmc_kernel/): same stamp rule -- the hash the box
+# measured must be this tree's
+sq_dir = os.path.join(ROOT, "gpurun_out", "pmc_kernel")
+sq_json = os.path.join(sq_dir, "sq_counters.json")
+if os.path.exists(sq_json) and os.path.exists(os.path.join(sq_dir, "source_sha.txt")):
+    sq_sha = open(os.path.join(sq_dir, "source_sha.txt")).read().split()[0]
+    if sq_sha == current or "--keep-stale" in sys.argv:
+        q = json.load(open(sq_json))
+        q["kernel_source_sha"], q["commit"], q["profile"] = sq_sha, d["commit"], name
+        json.dump(q, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1, sort_keys=True)
+        json.dump(q, open(os.path.join(ROOT, "profiles", "sq_counters_latest.json"), "w"), indent=1, sort_keys=True)
+        txt = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "sq_table.py"), sq_dir]).decode()
+        open(os.path.join(dst, "sq_counters.txt"), "w").write(txt)
+        print("profiles/%s/sq_counters.{txt,json} filed (%s)" % (name, sq_sha))
+    else:
+        print("gpurun_out/pmc_kernel was measured on other kernel sources (%s): SQ table NOT filed" % sq_sha)
 print("profiles/%s ready; pmc_traffic_latest.json stamped %s @ %s" % (name, d["kernel_source_sha"], d["commit"]))
