@@ -24,12 +24,15 @@ constexpr int kNmsBlock = 256;            // candidates per greedy block (4 x 64
 // by one wave per frame (k_nms_scan).  Inside k_sort_nms the quadratic work of such a frame runs on
 // ONE compute unit and set the latency of the whole batch (1359 candidates: 380 us).
 constexpr int kMatMin = 256;              // frames with more candidates than this take the matrix path
-constexpr int kMatHalf = 2048;            // the scan walks the matrix in halves of this many rows / columns
-constexpr int kMatMax = 4096;             // frames up to this many candidates take it: their keys are sorted in LDS (kSortLdsHeavy)
+constexpr int kMatHalf = 2048;            // the scan walks the matrix in squares of this many rows / columns (up to four on the diagonal)
+constexpr int kMatMax = 8192;             // frames up to this many candidates take it (round 4; 4096 before: the reference has no cap,
+                                          // nn.rs:198-224, and a low threshold on a crowd picture reaches thousands)
 constexpr int kMatWords = kMatMax / 64;   // 64-bit words per matrix row
 constexpr int kHalfWords = kMatHalf / 64;
+constexpr int kMatGridRows = 64;          // row blocks in k_nms_matrix's grid: a frame with more than 4096 candidates takes two passes
 constexpr int kSortLdsHeavy = 4096;       // a frame with more than kSortLds candidates leaves for the matrix path after its
                                           // sort: the LDS of the greedy phase (selected boxes, block rows) holds its keys instead
+                                          // (4096 at a time: a frame of 4097..8192 candidates sorts its two halves one after the other)
 constexpr uint32_t kHeavyFlag = 0x80000000u;  // ndet[frame] = kHeavyFlag | n between the kernels
 
 __device__ __forceinline__ unsigned long long make_key(float conf, uint32_t k) {
@@ -196,6 +199,68 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
   while (n2 < n) n2 <<= 1;
   unsigned long long* keys;
   const bool heavy = n > mat_min && n <= mat_max;  // finished by k_nms_matrix / k_nms_scan
+  if (heavy && n2 > kSortLdsHeavy) {
+    // 4097..8192 candidates: eight blocks of 1024 keys, sorted four at a time in LDS (the two halves of the key array, written
+    // back in place), then merged by RANK like the four blocks of a 4096-key frame below: a key's place in the frame's order is
+    // its place in its own block plus, per other block, the number of keys there that precede it -- counted by binary search
+    // against the four blocks LDS holds (first 4..7, left there by the second sort, then 0..3 fetched back).  Thread t owns
+    // position t of every block: its eight keys and partial ranks stay in registers, so once the second count is done nobody
+    // reads the key array any more and the keys (and their boxes) are scattered to their final places in it.
+    constexpr int CB = kSortLds / 2, NB = 2 * kSortLdsHeavy / CB;  // 1024, 8
+    const LdsKeys lkeys = (LdsKeys)s_keys;
+    if (tid == 0) s_nsel = 0;
+    for (int h = 0; h < 2; h++) {
+      __syncthreads();
+      for (int i = tid; i < kSortLdsHeavy; i += nthr) s_keys[i] = h * kSortLdsHeavy + i < n ? fkeys[h * kSortLdsHeavy + i] : 0ull;
+      __syncthreads();
+      if (h == 0 && tid == 0) counts[frame] = 0;  // (every thread has read the count: see below)
+      bitonic_desc(s_keys, kSortLdsHeavy, CB, tid, nthr, true);
+      for (int i = tid; i < kSortLdsHeavy; i += nthr) fkeys[h * kSortLdsHeavy + i] = s_keys[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+    unsigned long long mine[NB];
+    int rank[NB];
+    auto count_in_lds = [&](int first_block) {  // LDS holds blocks first_block .. first_block + 3
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        const unsigned long long key = mine[c];
+        if (!key) continue;
+        for (int o = 0; o < 4; o++) {
+          if (first_block + o == c) continue;
+          const LdsKeys blk = lkeys + o * CB;
+          int lo = 0, hi = CB;  // first position whose key is smaller = number of keys greater
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (blk[mid] > key) lo = mid + 1;
+            else hi = mid;
+          }
+          rank[c] += lo;
+        }
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      mine[c] = c >= 4 ? (unsigned long long)lkeys[(c - 4) * CB + tid] : fkeys[c * CB + tid];
+      rank[c] = tid;
+    }
+    count_in_lds(4);
+    __syncthreads();
+    for (int i = tid; i < kSortLdsHeavy; i += nthr) s_keys[i] = fkeys[i];
+    __syncthreads();
+    count_in_lds(0);
+    __syncthreads();  // (every read of the key array is done: scatter in place)
+    const float4* fb8 = reinterpret_cast<const float4*>(boxes) + (size_t)frame * K;
+    float4* fspill8 = spill + (size_t)frame * K;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      if (!mine[c]) continue;
+      fkeys[rank[c]] = mine[c];
+      fspill8[rank[c]] = fb8[(int)(mine[c] & 0xffffffffull) - 1];
+    }
+    if (tid == 0) ndet[frame] = kHeavyFlag | (uint32_t)n;
+    return;
+  }
   if (n2 <= kSortLds || (heavy && n2 <= kSortLdsHeavy)) {
     for (int i = tid; i < n2; i += nthr) s_keys[i] = i < n ? fkeys[i] : 0ull;
     keys = s_keys;
@@ -379,9 +444,10 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
 // Suppression matrix of a heavy frame: bit j of row i (i < j, sorted order) = "i, once selected,
 // suppresses j".  Block (rb, cg) = 64 rows x 4 column words, one word per wave, lane = row; every
 // test is iou_exceeds(candidate j, selected i), the in-kernel path's call.
-// A frame with more than kMatHalf candidates has four times the blocks: the grid covers all its row blocks but only the
-// column groups of one half (most batches have no such frame, and every block of the grid is launched for every frame:
-// 4.6 us for the 8192 blocks of a batch that leave at once), and a block of such a frame walks the column halves.
+// A frame with more than kMatHalf candidates has many times the blocks: the grid covers the row blocks of 4096 candidates
+// and the column groups of one 2048-column square only (most batches have no such frame, and every block of the grid is
+// launched for every frame: 4.6 us for the blocks of a batch that leave at once), and a block of a larger frame walks the
+// column squares right of its row's own and, past 4096 candidates, a second row block.
 constexpr int kMatColGroups = kHalfWords / 4;
 __global__ __launch_bounds__(256) void k_nms_matrix(const uint32_t* __restrict__ ndet, const float4* __restrict__ spill, int K,
                                                     float max_iou, unsigned long long* __restrict__ mat) {
@@ -393,10 +459,10 @@ __global__ __launch_bounds__(256) void k_nms_matrix(const uint32_t* __restrict__
   const int n = (int)(flag & ~kHeavyFlag);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float4* fsp = spill + (size_t)frame * K;
-  const int quads = n > kMatHalf ? 2 : 1;
-  const int rb = (int)blockIdx.x;
-  if (rb * 64 >= n) return;
-  for (int cq = rb / kHalfWords; cq < quads; cq++) {  // (the column half left of the row's own is below the diagonal)
+  const int quads = (n + kMatHalf - 1) / kMatHalf;  // squares along the diagonal: 1..4
+  // (the grid has kMatGridRows row blocks: a frame of more than 4096 candidates takes a second pass over the rows below)
+  for (int rb = (int)blockIdx.x; rb * 64 < n; rb += kMatGridRows)
+  for (int cq = rb / kHalfWords; cq < quads; cq++) {  // (column squares left of the row's own are below the diagonal)
       const int cg = (int)blockIdx.y + kMatColGroups * cq;
       if (cg * 4 + 3 < rb || cg * 256 >= n) continue;  // below the diagonal / past the end (block-uniform)
       const int cb = cg * 4 + wave;  // this wave's column word
@@ -504,60 +570,90 @@ __device__ __forceinline__ int nms_scan_half(const unsigned long long* __restric
 }
 
 // One workgroup per heavy frame.  Up to kMatHalf candidates: wave 0 scans the one square, the other waves leave at once.
-// More (two halves): wave 0 scans the first square and publishes, block by block, which rows it kept; waves 1..3 follow
-// it and OR the kept rows' words of the SECOND column half (the off-diagonal square: bulk loads, no serial chain) into
-// the mask the second square starts from; wave 0 then scans the second square.
+// More (two to four squares on the diagonal): wave 0 scans square q and publishes, block by block, which rows it kept; waves
+// 1..3 follow it and OR the kept rows' words of the column squares to the RIGHT of q (the off-diagonal squares: bulk loads,
+// no serial chain) into the masks the later squares start from; then wave 0 scans square q + 1.
 __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __restrict__ gkeys, size_t key_stride,
                                                  const float4* __restrict__ spill, int K, const unsigned long long* __restrict__ mat,
                                                  Det* __restrict__ dets, uint32_t det_stride, uint32_t* __restrict__ ndet) {
+  constexpr int QMAX = kMatMax / kMatHalf;  // 4
   __shared__ unsigned long long s_kept[kHalfWords];
-  __shared__ unsigned long long s_hi[3][kHalfWords];
+  __shared__ unsigned long long s_hi[3][QMAX - 1][kHalfWords];  // [follower wave][later square][word]
+  __shared__ unsigned long long s_removed[QMAX][kHalfWords];    // mask every square starts from
   __shared__ int s_progress;
   const int frame = blockIdx.x;
   const uint32_t flag = ndet[frame];
   if (!(flag & kHeavyFlag)) return;
   const int n = (int)(flag & ~kHeavyFlag);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, word = lane & 31;
-  const bool two = n > kMatHalf;
-  if (!two && wave > 0) return;  // (no barrier on this path)
+  const int Q = (n + kMatHalf - 1) / kMatHalf;
+  if (Q == 1 && wave > 0) return;  // (no barrier on this path)
   const unsigned long long* fmat = mat + (size_t)frame * kMatMax * kMatWords;
   const unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
   const float4* fsp = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
-  if (!two) {
+  if (Q == 1) {
     const int nsel = nms_scan_half(fmat, n, 0, 0, 0ull, fkeys, fsp, fd, det_stride, 0, nullptr, nullptr);
     if (lane == 0) ndet[frame] = (uint32_t)nsel;
     return;
   }
-  if (threadIdx.x == 0) s_progress = 0;
-  __syncthreads();
+  for (int i = threadIdx.x; i < QMAX * kHalfWords; i += 256) s_removed[i / kHalfWords][i % kHalfWords] = 0ull;
   int nsel = 0;
-  if (wave == 0) {
-    nsel = nms_scan_half(fmat, n, 0, 0, 0ull, fkeys, fsp, fd, det_stride, 0, s_kept, &s_progress);
-  } else {
-    // wave w: row blocks w - 1, w + 2, ... of the first half; lane = (row parity, word of the second column half)
-    unsigned long long acc = 0ull;
-    const int nw2 = (n - kMatHalf + 63) >> 6;  // words the second half uses
-    for (int rb = wave - 1; rb < kHalfWords; rb += 3) {
-      // all 32 row pairs of the block in flight at once (unconditional loads, selected afterwards: one memory round
-      // trip per block); they do not depend on what wave 0 keeps, so they are issued before the wait
-      unsigned long long v[32];
+  for (int q = 0; q < Q; q++) {
+    if (threadIdx.x == 0) s_progress = 0;
+    __syncthreads();
+    const bool more = q + 1 < Q;  // squares to the right of this one
+    if (wave == 0) {
+      nsel = nms_scan_half(fmat, n, q * kMatHalf, q * kHalfWords, s_removed[q][word], fkeys, fsp, fd, det_stride, nsel,
+                           more ? s_kept : nullptr, &s_progress);
+    } else if (more) {
+      // wave w: row blocks w - 1, w + 2, ... of square q (all 32: it is not the last); lane = (row parity, word of a later square)
+      unsigned long long acc[QMAX - 1];
 #pragma unroll
-      for (int q = 0; q < 32; q++) v[q] = fmat[(size_t)(rb * 64 + 2 * q + half) * kMatWords + kHalfWords + min(word, nw2 - 1)];
-      while (__hip_atomic_load(&s_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= rb) __builtin_amdgcn_s_sleep(8);
-      const unsigned long long kh = s_kept[rb] >> half;
+      for (int p = 0; p < QMAX - 1; p++) acc[p] = 0ull;
+      for (int rb = wave - 1; rb < kHalfWords; rb += 3) {
+        bool waited = false;
 #pragma unroll
-      for (int q = 0; q < 32; q++) acc |= ((kh >> (2 * q)) & 1ull) ? v[q] : 0ull;
+        for (int p = 0; p < QMAX - 1; p++) {
+          const int sq = q + 1 + p;  // the later square
+          if (sq >= Q) break;
+          const int nwp = (min(n - sq * kMatHalf, kMatHalf) + 63) >> 6;  // words that square uses
+          // all 32 row pairs of the block in flight at once (unconditional loads, selected afterwards: one memory round
+          // trip per block and square); they do not depend on what wave 0 keeps, so they are issued before the wait
+          unsigned long long v[32];
+#pragma unroll
+          for (int r = 0; r < 32; r++)
+            v[r] = fmat[(size_t)(q * kMatHalf + rb * 64 + 2 * r + half) * kMatWords + sq * kHalfWords + min(word, nwp - 1)];
+          if (!waited) {
+            while (__hip_atomic_load(&s_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= rb) __builtin_amdgcn_s_sleep(8);
+            waited = true;
+          }
+          const unsigned long long kh = s_kept[rb] >> half;
+#pragma unroll
+          for (int r = 0; r < 32; r++) acc[p] |= ((kh >> (2 * r)) & 1ull) ? v[r] : 0ull;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < QMAX - 1; p++) {
+        const int sq = q + 1 + p;
+        if (sq >= Q) break;
+        const int nwp = (min(n - sq * kMatHalf, kMatHalf) + 63) >> 6;
+        unsigned long long a = acc[p];
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)a, 32), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(a >> 32), 32);
+        a |= ((unsigned long long)ohi << 32) | olo;
+        if (half == 0) s_hi[wave - 1][p][word] = word < nwp ? a : 0ull;
+      }
     }
-    const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)acc, 32), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), 32);
-    acc |= ((unsigned long long)ohi << 32) | olo;
-    if (half == 0) s_hi[wave - 1][word] = word < nw2 ? acc : 0ull;
+    __syncthreads();
+    if (more) {
+      for (int i = threadIdx.x; i < (Q - 1 - q) * kHalfWords; i += 256) {
+        const int p = i / kHalfWords, w = i % kHalfWords;
+        s_removed[q + 1 + p][w] |= s_hi[0][p][w] | s_hi[1][p][w] | s_hi[2][p][w];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave > 0) return;
-  const unsigned long long removed = s_hi[0][word] | s_hi[1][word] | s_hi[2][word];
-  nsel = nms_scan_half(fmat, n, kMatHalf, kHalfWords, removed, fkeys, fsp, fd, det_stride, nsel, nullptr, nullptr);
-  if (lane == 0) ndet[frame] = (uint32_t)nsel;
+  if (threadIdx.x == 0) ndet[frame] = (uint32_t)nsel;
 }
 
 }  // namespace
@@ -586,7 +682,7 @@ void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_
                      d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : 0, use_matrix ? kMatMax : 0);
   if (!use_matrix) return;
   // (both return at once for frames the first kernel finished itself)
-  hipLaunchKernelGGL(k_nms_matrix, dim3(kMatWords, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
+  hipLaunchKernelGGL(k_nms_matrix, dim3(kMatGridRows, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
   hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
                      d_ndet);
 }

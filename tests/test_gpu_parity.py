@@ -217,6 +217,39 @@ def test_postproc_two_matrix_halves(model640, oracle_lib, size):
             assert np.array_equal(g, ref), "%d candidates differ" % n
 
 
+@pytest.mark.parametrize("size", [0.012, 0.06])
+def test_postproc_up_to_four_matrix_squares(model640, oracle_lib, size):
+    """Frames with 4097..8192 candidates (round 4: the matrix path's cap moved from 4096 to 8192; the reference has none,
+    nn.rs:198-224): keys sorted as eight 1024-key blocks in two LDS passes and merged by rank, the suppression matrix in up to
+    ten 2048 x 2048 squares, the scan over up to four diagonal squares with the off-diagonal ones folded in between.  Both
+    sides of every boundary (4096/4097, 6144/6145, 8192/8193: the last falls back to the in-kernel block loop), next to light
+    frames in the same batch, with confidence ties and zero-area boxes: bit-exact selection and order."""
+    rng = np.random.default_rng(int(size * 1000) + 19)
+    K = model640.num_priors
+    counts = [4097, 8192, 300, 6144, 6145, 5000, 8193, 0, 8191, 7000, 4096, 9000]
+    for b0 in range(0, len(counts), 4):
+        sc, bx = [], []
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            conf = rng.random(K).astype(np.float32) * 0.5
+            hot = rng.permutation(K)[:n]
+            conf[hot] = 0.5 + (1 + rng.random(n).astype(np.float32)) * 0.249
+            if f % 2 == 1:
+                conf[hot] = np.round(conf[hot] * 512) / 512  # many exact ties
+            c = rng.random((K, 2)).astype(np.float32)
+            s = (rng.random((K, 2)).astype(np.float32) * size + 0.004)
+            boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+            boxes[::53, 2] = boxes[::53, 0] - 0.01  # degenerate boxes: zero area
+            sc.append(np.stack([1 - conf, conf], 1).astype(np.float32))
+            bx.append(boxes)
+        got = model640.debug_postproc(np.stack(sc), np.stack(bx))
+        for f, n in enumerate(counts[b0:b0 + 4]):
+            ref = oracle_lib.postproc(sc[f], bx[f], 0.5, 0.5)
+            g = dets_array(got[f])
+            assert int((sc[f][:, 1] > 0.5).sum()) == n
+            assert g.shape == ref.shape, "%d candidates: %d vs %d selected" % (n, len(g), len(ref))
+            assert np.array_equal(g, ref), "%d candidates differ" % n
+
+
 # ---------------------------------------------------------------- end to end
 @pytest.mark.parametrize("variant,src", [(320, (320, 240)), (640, (640, 480)), (640, (1280, 720)), (320, (1280, 720)),
                                          (640, (640, 427))])

@@ -15,7 +15,7 @@ m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=synth.synt
                       max_batch=4, profile=True, det_cap=17640)
 K = m.num_priors
 rng = np.random.default_rng(3)
-for n in (32, 256, 257, 1024, 2048, 2049, 3000, 4096, 4097, 8000):
+for n in (32, 256, 257, 1024, 2048, 2049, 3000, 4096, 4097, 6000, 8000, 8192, 8193, 12000):
     conf = rng.random(K).astype(np.float32) * 0.5
     hot = rng.permutation(K)[:n]
     conf[hot] = 0.5 + (1 + rng.random(n).astype(np.float32)) * 0.249
