@@ -1685,6 +1685,12 @@ static bool want_splitk(long wave_tiles, int cts, int ksteps) {
   // chain length (15x20 maps, 64->4/8 heads at 30x40, the 256-channel layers); costs otherwise
   return wave_tiles * cts < 6L * ksteps;
 }
+// The 1x1 kernel also splits chains that are a multiple of 8 k-steps (the RFB's summed conv: 48 + 64 channels = 56 k-steps,
+// 23 us for ONE frame unsplit): k_pw_mfma<1, 2, 4>.
+static bool pw_wants_splitk(long wave_tiles, int cts, int ksteps) {
+  if (ksteps % 8 != 0) return false;
+  return wave_tiles * cts < 6L * ksteps;
+}
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS of a gfx950 CU
 // Kernels that ask for more than the default 64 KB of dynamic LDS: raised once per kernel and host thread.
 static void allow_large_lds(const void* kernel) {
@@ -1712,7 +1718,7 @@ static PwConfig pw_config(const ConvArgs* args, int n) {
   c.ksteps = r.cin >> 1;
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
-  c.sk = want_splitk(wave_tiles, max_cts * n, c.ksteps);
+  c.sk = pw_wants_splitk(wave_tiles, max_cts * n, c.ksteps);
   c.lds = ((size_t)kBiasLds + (size_t)c.ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
@@ -1728,7 +1734,9 @@ static PwConfig pw_config(const ConvArgs* args, int n) {
 // n (<= 3) convolutions with identical shapes except cout / weights / outputs
 void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
   const PwConfig c = pw_config(args, n);
-  if (c.sk)
+  if (c.sk && c.ksteps % 16 != 0)  // (a quarter of the chain is not a multiple of four k-steps: ring depth 2)
+    hipLaunchKernelGGL((k_pw_mfma<1, 2, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+  else if (c.sk)
     hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
   else if (c.ksteps % 4 == 0)
     hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
@@ -1744,14 +1752,20 @@ const char* conv_pointwise_instance(const ConvArgs* args, int n) {
   const int ksteps = r.cin >> 1;
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
-  if (want_splitk((groups + 31) / 32, max_cts * n, ksteps)) return "<1, 4, 4>";
+  if (pw_wants_splitk((groups + 31) / 32, max_cts * n, ksteps)) return ksteps % 16 ? "<1, 2, 4>" : "<1, 4, 4>";
   return ksteps % 4 == 0 ? "<1, 4, 1>" : "<1, 1, 1>";
 }
 
 bool dwpw_uses_coop(const ConvArgs* args, int n) {
   // (4 cout tiles per block; the 2-tile form measured slower than k_dwpw_mfma)
   const int cts = (args[0].cout + 31) / 32, ksteps = args[0].cin >> 1;
-  return n == 1 && ksteps % 8 == 0 && cts % 4 == 0;
+  if (!(n == 1 && ksteps % 8 == 0 && cts % 4 == 0)) return false;
+  // A frame or a few at a time (the reference's operating point: one stream, one frame, inferer.rs:23,29-50): the launch
+  // has a handful of pixel tiles, and a cooperative wave walks the WHOLE channel chain of its tile -- the kernel then
+  // lasts as long for one frame as for 32 (k_dwpw_coop<1, 4> on the 30x40 maps: 16-28 us at batch 1, 29 us at batch 32).
+  // Split-K waves of k_dwpw_mfma walk a quarter of it each: where that kernel would split, it is the one to use.
+  const long groups = (long)args[0].B * (args[0].oh * args[0].ow / 4);
+  return !want_splitk((groups + kDwGroups - 1) / kDwGroups, cts, ksteps);
 }
 
 // Launch configuration of k_dwpw_mfma for n merged convs (the non-cooperative form): arguments with tiles / cts set,
@@ -1877,7 +1891,7 @@ bool choose_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int
   } else {
     if (b[0].in2 || b[0].res) return false;
     const PwConfig cb = pw_config(b, 1);
-    if (cb.ksteps % 4 != 0) return false;
+    if (cb.ksteps % 4 != 0 || (cb.sk && cb.ksteps % 16 != 0)) return false;  // (the dual instances are <1, 4, SK>)
     c.q.b = cb.p;
     blocks_b = cb.gx;
     c.lds = std::max(c.lds, cb.lds);
