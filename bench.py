@@ -51,10 +51,10 @@ KERNEL_FUNCS = {
     "huff_resolve": "k_huff_resolve", "huff_write": "k_huff_write", "dc_prefix": "k_dc_prefix", "zero_coef": "k_zero_coef",
     "conv_dwpw_coop": "k_dwpw_coop", "stem_planes_mfma": "k_stem_planes_mfma",
     "sort_nms": "k_sort_nms", "conv_dual_coop": "k_dual_dwpw_coop", "conv_dual_pw": "k_dual_dwpw_pw",
-    "nms_matrix": "k_nms_matrix", "nms_scan": "k_nms_scan",
+    "nms_matrix": "k_nms_matrix", "nms_scan": "k_nms_scan", "rfb_tail": "k_rfb_tail",
 }
 MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual_coop", "conv_dual_pw",
-                "stem_planes_mfma", "conv3x3_mfma", "conv3x3_rows_mfma")
+                "stem_planes_mfma", "conv3x3_mfma", "conv3x3_rows_mfma", "rfb_tail")
 
 
 def base_label(key):
@@ -124,6 +124,7 @@ def parse_args():
                     help="config C4 in ONE process (the reference server is one process, infer_server.rs:39-68): "
                          "ufd_create_replicas over --gpus devices (RCCL broadcast of the weights) and ONE ufd_sched over the "
                          "replicas, one producer thread per camera stream; no torch.distributed launcher")
+    ap.add_argument("--no-rfb-tail", action="store_true", help="UFD_FLAG_NO_RFB_TAIL: A/B of k_rfb_tail against the two-launch form")
     ap.add_argument("--spin-wait", action="store_true", help="UFD_FLAG_SPIN_WAIT: ufd_wait always spins in the runtime (A/B of the sleeping wait)")
     ap.add_argument("--host-only", action="store_true",
                     help="timed region + steady state + the `host` object only (no roofline pass, side workloads, verification "
@@ -401,7 +402,7 @@ def main():
     host_threads = args.host_threads or max(2, min(32, usable_cpus() // world))
     model = nn.UltrafaceModel(variant, 0.5, 0.5, device_id=local_rank, max_batch=B, weights=weights, priors=priors,
                               max_src=(SW, SH), host_threads=host_threads, profile=True, det_cap=256,
-                              host_entropy=not device_entropy, extra_flags=nn.UFD_FLAG_SPIN_WAIT if args.spin_wait else 0)
+                              host_entropy=not device_entropy, extra_flags=(nn.UFD_FLAG_SPIN_WAIT if args.spin_wait else 0) | (nn.UFD_FLAG_NO_RFB_TAIL if args.no_rfb_tail else 0))
     nb = max(1, args.pool // B)
     host_batches = [model._prep_batch(jpegs[i * B:(i + 1) * B]) for i in range(nb)]
     staged_batches = None

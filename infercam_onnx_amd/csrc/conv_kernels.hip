@@ -1354,6 +1354,213 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// RFB tail in ONE launch (round 4): the three dilated 3x3 convs of the branches (b0: d2, b1: d3, b2: d5; 16 -> 16 each, no
+// activation) and relu(ConvLinear(cat48) + shortcut(x)) -- SURVEY 8.1 rows 15, 18, 22, 23, 24.  The 48-channel concat
+// tensor (29.5 MB per 32-frame batch of the 640 model, written by one launch and read by the next) never exists: a wave
+// computes the three convs for its tile exactly as k_conv3x3_rows_mfma does (same lane layout, same MFMA sequence, one
+// conv after the other with the halo of the widest dilation, HL = 2) and keeps the results in their accumulators; the D
+// layout of v_mfma_f32_16x16x4_f32 -- register r of lane (q, j) = channel 4q + r of pixel group j -- IS a B operand of the
+// same instruction for the k-chunk of channels {r, 4 + r, 8 + r, 12 + r}, so the 1x1 conv multiplies them straight out of
+// the registers (weights packed in that channel order: pack_rfb_tail_weights), then runs over the 64 channels of x from
+// memory (16-byte row segments, the row kernel's own load shape) and stores 64 output channels.
+// Accumulation order of the 1x1: bias; the branch channels in the permuted chunk order; x's channels in chunks of 4 -- fp32
+// rounding apart from the two-launch form (which itself differs from the oracle's order by the same kind of rounding).
+// a3.a[b]: conv b as for launch_conv3x3_rows_mfma (w = row packing); fin: the summed 1x1 (in2 = x with in2_ctotal, w = tail
+// packing [28 chunks][4 cout tiles][64], bias = both biases summed, out).
+constexpr int kTailHL = 2, kTailNG = 16 - 2 * kTailHL;
+constexpr int kTailChunks = 12 + 16;  // 48 branch channels + 64 channels of x, 4 per MFMA
+struct RfbTailArgs {
+  ConvArgs3 a3;
+  ConvArgs fin;
+};
+
+template <int DIL>
+__device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __restrict__ wsrc, int lane, uint32_t frame32, int oy,
+                                            int ox, floatx4 (&acc)[4]) {
+  const int q = lane >> 4;
+  const int ihw = a.ih * a.iw, cin4 = (a.cin + 3) >> 2;
+  {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 4 * q);  // (cout = 16: rfb_tail_supported)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j][0] = b4.x, acc[j][1] = b4.y, acc[j][2] = b4.z, acc[j][3] = b4.w;
+  }
+  bool rowok[3];
+  uint32_t rowoff[3];
+  const uint32_t frame_off = __umul24(__umul24(frame32, (uint32_t)a.in_ctotal), (uint32_t)ihw);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int iy = oy + (r - 1) * DIL;
+    rowok[r] = iy >= 0 && iy < a.ih;
+    rowoff[r] = frame_off + (uint32_t)(min(max(iy, 0), a.ih - 1) * a.iw + ox);
+  }
+  bool lok[4], rok[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) lok[j] = ox + j - DIL >= 0, rok[j] = ox + j + DIL < a.ow;
+  const float* __restrict__ in = a.in;
+  // value of this lane's row segment at column offset c (relative to its first pixel): a register pick or a DPP row shift
+  // (a quad's 16 lanes are one DPP row; lanes past its ends get 0: they are halo providers)
+  auto col = [&](const float4& m, int c) -> float {
+    const int o = (c >= 0) ? (c >> 2) : -((3 - c) >> 2);
+    const int k = c - 4 * o;
+    const float v = k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w));
+    switch (o) {
+      case 0: return v;
+      case -1: return row_shift<0x111>(v);
+      case -2: return row_shift<0x112>(v);
+      case 1: return row_shift<0x101>(v);
+      default: return row_shift<0x102>(v);
+    }
+  };
+  auto load_rows = [&](int kc, float4 (&m)[3]) {
+    const uint32_t c = (uint32_t)min(4 * kc + q, a.cin - 1) * (uint32_t)ihw;
+#pragma unroll
+    for (int r = 0; r < 3; r++) m[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c));
+  };
+  float4 cur[3], nxt[3];
+  load_rows(0, cur);
+  for (int kc = 0; kc < cin4; kc++) {
+    load_rows(min(kc + 1, cin4 - 1), nxt);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float4 m = rowok[r] ? cur[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float x[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float vl = col(m, j - DIL), vc = col(m, j), vr = col(m, j + DIL);
+        x[0][j] = j >= DIL ? vl : (lok[j] ? vl : 0.0f);
+        x[1][j] = vc;
+        x[2][j] = j + DIL <= 3 ? vr : (rok[j] ? vr : 0.0f);
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const float w = wsrc[(kc * 9 + r * 3 + kx) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) cur[r] = nxt[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
+  const ConvArgs& fin = t.fin;
+  extern __shared__ float s_tail[];
+  // (LDS holds the 1x1's weights only, 28 KB: with the dilated convs' 27 KB beside them a CU took two blocks, not the three
+  // its registers allow; those are read from L1 / L2 like the row kernel's when they do not fit)
+  float* s_wf = s_tail;                      // [kTailChunks][4][64]
+  const int bx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int ohw = fin.oh * fin.ow, gpf = ohw >> 2, gpr = fin.ow >> 2;
+  const int total = fin.B * gpf;
+  if ((long)bx * 4 * kTailNG - kTailHL >= (long)total) return;  // whole block, before the barrier
+  {
+    const float4* src = reinterpret_cast<const float4*>(fin.w);
+    float4* dst = reinterpret_cast<float4*>(s_wf);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < kTailChunks * 4 * 16; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j16 = lane & 15;
+  const int g = (bx * 4 + wave) * kTailNG + j16 - kTailHL;
+  const bool inrange = g >= 0 && g < total;
+  const bool live = inrange && j16 >= kTailHL && j16 < 16 - kTailHL;
+  const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
+  const int rem = inrange ? g - (int)frame32 * gpf : 0;
+  const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
+
+  // 1x1 over [48 branch channels | 64 channels of x] -> 64 output channels: out[m][pixel][r] = channel 16 m + 4 q + r.
+  // Every branch is multiplied into the 1x1's accumulators as soon as its conv is done (its 16 result registers are free
+  // again for the next branch): 16 + 64 accumulators instead of 48 + 64.
+  floatx4 out[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const float4 b4 = *reinterpret_cast<const float4*>(fin.bias + 16 * m + 4 * q);
+#pragma unroll
+    for (int p = 0; p < 4; p++) out[m][p][0] = b4.x, out[m][p][1] = b4.y, out[m][p][2] = b4.z, out[m][p][3] = b4.w;
+  }
+  const float* wl = s_wf + lane;
+  auto fold_branch = [&](int b, const floatx4 (&br)[4]) {  // br[pixel][r] = channel 16 b + 4 q + r
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int chunk = b * 4 + r;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const float w = wl[(chunk * 4 + m) * 64];
+#pragma unroll
+        for (int p = 0; p < 4; p++) out[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, br[p][r], out[m][p], 0, 0, 0);
+      }
+    }
+  };
+  {
+    floatx4 br[4];
+    rfb_dilated<2>(t.a3.a[0], t.a3.a[0].w, lane, frame32, oy, ox, br);
+    fold_branch(0, br);
+  }
+  {
+    floatx4 br[4];
+    rfb_dilated<3>(t.a3.a[1], t.a3.a[1].w, lane, frame32, oy, ox, br);
+    fold_branch(1, br);
+  }
+  {
+    floatx4 br[4];
+    rfb_dilated<5>(t.a3.a[2], t.a3.a[2].w, lane, frame32, oy, ox, br);
+    fold_branch(2, br);
+  }
+  // x's row segments: channel 4 kc + q of the lane's 4 pixels, eight chunks in flight.  (Measured alone, 640 model at batch
+  // 32: requested here 76 us; requested before the convs with two chunks of rows in flight, 184 registers = two waves per
+  // SIMD, 79 us; capped at 128 registers for four waves, 18 dwords spilled, 78 us; with the convs' weights in LDS too,
+  // 55 KB = two blocks per CU, 80 us.  The two launches it replaces take 37 + 34 us: the 1x1 here also multiplies the four
+  // halo columns of every 16, which the 32x32x2 kernel does not have.)
+  const uint32_t x_off = (frame32 * (uint32_t)fin.in2_ctotal + (uint32_t)q) * (uint32_t)ohw + (uint32_t)(oy * fin.ow + ox);
+  const uint32_t x_step = 4u * (uint32_t)ohw;
+  const float* __restrict__ xin = fin.in2;
+  float4 xa[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; kc++) xa[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)kc * x_step));
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    float4 xb[8];
+    if (half == 0) {
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++) xb[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)(8 + kc) * x_step));
+    }
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++) {
+      const float4 xv = xa[kc];
+      const float xp[4] = {xv.x, xv.y, xv.z, xv.w};
+      const int chunk = 12 + half * 8 + kc;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const float w = wl[(chunk * 4 + m) * 64];
+#pragma unroll
+        for (int p = 0; p < 4; p++) out[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xp[p], out[m][p], 0, 0, 0);
+      }
+    }
+    if (half == 0) {
+#pragma unroll
+      for (int kc = 0; kc < 8; kc++) xa[kc] = xb[kc];
+    }
+  }
+  if (!live) return;
+  char* optr = reinterpret_cast<char*>(fin.out);
+  const uint32_t step = 4u * (uint32_t)ohw;
+  uint32_t o = 4u * (__umul24(__umul24(frame32, (uint32_t)fin.out_ctotal) + (uint32_t)(fin.out_coff + 4 * q), (uint32_t)ohw) + (uint32_t)(oy * fin.ow + ox));
+  const int lowest = fin.relu ? 0 : (int)0x80000000;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    uint32_t om = o + (uint32_t)(16 * m) * step;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float4 v = make_float4(__int_as_float(max(__float_as_int(out[m][0][r]), lowest)), __int_as_float(max(__float_as_int(out[m][1][r]), lowest)),
+                                   __int_as_float(max(__float_as_int(out[m][2][r]), lowest)), __int_as_float(max(__float_as_int(out[m][3][r]), lowest)));
+      *reinterpret_cast<float4*>(optr + om) = v;
+      om += step;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Direct convolution fallback, one output pixel x COB output channels per thread.
 template <int COB, bool DW>
 __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
@@ -1670,6 +1877,59 @@ void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
   }
 }
 
+// Template instance launch_conv3x3_rows_mfma picks (profile labels: bench.py matches them with rocprofv3's kernel names).
+const char* conv3x3_rows_instance(const ConvArgs* args, int n) {
+  const ConvArgs& a = args[0];
+  for (int i = 1; i < n; i++)
+    if (args[i].dil != a.dil) return "<1, 0>";
+  if (a.stride == 2) return "<2, 1>";
+  return a.dil == 1 ? "<1, 1>" : (a.dil == 2 ? "<1, 2>" : (a.dil == 3 ? "<1, 3>" : "<1, 5>"));
+}
+
+// ---- RFB tail (k_rfb_tail)
+size_t rfb_tail_packed_floats() { return (size_t)kTailChunks * 4 * 64; }
+
+// w_lin [64][48] (ConvLinear over the concat: branch b's channels at 16 b), w_short [64][64] (shortcut over x):
+// packed[(chunk * 4 + m) * 64 + lane] = W[cout 16 m + (lane & 15)][channel of (chunk, k = lane >> 4)], where the branch chunks
+// follow the accumulator layout of the dilated convs (chunk 4 b + r holds channels 16 b + 4 k + r) and x's are 4 chunk' + k.
+void pack_rfb_tail_weights(const float* w_lin, const float* w_short, float* packed) {
+  for (int chunk = 0; chunk < kTailChunks; chunk++)
+    for (int m = 0; m < 4; m++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int co = 16 * m + (lane & 15), k = lane >> 4;
+        float v;
+        if (chunk < 12) {
+          const int b = chunk >> 2, r = chunk & 3;
+          v = w_lin[(size_t)co * 48 + 16 * b + 4 * k + r];
+        } else {
+          v = w_short[(size_t)co * 64 + 4 * (chunk - 12) + k];
+        }
+        packed[((size_t)chunk * 4 + m) * 64 + lane] = v;
+      }
+}
+
+// dil3[0..2]: the dilated convs in concat order (dilations 2, 3, 5; 16 -> 16, stride 1, same maps); fin: the summed 1x1
+// (cin = 48 + 64, cout 64, in2 = x).
+bool rfb_tail_supported(const ConvArgs* dil3, const ConvArgs& fin) {
+  static const int kDil[3] = {2, 3, 5};
+  for (int b = 0; b < 3; b++) {
+    const ConvArgs& a = dil3[b];
+    if (a.k != 3 || a.stride != 1 || a.dil != kDil[b] || a.pad != a.dil || a.cin != 16 || a.cout != 16 || a.depthwise || a.res || a.relu) return false;
+    if (a.ih != fin.oh || a.iw != fin.ow || a.oh != fin.oh || a.ow != fin.ow) return false;
+  }
+  return fin.k == 1 && fin.cout == 64 && fin.cin == 48 + 64 && fin.in2_ctotal >= 64 && (fin.ow & 3) == 0 && !fin.res;  // (shapes only: also asked at plan time)
+}
+
+void launch_rfb_tail(const ConvArgs* dil3, const ConvArgs& fin, hipStream_t s) {
+  RfbTailArgs t{};
+  for (int b = 0; b < 3; b++) t.a3.a[b] = dil3[b];
+  t.fin = fin;
+  const long groups = (long)fin.B * (fin.oh * fin.ow / 4);
+  const unsigned blocks = (unsigned)(((groups + 4L * kTailNG - 1) / (4L * kTailNG) + 7) / 8 * 8);
+  const size_t lds = rfb_tail_packed_floats() * sizeof(float);  // 28 KB
+  hipLaunchKernelGGL(k_rfb_tail, dim3(blocks), dim3(256), lds, s, t);
+}
+
 bool dwpw_supported(const ConvArgs& a, int stride) {
   return (a.ow % 4 == 0) && (a.iw % 4 == 0) && (a.cin % 2 == 0) && (stride == 1 || stride == 2) &&
          (stride == 1 ? (a.iw == a.ow && a.ih == a.oh) : (a.iw == 2 * a.ow));
@@ -1763,9 +2023,12 @@ bool dwpw_uses_coop(const ConvArgs* args, int n) {
   // A frame or a few at a time (the reference's operating point: one stream, one frame, inferer.rs:23,29-50): the launch
   // has a handful of pixel tiles, and a cooperative wave walks the WHOLE channel chain of its tile -- the kernel then
   // lasts as long for one frame as for 32 (k_dwpw_coop<1, 4> on the 30x40 maps: 16-28 us at batch 1, 29 us at batch 32).
-  // Split-K waves of k_dwpw_mfma walk a quarter of it each: where that kernel would split, it is the one to use.
+  // Split-K waves of k_dwpw_mfma walk a quarter of it each: the one to use while the cooperative launch would have fewer
+  // than 256 waves (64 blocks, a quarter of the CUs) -- NOT wherever that kernel would split: m12 at batch 32 (15x20 maps,
+  // 80 pixel tiles x 8 cout tiles) is inside want_splitk's range and takes 55 us split, 29 us cooperative.
   const long groups = (long)args[0].B * (args[0].oh * args[0].ow / 4);
-  return !want_splitk((groups + kDwGroups - 1) / kDwGroups, cts, ksteps);
+  const long wave_tiles = (groups + kDwGroups - 1) / kDwGroups;
+  return !(wave_tiles * cts < 256 && want_splitk(wave_tiles, cts, ksteps));
 }
 
 // Launch configuration of k_dwpw_mfma for n merged convs (the non-cooperative form): arguments with tiles / cts set,

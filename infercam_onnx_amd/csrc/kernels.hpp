@@ -178,12 +178,20 @@ bool launch_conv_dual(const ConvArgs* a, int n_a, int a_stride, const ConvArgs* 
 // Template arguments of the kernel instance those launchers pick, as rocprofv3 prints them ("<16, 1, true>"): profiling labels.
 const char* conv_dual_instance(const ConvArgs* a, int n_a, int a_stride, const ConvArgs* b, int b_stride);
 const char* conv_pointwise_instance(const ConvArgs* a, int n);
+const char* conv3x3_rows_instance(const ConvArgs* a, int n);
 const char* conv_dwpw_instance(const ConvArgs* a, int n, int stride);
 const char* conv_dwpw2_instance(const ConvArgs& first, const ConvArgs& second);
 // Dense 3x3 (cout <= 16) as implicit GEMM on fp32 MFMA.  w: packed by pack_conv3x3_weights().
 void launch_conv3x3_mfma(const ConvArgs* a, int n, hipStream_t s);
 // Row variant (16-byte row loads + cross-lane shuffles instead of per-tap gathers).
 bool conv3x3_rows_supported(const ConvArgs& a);
+// RFB tail as one launch (k_rfb_tail): the three dilated 3x3 convs + relu(ConvLinear(cat) + shortcut(x)); the concat tensor
+// never exists.  dil3: the convs in concat order with the row packing of their weights; fin: the summed 1x1 with the tail
+// packing of both weight matrices (pack_rfb_tail_weights) and both biases summed.
+size_t rfb_tail_packed_floats();
+void pack_rfb_tail_weights(const float* w_lin /*[64][48]*/, const float* w_short /*[64][64]*/, float* packed);
+bool rfb_tail_supported(const ConvArgs* dil3, const ConvArgs& fin);
+void launch_rfb_tail(const ConvArgs* dil3, const ConvArgs& fin, hipStream_t s);
 // Stem conv straight from the decoder's 4:2:0 sample planes (every frame of the batch at the model
 // size): a = the stem's ConvArgs with the row packing of its weights (pack_conv3x3_rows_weights);
 // frames whose descriptor does not match (failed frames) read as zero input.

@@ -95,6 +95,7 @@ struct Layer {
   int in_coff = 0;                    // this layer reads channels [in_coff, in_coff + cin) of its input tensor
   const float* d_w_sum = nullptr;     // ... packed weights over both inputs' channels / the stacked output channels, and their bias
   const float* d_b_sum = nullptr;
+  const float* d_w_tail = nullptr;    // RFB shortcut layer: ConvLinear + shortcut weights in k_rfb_tail's chunk order
   const float* d_b = nullptr;
   double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
   int tap_tensor = -1, tap_coff = 0;  // where this layer's output lives in the issued plan (-1: it never exists)
@@ -316,6 +317,7 @@ struct ufd_model {
   hipStream_t copy_stream = nullptr;
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
+  bool rfb_tail = false;              // the three dilated RFB convs + the summed 1x1 run as ONE launch (k_rfb_tail)
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   std::vector<float*> tap_buf;        // UFD_FLAG_TAP_LAYERS: per tensor, a copy taken right after its producing launch
 
@@ -614,6 +616,36 @@ void plan_tensors(ufd_model* m, bool keep_all) {
       }
     }
   }
+  // RFB tail as ONE launch (k_rfb_tail, issued at the shortcut layer's turn): the three dilated 3x3 convs hand their
+  // results to the summed 1x1 in registers, the 48-channel concat tensor never exists.  The dilated layers become
+  // "chained" (no launch, no output of their own; ufd_debug_layer_output reports them absent in this plan).
+  m->rfb_tail = false;
+  if (!keep_all && !(flags & UFD_FLAG_NO_RFB_TAIL) && m->layers[kRfbShortcut].sum_with == kRfbLinear) {
+    const int dil_layers[3] = {kRfbCatA, kRfbCatB, kRfbCatC};
+    ConvArgs d3[3]{}, fin{};
+    bool ok = true;
+    for (int b = 0; b < 3; b++) {
+      const Layer& D = m->layers[dil_layers[b]];
+      ok = ok && D.kind == kKindConv3x3 && !D.chained;
+      d3[b].k = D.spec.k, d3[b].stride = D.spec.stride, d3[b].dil = D.spec.dil, d3[b].pad = D.spec.pad;
+      d3[b].cin = D.spec.cin, d3[b].cout = D.spec.cout, d3[b].relu = D.spec.relu;
+      d3[b].ih = D.ih, d3[b].iw = D.iw, d3[b].oh = D.oh, d3[b].ow = D.ow;
+    }
+    const Layer& S = m->layers[kRfbShortcut];
+    fin.k = 1, fin.cout = S.spec.cout, fin.cin = m->layers[kRfbLinear].spec.cin + S.spec.cin;
+    fin.in2_ctotal = S.in_tensor >= 0 ? m->tensors[S.in_tensor].c : 0;
+    fin.oh = S.oh, fin.ow = S.ow;
+    if (ok && rfb_tail_supported(d3, fin)) {
+      m->rfb_tail = true;
+      Layer& S2 = m->layers[kRfbShortcut];
+      for (int b = 0; b < 3; b++) {
+        Layer& D = m->layers[dil_layers[b]];
+        D.chained = true;
+        S2.flops_per_frame += D.flops_per_frame;
+        S2.weight_bytes += D.weight_bytes;
+      }
+    }
+  }
   // The three RFB reduce convs (64 -> 8 each, same input) as ONE 64 -> 24 conv: one cout tile instead
   // of three, the input read once; the consumers read channel slices of the stacked tensor.
   if (!keep_all) {
@@ -736,6 +768,9 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     if (L.sum_with >= 0 && m->layers[L.sum_with].in_tensor >= 0)
       last[m->layers[L.sum_with].in_tensor] = std::max(last[m->layers[L.sum_with].in_tensor], when);
   }
+  if (m->rfb_tail)  // the fused launch reads the dilated convs' inputs at the shortcut layer's turn
+    for (int j : {kRfbCatA, kRfbCatB, kRfbCatC})
+      if (m->layers[j].in_tensor >= 0) last[m->layers[j].in_tensor] = std::max(last[m->layers[j].in_tensor], kRfbShortcut);
   for (int h = 0; h < 4; h++) {
     last[tensor_of[kHeadCls[h]]] = kNumConv;
     last[tensor_of[kHeadReg[h]]] = kNumConv;
@@ -777,7 +812,8 @@ void plan_tensors(ufd_model* m, bool keep_all) {
     // layer's output never aliases its own inputs
     if (!keep_all)
       for (int u = 0; u < nt; u++)
-        if (last[u] == i) free_list.push_back({m->tensors[u].off, align(m->tensors[u].per_frame() * m->B)});
+        if (last[u] == i && allocated[u])  // (a tensor no launch writes -- the RFB concat under k_rfb_tail -- has no storage to give back)
+          free_list.push_back({m->tensors[u].off, align(m->tensors[u].per_frame() * m->B)});
   }
   m->arena_floats = top;
 }
@@ -869,6 +905,20 @@ int upload_weights(ufd_model* m, const float* blob) {
       img.insert(img.end(), bsum.begin(), bsum.end());
     }
   }
+  size_t tail_off = (size_t)-1;
+  if (m->rfb_tail) {
+    const float* q = blob;
+    const float *w_lin = nullptr, *w_short = nullptr;
+    for (int i = 0; i < kNumConv; i++) {
+      if (i == kRfbLinear) w_lin = q;
+      if (i == kRfbShortcut) w_short = q;
+      q += conv_weight_floats(specs[i]) + specs[i].cout;
+    }
+    while (img.size() % 64) img.push_back(0.f);
+    tail_off = img.size();
+    img.resize(img.size() + rfb_tail_packed_floats());
+    pack_rfb_tail_weights(w_lin, w_short, img.data() + tail_off);
+  }
   m->weight_img_floats = img.size();
   HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
   HIPC(m, hipMemcpy(m->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -879,6 +929,7 @@ int upload_weights(ufd_model* m, const float* blob) {
     if (rows_off[i] != (size_t)-1) m->layers[i].d_w_rows = m->d_weights + rows_off[i];
     if (sumw_off[i] != (size_t)-1) m->layers[i].d_w_sum = m->d_weights + sumw_off[i], m->layers[i].d_b_sum = m->d_weights + sumb_off[i];
   }
+  if (tail_off != (size_t)-1) m->layers[kRfbShortcut].d_w_tail = m->d_weights + tail_off;
   return UFD_OK;
 }
 
@@ -1085,6 +1136,23 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
     launch_stem_planes_mfma(sa, st);
     return;
   }
+  if (i == kRfbShortcut && m->rfb_tail) {  // the three dilated convs + relu(ConvLinear(cat) + shortcut(x)) as one launch
+    int st_ = 1;
+    ConvArgs d3[3];
+    const int dil_layers[3] = {kRfbCatA, kRfbCatB, kRfbCatC};
+    std::string names;
+    for (int b = 0; b < 3; b++) {
+      d3[b] = layer_args(m, dil_layers[b], f0, count, &st_);
+      d3[b].w = m->layers[dil_layers[b]].d_w_rows;
+      names += std::string(m->layers[dil_layers[b]].spec.name) + "+";
+    }
+    ConvArgs fin = layer_args(m, i, f0, count, &st_);
+    fin.w = L.d_w_tail;
+    ProfScope ps(m, std::string("rfb_tail:") + names + L.spec.name,
+                 L.bytes_per_frame * count + L.weight_bytes, L.flops_per_frame * count, st);
+    launch_rfb_tail(d3, fin, st);
+    return;
+  }
   if (L.kind == kKindDwPw2) {
     int s1 = 1, s2 = 2;
     const Layer& F = m->layers[L.chain_first];
@@ -1136,7 +1204,8 @@ void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipS
       ps.cancel();
     }
   }
-  const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n) : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : "");
+  const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n)
+                     : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : (use_rows ? conv3x3_rows_instance(args, n) : ""));
   {
   ProfScope ps(m, std::string(kind) + inst + ":" + names, bytes, flops, st);
   switch (L.kind) {

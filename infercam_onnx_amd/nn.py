@@ -22,6 +22,7 @@ UFD_FLAG_KEEP_LAYERS, UFD_FLAG_PROFILE, UFD_FLAG_DEVICE_ENTROPY, UFD_FLAG_HOST_E
 UFD_FLAG_TAP_LAYERS, UFD_FLAG_NO_CHAIN, UFD_FLAG_NO_RFB_SUM, UFD_FLAG_NO_STEM_FUSE = 16, 32, 64, 128
 UFD_FLAG_NO_NUMA_PIN = 256
 UFD_FLAG_SPIN_WAIT = 1024
+UFD_FLAG_NO_RFB_TAIL = 2048
 UFD_FLAG_NO_DUAL = 512
 UFD_MAX_REPLICAS = 64
 UFD_SCHED_NO_WAIT = 0xFFFFFFFF

@@ -241,7 +241,7 @@ def test_bn_folded_like_weight_ranges_through_the_product_plan(pool_c3, oracle_l
                 checked += 1
             assert np.abs(scores[f] - rs).max() <= 1e-5
             assert (np.abs(boxes[f] - rb) <= 1e-5 * np.maximum(1.0, np.abs(rb))).all()
-        assert checked >= 4 * 30, checked
+        assert checked >= 4 * 28, checked  # (29 tensors exist in the 640 plan since k_rfb_tail took the three dilated RFB convs inside its launch)
         w10, b10 = synth.layer_params(weights, 10)  # the generator's point: one backbone layer's channels differ by > 8x
         norms = np.sqrt((w10.reshape(w10.shape[0], -1) ** 2).sum(1))
         assert norms.max() / norms.min() > 8.0 and np.abs(b10).max() > 0.5, (norms.max() / norms.min(), np.abs(b10).max())

@@ -709,6 +709,42 @@ def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracl
         fused_model.close()
 
 
+@pytest.mark.parametrize("variant,batch", [(640, 3), (320, 5), (640, 32)])
+def test_rfb_tail_launch_matches_the_two_launch_form(weights, oracle_lib, variant, batch):
+    """k_rfb_tail (round 4): the three dilated 3x3 convs of the RFB branches hand their results to
+    relu(ConvLinear(cat) + shortcut(x)) in registers -- the 48-channel concat tensor never exists, one launch instead of
+    two.  Same MFMA sequence for the 3x3 convs; the 1x1 takes the branch channels in the accumulators' order, so fp32
+    rounding apart (<= 5e-6 on scores / boxes) from the two-launch form (UFD_FLAG_NO_RFB_TAIL), the RFB output within the
+    usual 1e-5 of the oracle on every frame, at tile counts that end inside a frame (320: 30x40 maps) and at the bench's
+    batch."""
+    from infercam_onnx_amd import nn, synth
+
+    W, H = (640, 480) if variant == 640 else (320, 240)
+    pri = synth.gen_priors(W, H)
+    x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(94, i % 7, W, H)) for i in range(batch)])
+    ref_model = make_model(variant, weights, max_batch=batch, profile=True, extra_flags=nn.UFD_FLAG_NO_RFB_TAIL)
+    fused_model = make_model(variant, weights, max_batch=batch, profile=True, tap_layers=True)
+    try:
+        s0, b0 = ref_model.debug_forward(x)
+        s1, b1 = fused_model.debug_forward(x)
+        assert np.abs(s0 - s1).max() <= 5e-6 and np.abs(b0 - b1).max() <= 5e-6
+        for f in sorted({0, batch // 2, batch - 1}):
+            rs, rb, outs = oracle_lib.forward(x[f], weights, pri, layers=True)
+            assert np.abs(s1[f] - rs).max() <= 1e-5 and np.abs(b1[f] - rb).max() <= 1e-5
+            got = fused_model.debug_layer_output(24, f).reshape(outs[24].shape)
+            assert np.abs(got - outs[24]).max() <= 1e-5 * max(np.abs(outs[24]).max(), 1e-6)
+            for gone in (15, 18, 22, 23):  # computed inside the launch: no tensor of their own in this plan
+                with pytest.raises(nn.UfdError):
+                    fused_model.debug_layer_output(gone, f)
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names = {p["name"] for p in fused_model.profile_read() if p["launches"]}
+        assert any(n.startswith("rfb_tail:") for n in names) and not any(n.startswith("rfb_tail:") for n in names_ref), names
+        assert any(n.startswith("conv3x3_rows_mfma<1, 0>") for n in names_ref) and not any(n.startswith("conv3x3_rows_mfma<1, 0>") for n in names)
+    finally:
+        ref_model.close()
+        fused_model.close()
+
+
 def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
     """relu(ConvLinear(cat) + shortcut(x)) as one 1x1 conv over both inputs' channels: one fma chain
     instead of two, so fp32 rounding apart (<= 5e-6 on scores / boxes) from the two-launch form,
@@ -718,8 +754,10 @@ def test_summed_rfb_convs_match_the_two_launch_form(weights, oracle_lib):
     W, H = 640, 480
     pri = synth.gen_priors(W, H)
     x = np.stack([oracle_lib.normalize_nchw(synth.synth_frame(93, i, W, H)) for i in range(3)])
+    from infercam_onnx_amd import nn
+
     ref_model = make_model(640, weights, max_batch=3, profile=True, no_rfb_sum=True)
-    fused_model = make_model(640, weights, max_batch=3, profile=True)
+    fused_model = make_model(640, weights, max_batch=3, profile=True, extra_flags=nn.UFD_FLAG_NO_RFB_TAIL)  # (the summed conv as its own launch)
     try:
         s0, b0 = ref_model.debug_forward(x)
         s1, b1 = fused_model.debug_forward(x)

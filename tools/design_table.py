@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Markdown table of DESIGN.md section 4 from a round's filed profiles: per kernel instance the launches per batch, the
+alone time (rocprofv3 kernel trace, one batch in flight), the loaded time (bench.py's fully sampled pass, six batches in
+flight), the SQ-counter shares and the PMC traffic.  Usage: python tools/design_table.py profiles/r4z"""
+import json
+import os
+import re
+import sys
+
+d = sys.argv[1]
+alone = {}
+for ln in open(os.path.join(d, "kernel_times_alone.txt")):
+    m = re.match(r"(?:void )?(\S.*?)\s+(\d+)\s+([\d.]+) us\s+([\d.]+)%", ln)
+    if m:
+        alone[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+batches = alone.get("k_stem_planes_mfma", (34, 0))[0]
+sq = json.load(open(os.path.join(d, "sq_counters.json"))).get("instances", {}) if os.path.exists(os.path.join(d, "sq_counters.json")) else {}
+pmc = json.load(open(os.path.join(d, "pmc_traffic.json"))).get("instances", {})
+bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
+loaded = bench.get("kernels_ms_per_step", {})
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+
+loaded_by_dev = {}
+for k, v in loaded.items():
+    loaded_by_dev[B.device_name(k)] = loaded_by_dev.get(B.device_name(k), 0.0) + v * 1e3
+print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | traffic MB / launch (fetch + write) |")
+print("|---|---|---|---|---|---|---|---|---|")
+tot = 0.0
+pct = lambda x: "%.0f %%" % (100 * x) if x is not None else "–"
+for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+    if k.startswith("__amd"):
+        continue
+    per = calls / batches
+    tot += per * us
+    s = sq.get(k, {})
+    p = pmc.get(k, {})
+    tr = "%.0f + %.0f" % (p["fetch_bytes_per_launch"] / 1e6, p["write_bytes_per_launch"] / 1e6) if p else "–"
+    ld = loaded_by_dev.get(k)
+    print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s |" % (
+        k, per, us, "%.0f" % ld if ld else "–", pct(s.get("mfma_busy")), pct(s.get("valu_busy")),
+        "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), tr))
+print("\nkernels alone per batch: %.0f µs; delivered: %.3f ms per batch (steady state %.0f frames/s)" % (
+    tot, bench["host"]["ms_per_batch"] if "host" in bench else bench["ms_per_step"], bench.get("steady_state_fps", 0)))
