@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Markdown table of DESIGN.md section 4 from a round's filed profiles: per kernel instance the launches per batch, the
 alone time (rocprofv3 kernel trace, one batch in flight), the loaded time (bench.py's fully sampled pass, six batches in
-flight), the SQ-counter shares and the PMC traffic.  Usage: python tools/design_table.py profiles/r4z"""
+flight), the SQ-counter shares and the PMC traffic.  With --update the table replaces the region between the
+KERNEL_TABLE markers of DESIGN.md, so that the measured columns are never typed by hand.
+Usage: python tools/design_table.py profiles/r4z [--update]"""
 import json
 import os
 import re
@@ -24,6 +26,16 @@ import bench as B  # noqa: E402
 loaded_by_dev = {}
 for k, v in loaded.items():
     loaded_by_dev[B.device_name(k)] = loaded_by_dev.get(B.device_name(k), 0.0) + v * 1e3
+out_lines = []
+_print = print
+
+
+def print(*a):  # noqa: A001  (collect what is printed: --update writes it into DESIGN.md)
+    out_lines.append(" ".join(str(x) for x in a))
+    _print(*a)
+
+
+print("Source: `%s/` (kernel_times_alone.txt, bench.json, sq_counters.json, pmc_traffic.json); regenerate with `python tools/design_table.py %s --update`.\n" % (d.rstrip("/"), d.rstrip("/")))
 print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | traffic MB / launch (fetch + write) |")
 print("|---|---|---|---|---|---|---|---|---|")
 tot = 0.0
@@ -42,3 +54,12 @@ for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1])
         "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), tr))
 print("\nkernels alone per batch: %.0f µs; delivered: %.3f ms per batch (steady state %.0f frames/s)" % (
     tot, bench["host"]["ms_per_batch"] if "host" in bench else bench["ms_per_step"], bench.get("steady_state_fps", 0)))
+
+if "--update" in sys.argv:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "DESIGN.md")
+    text = open(path).read()
+    a, b = "<!-- KERNEL_TABLE_BEGIN -->", "<!-- KERNEL_TABLE_END -->"
+    i, j = text.index(a) + len(a), text.index(b)
+    open(path, "w").write(text[:i] + "\n" + "\n".join(out_lines) + "\n" + text[j:])
+    _print("DESIGN.md updated")
