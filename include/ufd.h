@@ -359,6 +359,26 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
 int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, size_t cap_i16, uint32_t* n_i16,
                                 uint32_t* w, uint32_t* h);
 
+/* The launch plan of the network alone (no GPU needed): what ufd_create would issue for `variant` at `max_batch` under
+ * `flags` -- per conv layer of SURVEY 8.1 how it runs (kind: 0 pointwise, 1 dw->pw, 2 second block of a chained pair,
+ * 3 depthwise computed inside the next launch, 4 dense 3x3, 5 direct), whether it issues a launch of its own at its turn,
+ * rides in another layer's grid (`ride`), is computed inside a later launch (`chained`), which tensors it reads and writes;
+ * per activation tensor its place in the arena (float offset and size for the whole batch), the turns it is first written
+ * and last read (52 = until the head decode) and whether it has storage at all.  *n_layers / *n_tensors receive the full
+ * counts; at most the caps are written.  The CPU test suite checks on this that no two tensors share arena bytes while
+ * both are live, for every combination of the plan flags. */
+typedef struct ufd_plan_layer {
+  char name[24];
+  int32_t kind, leader, ride, chain_first, fused_dw, chained, materialize, launches, rfb_tail;
+  int32_t in_tensor, out_tensor, out_coff, tap_tensor;
+} ufd_plan_layer;
+typedef struct ufd_plan_tensor {
+  uint64_t off_floats, size_floats;
+  int32_t c, h, w, first, last, stored;
+} ufd_plan_tensor;
+int ufd_debug_plan(uint32_t variant, uint32_t max_batch, uint32_t flags, ufd_plan_layer* layers, uint32_t layer_cap, uint32_t* n_layers,
+                   ufd_plan_tensor* tensors, uint32_t tensor_cap, uint32_t* n_tensors, uint64_t* arena_floats);
+
 /* get_model alone (nn.rs:143-175; no GPU needed): parse an UltraFace-RFB .onnx into the packed
  * blob (273 888 floats) and, if the graph embeds them, the K*4 priors (*priors_found = 1). */
 int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size_t weights_cap, float* priors,

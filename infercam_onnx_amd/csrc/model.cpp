@@ -61,6 +61,11 @@ inline uint64_t now_ns() {
 struct Tensor {
   size_t off = 0;  // float offset in the activation arena (for the whole batch)
   int c = 0, h = 0, w = 0;
+  // liveness in the issued plan, in layer turns: written at `first` (kNumConv: no launch writes it, it has no storage),
+  // read last at `last` (kNumConv: until the head decode); ufd_debug_plan reports them, the CPU suite checks that no two
+  // tensors share arena bytes while both are live
+  int first = 0, last = -1;
+  bool stored = false;
   size_t per_frame() const { return (size_t)c * h * w; }
 };
 
@@ -815,6 +820,7 @@ void plan_tensors(ufd_model* m, bool keep_all) {
         if (last[u] == i && allocated[u])  // (a tensor no launch writes -- the RFB concat under k_rfb_tail -- has no storage to give back)
           free_list.push_back({m->tensors[u].off, align(m->tensors[u].per_frame() * m->B)});
   }
+  for (int u = 0; u < nt; u++) m->tensors[u].first = first[u], m->tensors[u].last = last[u], m->tensors[u].stored = allocated[u];
   m->arena_floats = top;
 }
 
@@ -3009,6 +3015,39 @@ int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, 
     if (cap_i16 < d.coef_total) return UFD_E_ARG;
     st = jpeg_decode_coefficients(jpeg, len, &d, coef, cap_i16);
     return st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : UFD_E_UNSUPPORTED);
+  } catch (...) {
+    return UFD_E_DEVICE;
+  }
+}
+
+int ufd_debug_plan(uint32_t variant, uint32_t max_batch, uint32_t flags, ufd_plan_layer* layers, uint32_t layer_cap, uint32_t* n_layers,
+                   ufd_plan_tensor* tensors, uint32_t tensor_cap, uint32_t* n_tensors, uint64_t* arena_floats) {
+  if ((variant != 640 && variant != 320) || !max_batch || !n_layers || !n_tensors) return UFD_E_ARG;
+  try {
+    std::unique_ptr<ufd_model> m(new ufd_model());
+    m->cfg.variant = variant, m->cfg.flags = flags, m->cfg.max_batch = max_batch;
+    m->W = variant == 640 ? 640 : 320, m->H = variant == 640 ? 480 : 240;
+    m->B = max_batch;
+    plan_tensors(m.get(), (flags & UFD_FLAG_KEEP_LAYERS) != 0);
+    *n_layers = (uint32_t)m->layers.size(), *n_tensors = (uint32_t)m->tensors.size();
+    if (arena_floats) *arena_floats = m->arena_floats;
+    for (uint32_t i = 0; i < *n_layers && i < layer_cap && layers; i++) {
+      const Layer& L = m->layers[i];
+      ufd_plan_layer& o = layers[i];
+      std::memset(&o, 0, sizeof(o));
+      std::snprintf(o.name, sizeof(o.name), "%s", L.spec.name);
+      o.kind = (int32_t)L.kind, o.leader = L.leader, o.ride = L.ride, o.chain_first = L.chain_first, o.fused_dw = L.fused_dw;
+      o.chained = L.chained ? 1 : 0, o.materialize = L.materialize ? 1 : 0;
+      o.in_tensor = L.in_tensor, o.out_tensor = L.out_tensor, o.out_coff = L.out_coff, o.tap_tensor = L.tap_tensor;
+      // issues a launch of its own at its turn: not computed inside another launch, not a non-leading member, not a rider
+      o.launches = !(L.kind == kKindFusedAway && !L.materialize) && !L.chained && L.leader == (int)i && L.ride < 0;
+      if ((int)i == kRfbShortcut && m->rfb_tail) o.rfb_tail = 1;
+    }
+    for (uint32_t t = 0; t < *n_tensors && t < tensor_cap && tensors; t++) {
+      const Tensor& T = m->tensors[t];
+      tensors[t] = ufd_plan_tensor{(uint64_t)T.off, (uint64_t)T.per_frame() * max_batch, T.c, T.h, T.w, T.first, T.last, T.stored ? 1 : 0};
+    }
+    return UFD_OK;
   } catch (...) {
     return UFD_E_DEVICE;
   }

@@ -99,6 +99,17 @@ class UfdKernelStat(ctypes.Structure):
                 ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
 
 
+class UfdPlanLayer(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 24)] + [(n, ctypes.c_int32) for n in (
+        "kind", "leader", "ride", "chain_first", "fused_dw", "chained", "materialize", "launches", "rfb_tail", "in_tensor",
+        "out_tensor", "out_coff", "tap_tensor")]
+
+
+class UfdPlanTensor(ctypes.Structure):
+    _fields_ = [("off_floats", ctypes.c_uint64), ("size_floats", ctypes.c_uint64)] + [(n, ctypes.c_int32) for n in (
+        "c", "h", "w", "first", "last", "stored")]
+
+
 class UfdHostStats(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("num_ctx", ctypes.c_uint32), ("batches", ctypes.c_uint64),
                 ("launches", ctypes.c_uint64), ("wall_ms", ctypes.c_double), ("plan_ms", ctypes.c_double),
@@ -120,7 +131,7 @@ ABI_SYMBOLS = (
     "ufd_sched_flush", "ufd_sched_get_stats", "ufd_sched_debug_plan",
     "ufd_create_replicas", "ufd_model_placement", "ufd_annotate_parity", "ufd_model_host_alloc", "ufd_sched_debug_table",
     "ufd_host_stats_reset", "ufd_host_stats_read", "ufd_sched_stream_replica", "ufd_sched_get_replica_stats",
-    "ufd_sched_push_batch",
+    "ufd_sched_push_batch", "ufd_debug_plan",
 )
 
 _lib = None
@@ -199,10 +210,26 @@ def load_library():
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
+    L.ufd_debug_plan.argtypes = [u32, u32, u32, ctypes.POINTER(UfdPlanLayer), u32, pu32, ctypes.POINTER(UfdPlanTensor), u32, pu32,
+                                 ctypes.POINTER(ctypes.c_uint64)]
     L.ufd_host_stats_reset.argtypes = [vp]
     L.ufd_host_stats_read.argtypes = [vp, ctypes.POINTER(UfdHostStats)]
     _lib = L
     return L
+
+
+def debug_plan(variant, max_batch, flags=0):
+    """The launch plan of the network alone (ufd_debug_plan; no GPU needed): -> (layers, tensors, arena_floats) as dicts."""
+    L = load_library()
+    layers, tensors = (UfdPlanLayer * 64)(), (UfdPlanTensor * 128)()
+    nl, nt, arena = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+    rc = L.ufd_debug_plan(int(variant), int(max_batch), int(flags), layers, 64, ctypes.byref(nl), tensors, 128, ctypes.byref(nt),
+                          ctypes.byref(arena))
+    if rc:
+        raise UfdError(rc, "ufd_debug_plan")
+    ls = [dict(name=layers[i].name.decode(), **{f: getattr(layers[i], f) for f, _ in UfdPlanLayer._fields_[1:]}) for i in range(nl.value)]
+    ts = [{f: getattr(tensors[i], f) for f, _ in UfdPlanTensor._fields_} for i in range(nt.value)]
+    return ls, ts, arena.value
 
 
 def jpeg_coefficients(jpeg):

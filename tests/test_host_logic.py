@@ -243,3 +243,57 @@ def test_create_replicas_argument_and_error_paths(weights):
         assert e.value.code == nn.UFD_E_DEVICE
     assert L.ufd_annotate_parity(0) == nn.UFD_PARITY_LABELS_UNPINNED
     assert L.ufd_annotate_parity(nn.UFD_ANNOT_NO_TEXT | nn.UFD_ANNOT_MULTIPART) == nn.UFD_PARITY_EXACT
+
+
+# ---- the launch planner alone (ufd_debug_plan: no GPU) ----
+_PLAN_FLAGS = {"keep_layers": 1, "no_chain": 32, "no_rfb_sum": 64, "no_dual": 512, "no_rfb_tail": 2048}
+
+
+@pytest.mark.parametrize("variant", [320, 640])
+@pytest.mark.parametrize("flags", [0, 32, 64, 512, 2048, 32 | 64, 64 | 2048, 32 | 512 | 2048, 1])
+def test_planner_never_lets_two_live_tensors_share_arena_bytes(variant, flags):
+    """The arena recycles an activation buffer behind its last reader.  For every combination of the plan flags: tensors
+    whose arena ranges overlap have disjoint lifetimes (first write .. last read, in layer turns), every stored tensor lies
+    inside the arena, a tensor some launch reads has storage, and a tensor without storage is written by no launch.  (Round
+    4 found the one way this can go wrong on the GPU: the RFB concat under k_rfb_tail has no storage, and "giving it back"
+    behind its last reader handed live bytes to the next tensor -- detections of one frame per batch changed.)"""
+    from infercam_onnx_amd import nn
+
+    for batch in (1, 5, 32):
+        layers, tensors, arena = nn.debug_plan(variant, batch, flags)
+        assert len(layers) == 52
+        stored = [(i, t) for i, t in enumerate(tensors) if t["stored"]]
+        for i, t in stored:
+            assert t["size_floats"] == t["c"] * t["h"] * t["w"] * batch
+            assert t["off_floats"] + t["size_floats"] <= arena, (i, t, arena)
+            assert t["first"] < 52 and t["last"] >= t["first"] or t["last"] == -1, (i, t)
+        for a in range(len(stored)):
+            for b in range(a + 1, len(stored)):
+                (ia, ta), (ib, tb) = stored[a], stored[b]
+                overlap = ta["off_floats"] < tb["off_floats"] + tb["size_floats"] and tb["off_floats"] < ta["off_floats"] + ta["size_floats"]
+                if not overlap:
+                    continue
+                if flags & 1:  # keep_layers: nothing is recycled
+                    raise AssertionError("keep_layers plan: tensors %d and %d overlap" % (ia, ib))
+                # a buffer is reused only by a tensor first written AFTER the turn of its last reader
+                la, lb = max(ta["last"], ta["first"]), max(tb["last"], tb["first"])
+                assert la < tb["first"] or lb < ta["first"], "tensors %d %s and %d %s are live together on the same bytes" % (ia, ta, ib, tb)
+        for li, L in enumerate(layers):
+            out = tensors[L["out_tensor"]]
+            computed_elsewhere = L["chained"] or (L["kind"] == 3 and not L["materialize"])
+            if not computed_elsewhere:
+                assert out["stored"], (li, L, out)  # what a launch writes has storage ...
+                if L["in_tensor"] >= 0:
+                    assert tensors[L["in_tensor"]]["stored"] or L["kind"] in (1, 2), (li, L)  # ... and so has what it reads
+            assert L["launches"] == int(not computed_elsewhere and L["leader"] == li and L["ride"] < 0)
+        launches = sum(L["launches"] for L in layers)
+        # 640: stem; m1->m2; m3->m4; m5; m6; RFB reduce stack, first 3x3s, b2 middle, tail; heads 0 (m8 rides); m9; m10; heads 1
+        # (m11 rides); m12; heads 2 (extra.0 rides); extra.2 dw; extra.2 pw; heads 3.  320: its 8x10 maps (W = 10 is not a
+        # multiple of 4) keep m11 ... heads 2 as depthwise + pointwise launches.
+        if flags == 0:
+            assert launches == (18 if variant == 640 else 25) and sum(L["rfb_tail"] for L in layers) == 1, launches
+            gone = [li for li, L in enumerate(layers) if L["tap_tensor"] < 0]
+            for li in (2, 6, 15, 18, 22, 23):  # m1.pw, m3.pw (chained), the dilated RFB convs and rfb.linear (inside k_rfb_tail)
+                assert li in gone, (li, gone)
+        if flags == 2048:
+            assert launches == (19 if variant == 640 else 26) and not any(L["rfb_tail"] for L in layers)
