@@ -29,6 +29,7 @@
 #include <sched.h>
 
 #include <fstream>
+#include <functional>
 
 #include "../../include/ufd.h"
 #include "jpeg_host.hpp"
@@ -323,6 +324,7 @@ struct ufd_model {
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool rfb_tail = false;              // the three dilated RFB convs + the summed 1x1 run as ONE launch (k_rfb_tail)
+  bool plan_parallel = false;         // UFD_PLAN_PARALLEL=1 at ufd_create: header scan + staging copy on the pool (A/B knob)
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   std::vector<float*> tap_buf;        // UFD_FLAG_TAP_LAYERS: per tensor, a copy taken right after its producing launch
 
@@ -1558,7 +1560,21 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   DevicePlan p;
   HostScope hs(m, "host_plan");
   const uint64_t t_plan0 = now_ns();
-  tl_pool->parallel_for(count, [&](unsigned i) {
+  // The header scan is 4 us per frame and the staging copy 1-2 us (35 KB): a batch of 32 is 0.2 ms on the issuing worker
+  // itself, deterministically.  Handing it to the pool (round 3) is faster on a quiet host -- 40-60 us -- but every
+  // parallel_for wakes sleeping threads and waits for the LAST of them: on a host whose CPUs are busy elsewhere (eight
+  // ranks and other tenants on one box) the same two calls took 240 + 140 us per batch, the context's stream sat idle
+  // 480 us between batches and the frame rate fell from 53 k to 43 k (profiles/r4z/bench_driver_flags.json: `host`).  The
+  // pool is used only when the batch's bytes make the copy worth it (large frames).
+  size_t batch_bytes = 0;
+  for (uint32_t i = 0; i < count; i++) batch_bytes += lens[i];
+  const bool use_pool = m->plan_parallel || batch_bytes > ((size_t)8 << 20);
+  auto for_each_frame = [&](const std::function<void(unsigned)>& fn) {
+    if (use_pool) tl_pool->parallel_for(count, fn);
+    else
+      for (uint32_t i = 0; i < count; i++) fn(i);
+  };
+  for_each_frame([&](unsigned i) {
     JpegFrameDesc* d = &s.h_descs[i];
     // (no lookup tables yet: frames of a camera stream share their DHT bytes, found below by key)
     int st = (jpegs[i] && lens[i]) ? jpeg_plan_gpu_scan(jpegs[i], lens[i], d, &s.plans[i], /*build_luts=*/false) : kJpegCorrupt;
@@ -1626,7 +1642,7 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   }
   if (p.blob_base + blob_fill > m->stage_cap) return p;
   const uint64_t t_copy0 = now_ns();
-  tl_pool->parallel_for(count, [&](unsigned i) {
+  for_each_frame([&](unsigned i) {
     if (s.st[i] == kJpegOk) std::memcpy(s.h_blob + s.h_scans[i].blob_off, jpegs[i], lens[i]);
   });
   if (tl_worker) {
@@ -2307,6 +2323,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->max_w = std::max<uint32_t>(m->max_w, m->W);
   m->max_h = std::max<uint32_t>(m->max_h, m->H);
   m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
+  if (const char* e = std::getenv("UFD_PLAN_PARALLEL")) m->plan_parallel = std::atoi(e) != 0;
   unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   m->host_threads = threads;
 #define HIPB(expr)                                                                      \
