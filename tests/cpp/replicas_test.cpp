@@ -3,9 +3,15 @@
 // No Python, no torch in this process: exactly the environment of the reference's Rust binary.
 //   usage: replicas_test <weights.f32> <frame.jpg> [max devices]
 // Prints, per replica, "replica <i> dev <id> pci <bdf> numa <node> cpus <n> dets <count> <x_tl> <y_tl> <x_br> <y_br> <conf> ..."
-// (the caller compares with the oracle) and "ok".
+// (the caller compares with the oracle).  Then the rest of the server's shape: ONE scheduler over the replicas
+// (ufd_sched_config.models_320[n]; router.rs:64-71 pushing into it), 2 n + 1 camera streams placed stream i -> GPU i mod n,
+// a few frames pushed to each; every delivered frame must carry its stream's replica and the first replica's detections.
+// Prints "sched streams <s> frames <f> per-replica <f0> <f1> ..." and "ok".
+#include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iterator>
 #include <string>
@@ -16,6 +22,22 @@
 static std::vector<uint8_t> slurp(const std::string& p) {
   std::ifstream f(p, std::ios::binary);
   return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+struct Sink {
+  std::atomic<uint32_t> frames{0}, bad{0};
+  uint32_t n_replicas = 0, expect_n = 0;
+  std::vector<ufd_det> expect;
+};
+static void on_result(void* user, const ufd_frame_result* r) {  // (called from one completion thread per replica)
+  Sink* s = static_cast<Sink*>(user);
+  bool ok = r->status == UFD_OK && r->variant == 320 && r->replica == (uint32_t)(r->stream_id % s->n_replicas) && r->n == s->expect_n;
+  for (uint32_t k = 0; ok && k < r->n; k++) {  // (a batch of two may pick other kernel instances than one frame: fp32 rounding)
+    const float *a = &r->dets[k].x_tl, *b = &s->expect[k].x_tl;
+    for (int c = 0; c < 5; c++) ok = ok && std::fabs(a[c] - b[c]) <= 1e-5f;
+  }
+  if (!ok) s->bad++;
+  s->frames++;
 }
 
 int main(int argc, char** argv) {
@@ -53,6 +75,50 @@ int main(int argc, char** argv) {
     std::printf("replica %d dev %d pci %s numa %d cpus %u dets %u", i, dev, bdf, node, ncpu, cnt);
     for (uint32_t k = 0; k < cnt; k++) std::printf(" %.9g %.9g %.9g %.9g %.9g", dets[k].x_tl, dets[k].y_tl, dets[k].x_br, dets[k].y_br, dets[k].conf);
     std::printf("\n");
+  }
+  // ---- one scheduler over the replicas
+  {
+    Sink sink;
+    sink.n_replicas = (uint32_t)n;
+    sink.expect.resize(4420);
+    if (ufd_infer_jpeg(hs[0], jpeg.data(), jpeg.size(), sink.expect.data(), 4420, &sink.expect_n, nullptr, nullptr) != UFD_OK) return 1;
+    ufd_sched_config sc{};
+    sc.struct_size = sizeof(sc);
+    sc.models_320 = hs.data(), sc.n_320 = (uint32_t)n, sc.placement = UFD_SCHED_PLACE_ROUND_ROBIN;
+    sc.ring_slots = 8, sc.max_wait_us = 500, sc.max_inflight = 3, sc.det_cap = 4420;
+    sc.on_result = on_result, sc.user = &sink;
+    ufd_sched* sched = nullptr;
+    if (ufd_sched_create(&sc, &sched) != UFD_OK) return std::printf("ufd_sched_create over %d replicas failed\n", n), 1;
+    const uint32_t streams = 2u * (uint32_t)n + 1u, per_stream = 6;
+    std::vector<uint32_t> handle(streams);
+    for (uint32_t i = 0; i < streams; i++) {
+      ufd_stream_config st{};
+      st.struct_size = sizeof(st), st.stream_id = i, st.variant = 320;
+      uint32_t where = 99;
+      if (ufd_sched_add_stream(sched, &st, &handle[i]) != UFD_OK || ufd_sched_stream_replica(sched, handle[i], &where) != UFD_OK ||
+          where != i % (uint32_t)n)
+        return std::printf("stream %u placed on %u\n", i, where), 1;
+    }
+    uint32_t pushed = 0;
+    for (uint32_t t = 0; t < per_stream; t++)
+      for (uint32_t i = 0; i < streams; i++) {
+        int prc;
+        while ((prc = ufd_sched_push(sched, handle[i], jpeg.data(), jpeg.size(), t)) == UFD_E_FULL) {
+        }  // (the router would drop: the test wants every frame run)
+        if (prc != UFD_OK) return std::printf("push: %d\n", prc), 1;
+        pushed++;
+      }
+    if (ufd_sched_flush(sched) != UFD_OK) return 1;
+    std::vector<ufd_sched_replica_stats> rs((size_t)n);
+    uint32_t nr = 0;
+    if (ufd_sched_get_replica_stats(sched, 320, rs.data(), (uint32_t)n, &nr) != UFD_OK || nr != (uint32_t)n) return 1;
+    ufd_sched_destroy(sched);
+    if (sink.frames != pushed || sink.bad != 0) return std::printf("sched: %u of %u frames, %u wrong\n", sink.frames.load(), pushed, sink.bad.load()), 1;
+    std::printf("sched streams %u frames %u per-replica", streams, pushed);
+    uint64_t sum = 0;
+    for (int i = 0; i < n; i++) std::printf(" %llu", (unsigned long long)rs[(size_t)i].frames), sum += rs[(size_t)i].frames;
+    std::printf("\n");
+    if (sum != pushed) return std::printf("per-replica counts do not add up\n"), 1;
   }
   for (auto* h : hs) ufd_destroy(h);
   std::printf("ok\n");

@@ -211,6 +211,10 @@ def test_create_replicas_runs_the_rccl_broadcast(tmp_path, oracle_lib, weights):
     assert len(ref) > 0
     lines = [l.split() for l in out.stdout.splitlines() if l.startswith("replica ")]
     assert len(lines) >= 1
+    # ... and ONE scheduler over those replicas delivered every frame of 2 n + 1 streams from its stream's replica (checked
+    # in the C++ process against the first replica's detections, which are checked against the oracle below)
+    sched = [l.split() for l in out.stdout.splitlines() if l.startswith("sched streams")]
+    assert len(sched) == 1 and int(sched[0][2]) == 2 * len(lines) + 1 and int(sched[0][4]) == 6 * (2 * len(lines) + 1), out.stdout
     for l in lines:
         cnt = int(l[11])
         got = np.array([float(v) for v in l[12:]], np.float32).reshape(cnt, 5)
