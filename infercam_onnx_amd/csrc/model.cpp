@@ -384,6 +384,18 @@ namespace {
       return (m)->fail(UFD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
+// ---------------------------------------------------------------- events behind copies
+// ROCm 7.2's runtime keeps ~2 KB of host memory for every event recorded DIRECTLY behind an asynchronous copy-engine
+// transfer on a stream and never gives it back: the host-bytes path grew 2.1 KB per batch, 12 GB per hour at 54 k frames/s
+// (tools/soak.py; reproduced on the runtime alone by tools/ubench/leak_probe2.hip: copy + hipEventRecord grows whether the
+// event is waited for by a stream or by the host, copy + hipStreamSynchronize does not, and neither does copy + any kernel
+// + hipEventRecord).  So an empty kernel goes between a copy and the event that marks it.
+__global__ void k_copy_fence() {}
+hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream) {
+  hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, stream);
+  return hipEventRecord(ev, stream);
+}
+
 // ---------------------------------------------------------------- profiling
 int prof_name_id(ufd_model* m, const std::string& name) {
   for (size_t i = 0; i < m->prof_names.size(); i++)
@@ -1346,7 +1358,7 @@ int fetch_streams(ufd_model* m, Slot& s) {
     {
       std::lock_guard<std::mutex> lk(m->copy_mu);
       HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, m->copy_stream));
-      HIPC(m, hipEventRecord(s.enc_copied, m->copy_stream));
+      HIPC(m, record_behind_copy(s.enc_copied, m->copy_stream));
     }
     HIPC(m, hipEventSynchronize(s.enc_copied));
   }
@@ -1709,7 +1721,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
         ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.copy_stream);
         HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.copy_stream));
-        HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
+        HIPC(m, record_behind_copy(c.ev_copied[buf], c.copy_stream));
       }
       HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
       span_begin(s);
@@ -1753,7 +1765,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
     HIPC(m, hipMemcpy2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
                              hipMemcpyHostToDevice, c.copy_stream));
   }
-  HIPC(m, hipEventRecord(c.ev_copied[buf], c.copy_stream));
+  HIPC(m, record_behind_copy(c.ev_copied[buf], c.copy_stream));
   HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
   span_begin(s);
   return UFD_OK;

@@ -1,0 +1,80 @@
+"""Soak: the bench's submit / wait loop for a given time with the host and device memory of the process sampled -- leaks in
+the per-batch paths (event pools, table-set caches, staging) show as growth.  Every 50th batch carries a few corrupt frames
+and a stream with other Huffman tables, so the error and cache paths run too.
+Usage: python tools/soak.py [seconds] [clean] [spin] [staged] [hostentropy] [annot]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from infercam_onnx_amd import nn, synth
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+opts = sys.argv[2:]
+B = 32
+weights, pri = synth.synthetic_weights(), synth.gen_priors(640, 480)
+m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=pri, max_batch=B, max_src=(640, 480), det_cap=256,
+                      extra_flags=nn.UFD_FLAG_SPIN_WAIT if "spin" in opts else 0, host_entropy="hostentropy" in opts)
+jp = synth.synth_jpeg_pool(0, 192, 640, 480, quality=90, subsampling="4:2:0")
+odd = [synth.encode_jpeg(synth.synth_frame(7, i, 640, 480), optimize=True, quality=60 + i) for i in range(8)]  # per-frame optimised tables
+batches = [m._prep_batch(jp[i * B:(i + 1) * B]) for i in range(6)]
+bad = list(jp[:B])
+for k in (3, 11, 19):
+    bad[k] = bad[k][: len(bad[k]) // 2]
+for k in range(8):
+    bad[20 + k] = odd[k]
+batches.append(m._prep_batch(bad))
+if "staged" in opts:
+    batches = [m.stage_jpeg_batch(jp[i * B:(i + 1) * B]) for i in range(6)] + [batches[6]]
+if "annot" in opts:  # the whole Inferer::run iteration: + rectangles, labels, re-encode, streams copied back
+    batches = [m.prep_annotate_batch(jp[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=640 * 480) for i in range(7)]
+submit = (lambda b: m.submit_annotate_batch(b) if getattr(b, "annot", None) is not None else
+          (m.submit_staged(b) if getattr(b, "staged", None) else m.submit_jpeg_batch(b)))
+
+
+def rss_mb():
+    for ln in open("/proc/self/status"):
+        if ln.startswith("VmRSS"):
+            return int(ln.split()[1]) / 1024.0
+
+
+def gpu_used_mb():
+    free, total = torch.cuda.mem_get_info(0)
+    return (total - free) / 1e6
+
+
+inflight, n, t0, last = [], 0, time.time(), time.time()
+first = None
+while time.time() - t0 < secs:
+    if len(inflight) >= 6:
+        m.wait(inflight.pop(0), collect=False)
+    k = 6 if n % 50 == 49 and not any(b is batches[6] for b in [m._pending[t] for t in inflight]) else n % 6
+    if any(m._pending[t] is batches[k] for t in inflight):
+        m.wait(inflight.pop(0), collect=False)
+        continue
+    if "clean" in opts and k == 6:
+        k = 0
+        if any(m._pending[t] is batches[k] for t in inflight):
+            m.wait(inflight.pop(0), collect=False)
+            continue
+    inflight.append(submit(batches[k]))
+    n += 1
+    if time.time() - last > min(10, secs / 4):
+        last = time.time()
+        rec = (n, rss_mb(), gpu_used_mb())
+        first = first or rec
+        print("batches %7d  rss %8.1f MB  gpu %9.1f MB" % rec, flush=True)
+for t in inflight:
+    m.wait(t, collect=False)
+end = (n, rss_mb(), gpu_used_mb())
+print("soak: %d batches in %.0f s; rss %+0.1f MB, gpu %+0.1f MB since the first sample" % (n, time.time() - t0, end[1] - first[1], end[2] - first[2]))
+hs = m.host_stats()
+print("host:", hs["per_batch_us"], hs["gpu_span_share"])
+m.close()
+per_batch = (end[1] - first[1]) * 1048576.0 / max(n - first[0], 1)
+print("host memory per batch: %.0f bytes" % per_batch)
+ok = per_batch < 300 and abs(end[2] - first[2]) < 64  # (round 4's runtime leak was 2.1 KB per batch)
+print("ok" if ok else "GROWTH")
+sys.exit(0 if ok else 1)
