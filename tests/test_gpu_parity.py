@@ -830,15 +830,23 @@ def test_table_set_and_tap_caches_evict(weights, oracle_lib):
     model = make_model(320, weights, max_batch=4, profile=True)
     try:
         rng = np.random.default_rng(8)
+        early = []
         for k in range(80):  # optimize=True: Huffman tables fitted to each frame
             w, h = 64 + 8 * (k % 40), 48 + 8 * ((k * 7) % 23)
             rgb = synth.synth_frame(500 + k, k, w, h)
             rgb = np.clip(rgb.astype(np.int16) + rng.integers(-40, 40, rgb.shape), 0, 255).astype(np.uint8)
             j = synth.encode_jpeg(rgb, quality=60 + k % 35, optimize=True)
             assert np.array_equal(model.debug_decode_jpeg(j), oracle_lib.jpeg_decode_rgb(j)), k
+            if k < 12:
+                early.append(j)
             if k % 8 == 0:
                 got = dets_array(model.infer_jpeg(j))
                 assert_dets_match(got, oracle_lib.infer_jpeg(j, 320, 240, weights, synth.gen_priors(320, 240)), what="evict %d" % k)
+        # streams whose table set has been evicted meanwhile come back (round 4: sets are found by the key of their DHT bytes;
+        # a key whose set was replaced must miss, the tables be rebuilt and the key point at the new slot), twice over
+        for rep in range(2):
+            for k, j in enumerate(early):
+                assert np.array_equal(model.debug_decode_jpeg(j), oracle_lib.jpeg_decode_rgb(j)), ("back", rep, k)
         names = {p["name"] for p in model.profile_read() if p["launches"]}
         assert any(n.startswith("huff_write") for n in names), names  # the device entropy path stayed in use
     finally:
