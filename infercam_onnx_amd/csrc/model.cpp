@@ -1,388 +1,26 @@
-// model.cpp -- host side of libufacehip.so: the C ABI of include/ufd.h and the per-batch
-// pipeline that replaces the reference's single Inferer task (infer_server/src/inferer.rs:29-50):
-//   host workers: marker parse + Huffman decode -> coefficient slabs in pinned memory
-//   GPU (one HIP stream per handle): IDCT -> upsample/colour(+normalise) [-> Triangle resize]
-//        -> 52 convolutions -> softmax/prior decode/threshold -> sort + greedy NMS
-//   D2H: a few hundred bytes of detections per frame.
-// Weights (1.1 MB) and priors stay resident in HBM for the life of the handle.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <array>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <thread>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include <pthread.h>
-#include <time.h>
-#include <sched.h>
-
-#include <fstream>
-#include <functional>
-
-#include "../../include/ufd.h"
-#include "jpeg_host.hpp"
-#include "kernels.hpp"
-#include "onnx_loader.hpp"
-#include "thread_pool.hpp"
-#include "topology.hpp"
-#include "model_internal.hpp"
+// model.cpp -- host side of libufacehip.so: the C ABI of include/ufd.h and the per-batch pipeline that replaces the
+// reference's single Inferer task (infer_server/src/inferer.rs:29-50).  A handle owns three device contexts (a compute
+// stream and a working set each; one shared copy stream) and an issue worker per context:
+//   worker: header + marker scan of the batch's JPEGs, their bytes into one pinned block, one H2D, then every launch --
+//           device entropy decoding -> IDCT -> upsample / colour / normalise (fused into the stem) [-> Triangle resize] ->
+//           the network (plan.cpp) -> softmax / prior decode / threshold -> sort + greedy NMS [-> rectangles + re-encode]
+//   ufd_wait: a few hundred bytes of detections per frame come back (and the annotated streams).
+// Weights (1.1 MB) and priors stay resident in HBM for the life of the handle.  State and shared helpers: model_types.hpp.
+#include "model_types.hpp"
 
 namespace ufd {
-namespace {
-
 thread_local std::string g_create_error;
-
-struct Ctx;
-// Per-thread view of the handle: API threads use context 0 and the handle's pool; each context's
-// worker thread uses its own context and pool.
 thread_local Ctx* tl_cur = nullptr;
 thread_local ThreadPool* tl_pool = nullptr;
 thread_local bool tl_prof = true;  // record kernel events for the batch being issued by this thread
 thread_local bool tl_force_rider = false;  // enqueue_layer_launch: issue a riding layer on its own (its host could not take it)
-struct Worker;
 thread_local Worker* tl_worker = nullptr;  // issue worker this thread is (host statistics go to it), or null on API threads
 thread_local uint64_t tl_launches = 0;     // launches + copies enqueued by this thread (ProfScope counts them)
-
-inline uint64_t now_ns() {
-  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-struct Tensor {
-  size_t off = 0;  // float offset in the activation arena (for the whole batch)
-  int c = 0, h = 0, w = 0;
-  // liveness in the issued plan, in layer turns: written at `first` (kNumConv: no launch writes it, it has no storage),
-  // read last at `last` (kNumConv: until the head decode); ufd_debug_plan reports them, the CPU suite checks that no two
-  // tensors share arena bytes while both are live
-  int first = 0, last = -1;
-  bool stored = false;
-  size_t per_frame() const { return (size_t)c * h * w; }
-};
-
-enum LayerKind {
-  kKindPointwise,  // 1x1 on fp32 MFMA
-  kKindDwPw,       // 1x1 whose depthwise producer is fused in (the dw layer itself is kKindFusedAway)
-  kKindDwPw2,      // second 1x1 of two chained dw->pw blocks run as one launch (Layer::chain_first)
-  kKindFusedAway,  // depthwise layer computed inside the following kKindDwPw launch
-  kKindConv3x3,    // dense 3x3 implicit GEMM on fp32 MFMA
-  kKindDirect,     // VALU fallback
-};
-
-struct Layer {
-  ConvSpec spec;
-  int ih, iw, oh, ow;
-  int in_tensor, out_tensor, res_tensor;
-  int out_coff;
-  LayerKind kind;
-  int fused_dw = -1;       // kKindDwPw / kKindDwPw2: index of the depthwise layer
-  int chain_first = -1;    // kKindDwPw2: the kKindDwPw layer of the first block
-  bool chained = false;    // kKindDwPw layer computed inside a later kKindDwPw2 launch: its output never exists
-  int leader = -1;         // first layer of the launch this layer is issued in (itself when not merged)
-  int rider = -1;          // leader only: leader of an independent launch that rides in this one's grid (dual launch)
-  int ride = -1;           // leader only: the launch it rides in (issued at that layer's turn, not at its own)
-  int group[3] = {-1, -1, -1};  // leader only: members of its launch (itself first)
-  bool materialize = true; // kKindFusedAway: also run the stand-alone kernel (KEEP_LAYERS debugging)
-  const float* d_w = nullptr;  // kernel-specific packing
-  const float* d_w_rows = nullptr;    // dense 3x3 layers: packing of the row kernel
-  const float* d_w_dwpack = nullptr;  // depthwise layers: [c][12] image for the fused dw->pw kernel
-  int sum_with = -1;                  // pointwise layer whose 1x1 conv is summed into this launch (RFB shortcut + ConvLinear)
-  int stack[3] = {-1, -1, -1};        // 1x1 convs of the same input run as ONE conv with their output channels stacked (itself first)
-  int in_coff = 0;                    // this layer reads channels [in_coff, in_coff + cin) of its input tensor
-  const float* d_w_sum = nullptr;     // ... packed weights over both inputs' channels / the stacked output channels, and their bias
-  const float* d_b_sum = nullptr;
-  const float* d_w_tail = nullptr;    // RFB shortcut layer: ConvLinear + shortcut weights in k_rfb_tail's chunk order
-  const float* d_b = nullptr;
-  double bytes_per_frame = 0, flops_per_frame = 0, weight_bytes = 0;
-  int tap_tensor = -1, tap_coff = 0;  // where this layer's output lives in the issued plan (-1: it never exists)
-};
-
-struct ProfEntry {
-  int name_id;
-  hipEvent_t e0, e1;
-  double bytes, flops;
-};
-
-struct Slot {
-  bool busy = false;
-  bool waiting = false;  // a ufd_wait is finishing this slot outside the handle lock (guarded by ufd_model::mu)
-  bool relaxed_wait = false;  // ufd_wait found other batches in flight behind this one: sleep between polls instead of spinning
-  uint32_t ticket = 0, count = 0, cap = 0;
-  JpegFrameDesc* h_descs = nullptr;
-  int16_t* h_coef = nullptr;
-  Det* h_dets = nullptr;
-  Det* d_dets = nullptr;  // [B][K] detections of this slot's batch: stays valid until the slot is released (tail reads at ufd_wait)
-  uint32_t* h_ndet = nullptr;
-  uint32_t* h_gpu_status = nullptr;  // per frame: device entropy decoder flagged a corrupt stream
-  // One pinned block per slot, copied to the device with ONE hipMemcpyAsync:
-  //   [frame descriptors][scan layouts][restart intervals (n_iv)][JPEG bytes, frames packed back to back]
-  uint8_t* h_stage = nullptr;
-  uint8_t* h_blob = nullptr;        // = h_stage + blob_base of the batch (set by plan_device_entropy)
-  HuffScan* h_scans = nullptr;
-  HuffInterval* h_ivs = nullptr;
-  std::vector<GpuScanPlan> plans;
-  bool gpu_entropy = false;
-  bool coef_zigzag = false;  // the slabs hold zigzag-ordered blocks (self-synchronising decoder)
-  ufd_det* out = nullptr;
-  uint32_t* n = nullptr;
-  int32_t* status = nullptr;
-  std::vector<int32_t> st;
-  hipEvent_t done = nullptr;
-  Ctx* ctx = nullptr;  // context whose stream produced this slot's results
-  // asynchronous submission: the context's worker thread issues the batch
-  const uint8_t* const* job_jpegs = nullptr;
-  const size_t* job_lens = nullptr;
-  const ufd_staged* job_staged = nullptr;  // non-null: the batch is resident in HBM
-  bool job_prof = true;
-  // N1 (ufd_submit_annotate_batch): rectangles + re-encode after NMS.  The finished streams of the batch land in the
-  // slot's own device buffer (it stays valid until the slot is released: the host fetches them in ufd_wait, when
-  // their total size is known) -- the encoder's scratch belongs to the context.
-  bool annot = false, annot_ran = false;
-  ufd_annotate annot_args{};
-  uint8_t* d_enc_out = nullptr;
-  size_t enc_out_cap = 0;
-  uint32_t* d_enc_meta = nullptr;  // [B] length, [B] offset, [1] total
-  uint32_t* h_enc_meta = nullptr;  // pinned copy
-  hipEvent_t enc_copied = nullptr;
-  // host statistics: which pair of the context's span events this batch recorded (-1: none, e.g. nothing decodable)
-  int span_idx = -1;
-  uint64_t span_seq = 0;
-  int issue_rc = 0;          // result of the worker's entropy stage + enqueue
-  std::string issue_err;
-  int state = 0;             // 0 free, 1 queued for the worker, 2 issued to the GPU (guarded by Worker::mu)
-};
-
-struct Worker {
-  std::thread th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<Slot*> q;
-  bool stop = false;
-  Ctx* ctx = nullptr;
-  std::unique_ptr<ThreadPool> pool;
-  unsigned host_threads = 1;
-  // host statistics (ufd_host_stats_read): written by the worker thread only
-  std::atomic<uint64_t> ns_busy{0}, ns_plan{0}, ns_copy{0}, batches{0}, launches{0};
-};
-
-// Device-side working set of one in-flight batch.  A handle owns kNumCtx of them and alternates
-// batches between them: their kernels run on different HIP streams, so the latency-bound stages
-// of one batch (small feature maps, NMS) overlap the bandwidth-bound stages of the other.
-struct Ctx {
-  hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // the handle's one copy stream (shared by the contexts): H2D of the next batch overlaps kernels
-  float* d_arena = nullptr;
-  float* d_input = nullptr;
-  JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
-  int16_t* d_coef_buf[2] = {nullptr, nullptr};
-  // device entropy decoding: JPEG bytes, scan layouts and restart intervals of the batch
-  uint8_t* d_stage_buf[2] = {nullptr, nullptr};  // device image of Slot::h_stage (d_descs_buf points at its head)
-  uint8_t* d_sync = nullptr;  // scratch of the self-synchronising entropy decoder
-  const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 sample planes (fused stem)
-  SyncBuffers sync;
-  uint32_t* d_status = nullptr;
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool consumed_valid[2] = {false, false};
-  int flip = 0;
-  uint8_t* d_planes = nullptr;
-  uint8_t* d_rgb = nullptr;
-  float* d_scores = nullptr;
-  float* d_boxes = nullptr;
-  unsigned long long* d_keys = nullptr;
-  uint32_t* d_counts = nullptr;
-  uint32_t* d_ndet = nullptr;
-  float4* d_spill = nullptr;
-  unsigned long long* d_nms_mat = nullptr;  // suppression matrices of frames with many candidates
-  uint32_t last_forward_count = 0;
-  // host statistics: begin / end events of the last kSpanRing batches of this context (timing enabled).  Batch j uses pair
-  // j % kSpanRing; at most UFD_MAX_SLOTS batches are in flight, so pair j - 1 is still intact when batch j is finished.
-  static constexpr int kSpanRing = 2 * UFD_MAX_SLOTS;
-  hipEvent_t ev_span[kSpanRing][2] = {};
-  uint64_t span_issued = 0;    // batches that recorded a span (issue worker / API thread under the handle lock)
-  uint64_t span_last_done = 0; // 1 + sequence number of the last batch folded into the sums below (shared_mu)
-  uint64_t gpu_batches = 0;
-  double gpu_span_ms = 0, gpu_gap_ms = 0;
-  // N1 encoder scratch, sized for the largest frame an annotate batch of this context has had (regrown when a larger
-  // one arrives), and the (quality, framing) set-ups seen: quantiser + marker segments, each with its own device header,
-  // so that streams of one model that differ in quality or framing alternate without a stream drain
-  EncBuffers enc;
-  bool enc_ready = false;
-  size_t enc_mcus = 0;  // MCUs per frame the scratch holds
-  struct EncSetup {
-    int quality = -1, multipart = -1;
-    EncQuant q{};
-    bool ifast = true;
-    uint8_t* d_header = nullptr;
-    uint32_t pre_len = 0, hdr_len = 0, dim_off = 0, post_len = 0;
-    uint64_t last_use = 0;
-  };
-  static constexpr int kEncSetups = 4;
-  EncSetup enc_setups[kEncSetups];
-  int enc_cur = 0;  // set-up of the batch being issued
-  uint64_t enc_seq = 0;
-  uint32_t* d_enc_tables = nullptr;
-  JpegFrameDesc* d_enc_descs = nullptr;  // descriptors of frames that did not come out of the decoder (debug taps)
-  void* d_label_ops = nullptr;           // one drawing operation per detection of the batch
-  int* d_glyphs = nullptr;               // label glyph atlas (glyph_atlas.inc)
-  float* d_coverage = nullptr;
-};
-constexpr int kMaxCtx = 8;
-
-constexpr uint32_t kDetCopy = 256;  // detections per frame copied back with the batch
-
-struct TapsDev {
-  int32_t* left = nullptr;
-  int32_t* cnt = nullptr;
-  float* w = nullptr;
-  int stride = 0;
-};
-
-}  // namespace
 }  // namespace ufd
 
 using namespace ufd;
 
-struct ufd_model {
-  std::mutex mu;
-  std::string err;
-  ufd_config cfg{};
-  int W = 0, H = 0, K = 0;
-  uint32_t B = 0;
-  uint32_t max_w = 0, max_h = 0;
-  Ctx ctx[kMaxCtx];
-  Worker workers[kMaxCtx];
-  std::atomic<uint64_t> ns_wait{0}, waits{0};
-  uint64_t stats_t0 = 0;  // now_ns() of the last ufd_host_stats_reset (or of ufd_create)
-  int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s; each has its own stream pair
-  int next_ctx = 0;
-  std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
-  std::mutex err_mu;     // error string
-  std::mutex copy_mu;    // enqueue order on the shared copy stream
-  std::unique_ptr<ThreadPool> pool;
-  unsigned host_threads = 1;
-
-  // host placement: NUMA node of the GPU's PCIe root and the CPUs of it this process may use; the handle's issue
-  // workers and pool threads are pinned to them (8 ranks on a two-socket box must not stage JPEG bytes across sockets)
-  int numa_node = -1;
-  std::vector<int> pin_cpus;
-  std::string pci_bdf, cpu_list;
-
-  // resident model
-  size_t weight_img_floats = 0, priors_floats = 0;
-  float* d_weights = nullptr;
-  float* d_priors = nullptr;
-  float* d_lut = nullptr;
-  std::vector<Layer> layers;
-  std::vector<Tensor> tensors;
-  size_t arena_floats = 0;
-
-  // frame staging (device)
-  size_t coef_stride = 0, plane_stride = 0, rgb_stride = 0;
-
-  // post
-  size_t key_stride = 0;
-
-  // device entropy decoding: table sets seen so far (append-only, shared by the contexts)
-  // Huffman table sets seen so far (per-camera optimised tables make new ones).  A full cache evicts the set that has
-  // gone unused the longest, provided no batch that could still be in flight or staged refers to it.
-  static constexpr int kMaxLutSets = 64;
-  std::vector<std::array<HuffLut, 4>> lut_sets;
-  struct LutMeta {
-    uint64_t hash = 0, last_use = 0;  // content hash; plan sequence number of the last batch that used the set
-    uint32_t pins = 0;                // staged batches holding the set
-    uint32_t gen = 0;                 // bumped when the slot gets another set (stale key-cache entries then miss)
-  };
-  std::vector<LutMeta> lut_meta;
-  // Front cache of lut_sets keyed by what DETERMINES a table set -- the frame's DHT payload bytes + scan selectors
-  // (GpuScanPlan::key_bytes): a camera stream repeats them in every frame, and a hit means the frame's lookup tables
-  // are never built on the host at all (jpeg_plan_gpu_scan(build_luts = false), a quarter of the planning work).
-  struct LutKey {
-    uint64_t hash = 0;
-    std::vector<uint8_t> bytes;
-    int set = -1;
-    uint32_t gen = 0;
-  };
-  std::vector<LutKey> lut_keys;  // <= 2 * kMaxLutSets entries, replaced round-robin
-  size_t lut_key_next = 0;
-  uint64_t plan_seq = 0;
-  static constexpr size_t kMaxTapSets = 32;  // resize-tap tables kept (one per distinct source size)
-  std::map<std::pair<int, int>, uint64_t> taps_used;
-  SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
-  size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
-  size_t scans_off = 0, ivs_off = 0, stage_cap = 0;  // layout of the staging block (descriptors at 0)
-  hipStream_t copy_stream = nullptr;
-  uint32_t iv_cap = 0;      // restart intervals per batch
-  bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
-  bool rfb_tail = false;              // the three dilated RFB convs + the summed 1x1 run as ONE launch (k_rfb_tail)
-  bool plan_parallel = false;         // UFD_PLAN_PARALLEL=1 at ufd_create: header scan + staging copy on the pool (A/B knob)
-  bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
-  std::vector<float*> tap_buf;        // UFD_FLAG_TAP_LAYERS: per tensor, a copy taken right after its producing launch
-
-  Slot slots[UFD_MAX_SLOTS];
-  uint32_t next_ticket = 1;
-
-  std::map<std::pair<int, int>, std::pair<TapsDev, TapsDev>> taps;
-
-  // profiling
-  bool profile = false;
-  uint32_t prof_every = 1, prof_batch = 0;
-  std::vector<std::string> prof_names;
-  std::vector<ufd_kernel_stat> prof_stats;
-  std::vector<ProfEntry> prof_pending;
-  std::vector<hipEvent_t> prof_free;
-
-  int fail(int code, const std::string& msg) {
-    std::lock_guard<std::mutex> lk(err_mu);
-    err = msg;
-    return code;
-  }
-};
-
-struct DevicePlan {
-  bool ok = false;         // every decodable frame of the batch can take the device decoder
-  bool any_ok = false;
-  uint32_t n_iv = 0;       // intervals in h_ivs
-  size_t used_blob = 0, used_coef = 0;  // bytes of JPEG data in the packed blob; largest coefficient slab
-  size_t blob_base = 0;    // offset of the packed JPEG bytes inside the staging block
-  size_t stage_bytes = 0;  // bytes of the staging block to copy
-  uint32_t max_nsub = 0, max_bpm = 1;
-};
-
-
-// A batch whose JPEG bytes, frame descriptors and scan plans are resident in HBM
-// (ufd_stage_jpeg_batch): submitting it moves no input over PCIe.
-struct ufd_staged {
-  uint32_t count = 0;
-  DevicePlan plan;
-  std::vector<JpegFrameDesc> h_descs;
-  std::vector<HuffScan> h_scans;  // (which Huffman table sets the batch keeps pinned)
-  std::vector<int32_t> st;
-  uint8_t* d_stage = nullptr;  // device image of the staging block
-  uint8_t* d_blob = nullptr;
-  JpegFrameDesc* d_descs = nullptr;
-  HuffScan* d_scans = nullptr;
-  HuffInterval* d_ivs = nullptr;
-};
-
-
 namespace {
-
-#define HIPC(m, expr)                                                                                  \
-  do {                                                                                                 \
-    hipError_t e_ = (expr);                                                                            \
-    if (e_ != hipSuccess)                                                                              \
-      return (m)->fail(UFD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
-  } while (0)
 
 // ---------------------------------------------------------------- events behind copies
 // ROCm 7.2's runtime keeps ~2 KB of host memory for every event recorded DIRECTLY behind an asynchronous copy-engine
@@ -396,7 +34,10 @@ hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream) {
   return hipEventRecord(ev, stream);
 }
 
+}  // namespace
+
 // ---------------------------------------------------------------- profiling
+namespace ufd {
 int prof_name_id(ufd_model* m, const std::string& name) {
   for (size_t i = 0; i < m->prof_names.size(); i++)
     if (m->prof_names[i] == name) return (int)i;
@@ -418,61 +59,9 @@ hipEvent_t prof_event(ufd_model* m) {
   (void)hipEventCreate(&e);
   return e;
 }
+}  // namespace ufd
 
-struct ProfScope {
-  ufd_model* m;
-  ProfEntry pe;
-  bool on;
-  hipStream_t st;
-  ProfScope(ufd_model* mm, const std::string& name, double bytes, double flops, hipStream_t stream = nullptr)
-      : m(mm), on(mm->profile && tl_prof), st(stream ? stream : tl_cur->stream) {
-    tl_launches++;
-    if (!on) return;
-    {
-      std::lock_guard<std::mutex> lk(m->shared_mu);
-      pe.name_id = prof_name_id(m, name);
-      pe.e0 = prof_event(m);
-      pe.e1 = prof_event(m);
-    }
-    pe.bytes = bytes;
-    pe.flops = flops;
-    (void)hipEventRecord(pe.e0, st);
-  }
-  // the launch this scope was opened for did not happen: no sample, the events go back to the pool
-  void cancel() {
-    if (!on) return;
-    on = false;
-    std::lock_guard<std::mutex> lk(m->shared_mu);
-    m->prof_free.push_back(pe.e0);
-    m->prof_free.push_back(pe.e1);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(pe.e1, st);
-    std::lock_guard<std::mutex> lk(m->shared_mu);
-    m->prof_pending.push_back(pe);
-  }
-};
-
-// Host-side sections of the pipeline (header scan, staging copies, launch enqueue): wall time on the
-// issuing thread, reported beside the kernels as "host_*" entries (launches = batches).
-struct HostScope {
-  ufd_model* m;
-  const char* name;
-  bool on;
-  std::chrono::steady_clock::time_point t0;
-  HostScope(ufd_model* mm, const char* n) : m(mm), name(n), on(mm->profile && tl_prof) {
-    if (on) t0 = std::chrono::steady_clock::now();
-  }
-  ~HostScope() {
-    if (!on) return;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::lock_guard<std::mutex> lk(m->shared_mu);
-    auto& st = m->prof_stats[prof_name_id(m, name)];
-    st.launches++;
-    st.total_ms += ms;
-  }
-};
+namespace {
 
 void prof_flush(ufd_model* m) {
   std::lock_guard<std::mutex> lk(m->shared_mu);
@@ -489,468 +78,6 @@ void prof_flush(ufd_model* m) {
     m->prof_free.push_back(pe.e1);
   }
   m->prof_pending.clear();
-}
-
-// ---------------------------------------------------------------- model construction
-void gen_priors(int W, int H, std::vector<float>& out) {
-  // upstream generate_priors: float64 arithmetic, cast to f32, clamp to [0, 1]
-  out.clear();
-  for (int idx = 0; idx < 4; idx++) {
-    int fw = (W + kStrides[idx] - 1) / kStrides[idx], fh = (H + kStrides[idx] - 1) / kStrides[idx];
-    double shrink_w = (double)W / fw, shrink_h = (double)H / fh;
-    double scale_w = (double)W / shrink_w, scale_h = (double)H / shrink_h;
-    for (int j = 0; j < fh; j++)
-      for (int i = 0; i < fw; i++) {
-        double xc = (i + 0.5) / scale_w, yc = (j + 0.5) / scale_h;
-        for (int a = 0; a < kHeadAnchors[idx]; a++) {
-          double v[4] = {xc, yc, kMinBoxes[idx][a] / W, kMinBoxes[idx][a] / H};
-          for (double x : v) {
-            float f = (float)x;
-            out.push_back(f < 0.f ? 0.f : (f > 1.f ? 1.f : f));
-          }
-        }
-      }
-  }
-}
-
-// Liveness-based arena: every conv output gets [B][c][h][w]; buffers are recycled after their
-// last reader unless UFD_FLAG_KEEP_LAYERS asks to keep all of them for ufd_debug_layer_output.
-void plan_tensors(ufd_model* m, bool keep_all) {
-  const uint32_t flags = m->cfg.flags;
-  const ConvSpec* specs = conv_specs();
-  m->layers.resize(kNumConv);
-  m->tensors.clear();
-  std::vector<int> tensor_of(kNumConv, -1);
-  int cat_tensor = -1;
-  for (int i = 0; i < kNumConv; i++) {
-    Layer& L = m->layers[i];
-    L.spec = specs[i];
-    if (L.spec.src == -1) {
-      L.ih = m->H, L.iw = m->W;
-      L.in_tensor = -1;
-    } else if (L.spec.src == -2) {
-      L.ih = m->layers[kRfbCatA].oh, L.iw = m->layers[kRfbCatA].ow;
-      L.in_tensor = cat_tensor;
-    } else {
-      L.ih = m->layers[L.spec.src].oh, L.iw = m->layers[L.spec.src].ow;
-      L.in_tensor = tensor_of[L.spec.src];
-    }
-    L.oh = conv_out_dim(L.ih, L.spec);
-    L.ow = conv_out_dim(L.iw, L.spec);
-    if (L.spec.k == 1 && L.spec.groups == 1)
-      L.kind = kKindPointwise;
-    else if (L.spec.k == 3 && L.spec.groups == 1 && L.spec.cout <= 16 && L.spec.pad == L.spec.dil)
-      L.kind = kKindConv3x3;
-    else
-      L.kind = kKindDirect;
-    L.res_tensor = (i == kRfbShortcut) ? tensor_of[kRfbLinear] : -1;
-    L.out_coff = 0;
-    if (i == kRfbCatA || i == kRfbCatB || i == kRfbCatC) {
-      if (cat_tensor < 0) {
-        Tensor t;
-        t.c = 48, t.h = L.oh, t.w = L.ow;
-        m->tensors.push_back(t);
-        cat_tensor = (int)m->tensors.size() - 1;
-      }
-      L.out_tensor = cat_tensor;
-      L.out_coff = (i == kRfbCatA) ? 0 : (i == kRfbCatB ? 16 : 32);
-    } else {
-      Tensor t;
-      t.c = L.spec.cout, t.h = L.oh, t.w = L.ow;
-      m->tensors.push_back(t);
-      L.out_tensor = (int)m->tensors.size() - 1;
-    }
-    tensor_of[i] = L.out_tensor;
-    const double in_b = (double)L.spec.cin * L.ih * L.iw * 4, out_b = (double)L.spec.cout * L.oh * L.ow * 4;
-    L.weight_bytes = (double)(conv_weight_floats(L.spec) + L.spec.cout) * 4;
-    L.bytes_per_frame = in_b + out_b + (L.res_tensor >= 0 ? out_b : 0);
-    L.flops_per_frame = 2.0 * L.oh * L.ow * L.spec.cout * (L.spec.cin / L.spec.groups) * L.spec.k * L.spec.k;
-  }
-  // fuse every depthwise 3x3 into the pointwise conv that consumes it (its only consumer)
-  for (int i = 0; i + 1 < kNumConv; i++) {
-    Layer& D = m->layers[i];
-    Layer& P = m->layers[i + 1];
-    if (D.spec.groups == 1 || D.spec.groups != D.spec.cin || D.spec.k != 3 || D.spec.pad != 1 || D.spec.dil != 1 ||
-        !D.spec.relu)
-      continue;
-    if (P.kind != kKindPointwise || P.spec.src != i || P.res_tensor >= 0) continue;
-    ConvArgs probe{};
-    probe.ih = D.ih, probe.iw = D.iw, probe.oh = P.oh, probe.ow = P.ow, probe.cin = D.spec.cin;
-    if (!dwpw_supported(probe, D.spec.stride)) continue;
-    P.kind = kKindDwPw;
-    P.fused_dw = i;
-    D.kind = kKindFusedAway;
-    D.materialize = keep_all;
-    P.bytes_per_frame = (double)D.spec.cin * D.ih * D.iw * 4 + (double)P.spec.cout * P.oh * P.ow * 4;
-    P.flops_per_frame += D.flops_per_frame;
-    P.weight_bytes += D.weight_bytes;
-  }
-  // chain two dw->pw blocks into one launch where the tensor between them is the big one
-  // (m1 -> m2: 32 channels at half the input resolution) and nothing else reads it
-  if (!keep_all && !(flags & UFD_FLAG_NO_CHAIN)) {
-    for (int i = 0; i < kNumConv; i++) {
-      Layer& P2 = m->layers[i];
-      if (P2.kind != kKindDwPw) continue;
-      const Layer& D2 = m->layers[P2.fused_dw];
-      const int p1 = D2.spec.src;
-      if (p1 < 0 || m->layers[p1].kind != kKindDwPw || m->layers[p1].chained) continue;
-      Layer& P1 = m->layers[p1];
-      const Layer& D1 = m->layers[P1.fused_dw];
-      bool only_reader = true;
-      for (int j = 0; j < kNumConv; j++)
-        if (j != P2.fused_dw && m->layers[j].spec.src == p1) only_reader = false;
-      for (int h = 0; h < 4; h++)
-        if (kHeadCls[h] == p1 || kHeadReg[h] == p1) only_reader = false;
-      if (!only_reader || D1.spec.stride != 1 || D2.spec.stride != 2) continue;
-      ConvArgs f{}, g{};
-      f.cin = P1.spec.cin, f.cout = P1.spec.cout, f.ih = D1.ih, f.iw = D1.iw, f.oh = P1.oh, f.ow = P1.ow, f.relu = P1.spec.relu;
-      g.cin = P2.spec.cin, g.cout = P2.spec.cout, g.ih = D2.ih, g.iw = D2.iw, g.oh = P2.oh, g.ow = P2.ow;
-      if (!dwpw2_supported(f, g)) continue;
-      P2.kind = kKindDwPw2;
-      P2.chain_first = p1;
-      P1.chained = true;
-      P2.bytes_per_frame = (double)D1.spec.cin * D1.ih * D1.iw * 4 + (double)P2.spec.cout * P2.oh * P2.ow * 4;
-      P2.flops_per_frame += P1.flops_per_frame;
-      P2.weight_bytes += P1.weight_bytes;
-    }
-  }
-  // out = relu(ConvLinear(cat) + shortcut(x)) as ONE 1x1 conv over the channels of both inputs
-  // (weights side by side, biases summed): ConvLinear's output, written once and read back as the
-  // residual, never exists.  fp32 rounding apart from the two-launch form (one fma chain, not two).
-  if (!keep_all && !(flags & UFD_FLAG_NO_RFB_SUM)) {
-    Layer& S = m->layers[kRfbShortcut];
-    Layer& Lin = m->layers[kRfbLinear];
-    if (S.kind == kKindPointwise && Lin.kind == kKindPointwise && S.res_tensor == tensor_of[kRfbLinear] && S.oh == Lin.oh &&
-        S.ow == Lin.ow && S.spec.cout == Lin.spec.cout && (Lin.spec.cin & 1) == 0 && (S.spec.cin & 1) == 0) {
-      bool only_reader = true;
-      for (int j = 0; j < kNumConv; j++)
-        if (j != kRfbShortcut && m->layers[j].spec.src == kRfbLinear) only_reader = false;
-      if (only_reader) {
-        S.sum_with = kRfbLinear;
-        S.res_tensor = -1;
-        Lin.chained = true;
-        S.bytes_per_frame = ((double)Lin.spec.cin + S.spec.cin + S.spec.cout) * S.oh * S.ow * 4;
-        S.flops_per_frame += Lin.flops_per_frame;
-        S.weight_bytes += Lin.weight_bytes;
-      }
-    }
-  }
-  // RFB tail as ONE launch (k_rfb_tail, issued at the shortcut layer's turn): the three dilated 3x3 convs hand their
-  // results to the summed 1x1 in registers, the 48-channel concat tensor never exists.  The dilated layers become
-  // "chained" (no launch, no output of their own; ufd_debug_layer_output reports them absent in this plan).
-  m->rfb_tail = false;
-  if (!keep_all && !(flags & UFD_FLAG_NO_RFB_TAIL) && m->layers[kRfbShortcut].sum_with == kRfbLinear) {
-    const int dil_layers[3] = {kRfbCatA, kRfbCatB, kRfbCatC};
-    ConvArgs d3[3]{}, fin{};
-    bool ok = true;
-    for (int b = 0; b < 3; b++) {
-      const Layer& D = m->layers[dil_layers[b]];
-      ok = ok && D.kind == kKindConv3x3 && !D.chained;
-      d3[b].k = D.spec.k, d3[b].stride = D.spec.stride, d3[b].dil = D.spec.dil, d3[b].pad = D.spec.pad;
-      d3[b].cin = D.spec.cin, d3[b].cout = D.spec.cout, d3[b].relu = D.spec.relu;
-      d3[b].ih = D.ih, d3[b].iw = D.iw, d3[b].oh = D.oh, d3[b].ow = D.ow;
-    }
-    const Layer& S = m->layers[kRfbShortcut];
-    fin.k = 1, fin.cout = S.spec.cout, fin.cin = m->layers[kRfbLinear].spec.cin + S.spec.cin;
-    fin.in2_ctotal = S.in_tensor >= 0 ? m->tensors[S.in_tensor].c : 0;
-    fin.oh = S.oh, fin.ow = S.ow;
-    if (ok && rfb_tail_supported(d3, fin)) {
-      m->rfb_tail = true;
-      Layer& S2 = m->layers[kRfbShortcut];
-      for (int b = 0; b < 3; b++) {
-        Layer& D = m->layers[dil_layers[b]];
-        D.chained = true;
-        S2.flops_per_frame += D.flops_per_frame;
-        S2.weight_bytes += D.weight_bytes;
-      }
-    }
-  }
-  // The three RFB reduce convs (64 -> 8 each, same input) as ONE 64 -> 24 conv: one cout tile instead
-  // of three, the input read once; the consumers read channel slices of the stacked tensor.
-  if (!keep_all) {
-    static const int kStack[3] = {13, 16, 19};
-    Layer& A = m->layers[kStack[0]];
-    int cout_sum = 0;
-    bool ok = true;
-    for (int k = 0; k < 3; k++) {
-      const Layer& Bm = m->layers[kStack[k]];
-      ok = ok && Bm.kind == kKindPointwise && Bm.in_tensor == A.in_tensor && Bm.spec.cin == A.spec.cin && Bm.oh == A.oh &&
-           Bm.ow == A.ow && Bm.res_tensor < 0 && Bm.spec.relu == A.spec.relu && Bm.out_coff == 0 && !Bm.chained && Bm.sum_with < 0;
-      for (int h = 0; h < 4; h++) ok = ok && kHeadCls[h] != kStack[k] && kHeadReg[h] != kStack[k];
-      cout_sum += Bm.spec.cout;
-    }
-    if (ok && cout_sum <= 32) {
-      Tensor t;
-      t.c = cout_sum, t.h = A.oh, t.w = A.ow;
-      m->tensors.push_back(t);
-      const int stacked = (int)m->tensors.size() - 1;
-      int coff = 0;
-      for (int k = 0; k < 3; k++) {
-        Layer& Bm = m->layers[kStack[k]];
-        for (int j = 0; j < kNumConv; j++)
-          if (m->layers[j].in_tensor == Bm.out_tensor && m->layers[j].spec.src == kStack[k]) m->layers[j].in_tensor = stacked, m->layers[j].in_coff = coff;
-        Bm.tap_tensor = stacked, Bm.tap_coff = coff;
-        coff += Bm.spec.cout;
-        A.stack[k] = kStack[k];
-        if (k > 0) {
-          Bm.chained = true;
-          A.bytes_per_frame += (double)Bm.spec.cout * Bm.oh * Bm.ow * 4;
-          A.flops_per_frame += Bm.flops_per_frame;
-          A.weight_bytes += Bm.weight_bytes;
-        }
-      }
-      A.out_tensor = stacked;
-    }
-  }
-  // merged launches: layers with identical shapes whose inputs are ready at the leader's turn
-  for (int i = 0; i < kNumConv; i++) m->layers[i].leader = i, m->layers[i].group[0] = i, m->layers[i].group[1] = m->layers[i].group[2] = -1;
-  {
-    // (leader first: the launch is issued at the leader's turn, so a leader that is not the lowest
-    // index -- the RFB's dilated convs wait for the b2 branch -- delays the others to its turn)
-    static const int kGroups[][3] = {{13, 16, 19}, {14, 17, 20}, {22, 15, 18}, {26, 28, -1}, {36, 38, -1}, {44, 46, -1}, {50, 51, -1}};
-    for (const auto& g : kGroups) {
-      const Layer& A = m->layers[g[0]];
-      bool ok = !A.chained && A.stack[0] < 0;
-      for (int k = 1; k < 3 && g[k] >= 0; k++) {
-        ok = ok && !m->layers[g[k]].chained;
-        const Layer& Bm = m->layers[g[k]];
-        ok = ok && Bm.kind == A.kind && Bm.spec.cin == A.spec.cin && Bm.ih == A.ih && Bm.iw == A.iw && Bm.oh == A.oh &&
-             Bm.ow == A.ow && Bm.spec.k == A.spec.k && Bm.spec.stride == A.spec.stride &&
-             (Bm.spec.cout + 31) / 32 == (A.spec.cout + 31) / 32 && Bm.res_tensor < 0 && A.res_tensor < 0;
-        // dense 3x3 convs of stride 1 may differ in dilation (run-time dilation form of the row kernel)
-        const bool dil_free = A.kind == kKindConv3x3 && A.spec.stride == 1 && A.ow % 4 == 0 && Bm.spec.pad == Bm.spec.dil &&
-                              A.spec.pad == A.spec.dil && Bm.spec.dil <= 5 && A.spec.dil <= 5 && !keep_all;
-        ok = ok && (Bm.spec.dil == A.spec.dil || dil_free);
-        // one launch at the leader's turn: every member reads the same, already produced tensor, or
-        // a tensor whose producing launch comes before that turn
-        const int src_a = A.kind == kKindDwPw ? m->layers[A.fused_dw].in_tensor : A.in_tensor;
-        const int src_b = Bm.kind == kKindDwPw ? m->layers[Bm.fused_dw].in_tensor : Bm.in_tensor;
-        const int prod_b = Bm.spec.src;
-        const bool produced_before = Bm.kind == kKindConv3x3 && prod_b >= 0 && prod_b < g[0] && m->layers[prod_b].leader < g[0] &&
-                                     g[k] < g[0];
-        ok = ok && (src_a == src_b || produced_before);
-        if (A.kind == kKindDwPw)
-          ok = ok && m->layers[Bm.fused_dw].spec.stride == m->layers[A.fused_dw].spec.stride &&
-               m->layers[Bm.fused_dw].ih == m->layers[A.fused_dw].ih;
-        if (A.kind == kKindConv3x3) ok = ok && Bm.spec.cout <= 16 && A.spec.cout <= 16;  // (row kernel or gather kernel: one cout tile)
-      }
-      if (!ok) continue;
-      for (int k = 0; k < 3 && g[k] >= 0; k++) {
-        m->layers[g[k]].leader = g[0];
-        m->layers[g[0]].group[k] = g[k];
-      }
-    }
-  }
-  // Dual launches: a cls/reg head pair and the next backbone block both read the tensor produced just before them and
-  // do not depend on each other -- one grid for both (k_dual_*), issued at the head pair's turn.
-  if (!keep_all && !(flags & UFD_FLAG_NO_DUAL)) {
-    static const int kDuals[][2] = {{kHeadCls[0], 30}, {kHeadCls[1], 40}, {kHeadCls[2], 47}};
-    for (const auto& d : kDuals) {
-      Layer& A = m->layers[d[0]];
-      Layer& Bm = m->layers[d[1]];
-      if (A.kind != kKindDwPw || A.leader != d[0] || A.chained) continue;
-      if ((Bm.kind != kKindDwPw && Bm.kind != kKindPointwise) || Bm.leader != d[1] || Bm.group[1] >= 0 || Bm.chained ||
-          Bm.stack[0] >= 0 || Bm.sum_with >= 0 || Bm.res_tensor >= 0 || d[1] <= d[0])
-        continue;
-      // everything B reads exists before A's turn
-      const int src = Bm.kind == kKindDwPw ? m->layers[Bm.fused_dw].spec.src : Bm.spec.src;
-      if (src < 0 || src >= d[0] || m->layers[src].chained) continue;
-      const int src_turn = m->layers[src].ride >= 0 ? m->layers[src].ride : m->layers[src].leader;
-      if (src_turn >= d[0]) continue;
-      A.rider = d[1];
-      Bm.ride = d[0];
-    }
-  }
-  // where each layer's output can be read back in this plan (ufd_debug_layer_output)
-  for (int i = 0; i < kNumConv; i++) {
-    Layer& L = m->layers[i];
-    if (L.tap_tensor >= 0) continue;  // slice of the stacked reduce tensor
-    if ((L.kind == kKindFusedAway && !L.materialize) || L.chained) continue;
-    L.tap_tensor = L.out_tensor, L.tap_coff = L.out_coff;
-  }
-  // liveness: first writer, last reader (head outputs live until the decode kernel)
-  const int nt = (int)m->tensors.size();
-  std::vector<int> first(nt, kNumConv), last(nt, -1);
-  for (int i = 0; i < kNumConv; i++) {
-    const Layer& L = m->layers[i];
-    if (L.kind == kKindFusedAway && !L.materialize) continue;  // never written, never read
-    if (L.chained) continue;                                     // computed inside a later launch
-    const int lead = m->layers[L.leader].ride >= 0 ? std::min(L.leader, m->layers[L.leader].ride) : L.leader;
-    first[L.out_tensor] = std::min(first[L.out_tensor], lead);  // a merged layer writes at its leader's turn, a rider at its host's
-    last[L.out_tensor] = std::max(last[L.out_tensor], std::max(i, L.leader));
-    const int when = std::max(i, L.leader);  // a merged member is read at its leader's turn
-    int src_t = L.kind == kKindDwPw ? m->layers[L.fused_dw].in_tensor : L.in_tensor;
-    if (L.kind == kKindDwPw2) src_t = m->layers[m->layers[L.chain_first].fused_dw].in_tensor;
-    if (src_t >= 0) last[src_t] = std::max(last[src_t], when);
-    if (L.in_tensor >= 0 && L.kind != kKindDwPw && L.kind != kKindDwPw2) last[L.in_tensor] = std::max(last[L.in_tensor], when);
-    if (L.res_tensor >= 0) last[L.res_tensor] = std::max(last[L.res_tensor], when);
-    if (L.sum_with >= 0 && m->layers[L.sum_with].in_tensor >= 0)
-      last[m->layers[L.sum_with].in_tensor] = std::max(last[m->layers[L.sum_with].in_tensor], when);
-  }
-  if (m->rfb_tail)  // the fused launch reads the dilated convs' inputs at the shortcut layer's turn
-    for (int j : {kRfbCatA, kRfbCatB, kRfbCatC})
-      if (m->layers[j].in_tensor >= 0) last[m->layers[j].in_tensor] = std::max(last[m->layers[j].in_tensor], kRfbShortcut);
-  for (int h = 0; h < 4; h++) {
-    last[tensor_of[kHeadCls[h]]] = kNumConv;
-    last[tensor_of[kHeadReg[h]]] = kNumConv;
-  }
-  struct Blk {
-    size_t off, size;
-  };
-  std::vector<Blk> free_list;
-  size_t top = 0;
-  auto align = [](size_t v) { return (v + 63) & ~(size_t)63; };
-  auto allocate = [&](int t) {
-    const size_t need = align(m->tensors[t].per_frame() * m->B);
-    size_t best = (size_t)-1;
-    for (size_t i = 0; i < free_list.size(); i++)
-      if (free_list[i].size >= need && (best == (size_t)-1 || free_list[i].size < free_list[best].size)) best = i;
-    if (best != (size_t)-1) {
-      m->tensors[t].off = free_list[best].off;
-      if (free_list[best].size > need) {
-        free_list[best].off += need;
-        free_list[best].size -= need;
-      } else {
-        free_list.erase(free_list.begin() + best);
-      }
-    } else {
-      m->tensors[t].off = top;
-      top += need;
-    }
-  };
-  std::vector<bool> allocated(nt, false);
-  for (int i = 0; i < kNumConv; i++) {
-    for (int j = i; j < kNumConv; j++) {  // every tensor first written at turn i (merged members included)
-      const int tj = m->layers[j].out_tensor;
-      if (first[tj] == i && !allocated[tj]) {
-        allocate(tj);
-        allocated[tj] = true;
-      }
-    }  // (a fused-away depthwise output has first == kNumConv: no storage)
-    // a buffer is recycled only after the layer that reads it last has been issued, so a
-    // layer's output never aliases its own inputs
-    if (!keep_all)
-      for (int u = 0; u < nt; u++)
-        if (last[u] == i && allocated[u])  // (a tensor no launch writes -- the RFB concat under k_rfb_tail -- has no storage to give back)
-          free_list.push_back({m->tensors[u].off, align(m->tensors[u].per_frame() * m->B)});
-  }
-  for (int u = 0; u < nt; u++) m->tensors[u].first = first[u], m->tensors[u].last = last[u], m->tensors[u].stored = allocated[u];
-  m->arena_floats = top;
-}
-
-int upload_weights(ufd_model* m, const float* blob) {
-  const ConvSpec* specs = conv_specs();
-  std::vector<float> img;
-  std::vector<size_t> w_off(kNumConv), b_off(kNumConv), dw_off(kNumConv, (size_t)-1), rows_off(kNumConv, (size_t)-1);
-  const float* p = blob;
-  for (int i = 0; i < kNumConv; i++) {
-    const ConvSpec& s = specs[i];
-    const size_t nw = conv_weight_floats(s);
-    while (img.size() % 64) img.push_back(0.f);
-    w_off[i] = img.size();
-    const LayerKind kind = m->layers[i].kind;
-    if (kind == kKindPointwise || kind == kKindDwPw || kind == kKindDwPw2) {
-      const size_t np = pointwise_packed_floats(s.cin, s.cout);
-      img.resize(img.size() + np);
-      pack_pointwise_weights(p, s.cin, s.cout, img.data() + w_off[i]);
-    } else if (kind == kKindConv3x3) {
-      const size_t np = conv3x3_packed_floats(s.cin);
-      img.resize(img.size() + np);
-      pack_conv3x3_weights(p, s.cin, s.cout, img.data() + w_off[i]);
-    } else {
-      img.insert(img.end(), p, p + nw);
-    }
-    p += nw;
-    while (img.size() % 64) img.push_back(0.f);
-    b_off[i] = img.size();
-    img.insert(img.end(), p, p + s.cout);
-    if (kind == kKindConv3x3) {
-      while (img.size() % 64) img.push_back(0.f);
-      rows_off[i] = img.size();
-      img.resize(img.size() + conv3x3_rows_packed_floats(s.cin));
-      pack_conv3x3_rows_weights(p - nw, s.cin, s.cout, img.data() + rows_off[i]);
-    }
-    if (s.groups > 1 && s.k == 3) {  // depthwise: also the [c][12] image the fused kernel copies into LDS
-      while (img.size() % 64) img.push_back(0.f);
-      dw_off[i] = img.size();
-      img.resize(img.size() + depthwise_packed_floats(s.cout));
-      pack_depthwise_weights(p - nw, p, s.cout, img.data() + dw_off[i]);
-    }
-    p += s.cout;
-  }
-  // summed 1x1 pairs: weights of both convs side by side per output channel, biases added
-  std::vector<size_t> sumw_off(kNumConv, (size_t)-1), sumb_off(kNumConv, (size_t)-1);
-  {
-    std::vector<const float*> wsrc(kNumConv), bsrc(kNumConv);
-    const float* q = blob;
-    for (int i = 0; i < kNumConv; i++) {
-      wsrc[i] = q;
-      q += conv_weight_floats(specs[i]);
-      bsrc[i] = q;
-      q += specs[i].cout;
-    }
-    for (int i = 0; i < kNumConv; i++) {
-      if (m->layers[i].stack[0] != i) continue;
-      const int ci = specs[i].cin;
-      std::vector<float> wcat, bcat;
-      for (int k : m->layers[i].stack) {
-        if (k < 0) continue;
-        wcat.insert(wcat.end(), wsrc[k], wsrc[k] + (size_t)specs[k].cout * ci);
-        bcat.insert(bcat.end(), bsrc[k], bsrc[k] + specs[k].cout);
-      }
-      while (img.size() % 64) img.push_back(0.f);
-      sumw_off[i] = img.size();
-      img.resize(img.size() + pointwise_packed_floats(ci, (int)bcat.size()));
-      pack_pointwise_weights(wcat.data(), ci, (int)bcat.size(), img.data() + sumw_off[i]);
-      while (img.size() % 64) img.push_back(0.f);
-      sumb_off[i] = img.size();
-      img.insert(img.end(), bcat.begin(), bcat.end());
-    }
-    for (int i = 0; i < kNumConv; i++) {
-      const int j = m->layers[i].sum_with;
-      if (j < 0) continue;
-      const int ca = specs[j].cin, cb = specs[i].cin, co = specs[i].cout;
-      std::vector<float> wcat((size_t)co * (ca + cb)), bsum(co);
-      for (int o = 0; o < co; o++) {
-        std::memcpy(&wcat[(size_t)o * (ca + cb)], wsrc[j] + (size_t)o * ca, sizeof(float) * ca);
-        std::memcpy(&wcat[(size_t)o * (ca + cb) + ca], wsrc[i] + (size_t)o * cb, sizeof(float) * cb);
-        bsum[o] = bsrc[j][o] + bsrc[i][o];
-      }
-      while (img.size() % 64) img.push_back(0.f);
-      sumw_off[i] = img.size();
-      img.resize(img.size() + pointwise_packed_floats(ca + cb, co));
-      pack_pointwise_weights(wcat.data(), ca + cb, co, img.data() + sumw_off[i]);
-      while (img.size() % 64) img.push_back(0.f);
-      sumb_off[i] = img.size();
-      img.insert(img.end(), bsum.begin(), bsum.end());
-    }
-  }
-  size_t tail_off = (size_t)-1;
-  if (m->rfb_tail) {
-    const float* q = blob;
-    const float *w_lin = nullptr, *w_short = nullptr;
-    for (int i = 0; i < kNumConv; i++) {
-      if (i == kRfbLinear) w_lin = q;
-      if (i == kRfbShortcut) w_short = q;
-      q += conv_weight_floats(specs[i]) + specs[i].cout;
-    }
-    while (img.size() % 64) img.push_back(0.f);
-    tail_off = img.size();
-    img.resize(img.size() + rfb_tail_packed_floats());
-    pack_rfb_tail_weights(w_lin, w_short, img.data() + tail_off);
-  }
-  m->weight_img_floats = img.size();
-  HIPC(m, hipMalloc(&m->d_weights, img.size() * sizeof(float)));
-  HIPC(m, hipMemcpy(m->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
-  for (int i = 0; i < kNumConv; i++) {
-    m->layers[i].d_w = m->d_weights + w_off[i];
-    m->layers[i].d_b = m->d_weights + b_off[i];
-    if (dw_off[i] != (size_t)-1) m->layers[i].d_w_dwpack = m->d_weights + dw_off[i];
-    if (rows_off[i] != (size_t)-1) m->layers[i].d_w_rows = m->d_weights + rows_off[i];
-    if (sumw_off[i] != (size_t)-1) m->layers[i].d_w_sum = m->d_weights + sumw_off[i], m->layers[i].d_b_sum = m->d_weights + sumb_off[i];
-  }
-  if (tail_off != (size_t)-1) m->layers[kRfbShortcut].d_w_tail = m->d_weights + tail_off;
-  return UFD_OK;
 }
 
 int alloc_slot(ufd_model* m, Slot& s) {
@@ -1047,210 +174,6 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 }
 
 // ---------------------------------------------------------------- GPU stages
-float* tensor_ptr(ufd_model* m, int t) { return tl_cur->d_arena + m->tensors[t].off; }
-
-// one conv layer for frames [f0, f0 + count) of the batch
-// Kernel arguments of conv layer i for frames [f0, f0 + count)
-ConvArgs layer_args(ufd_model* m, int i, uint32_t f0, uint32_t count, int* dw_stride) {
-  const Layer& L = m->layers[i];
-  auto in_ptr = [&](int t, int ih, int iw) -> const float* {
-    if (t < 0) return tl_cur->d_input + (size_t)f0 * 3 * ih * iw;
-    return tensor_ptr(m, t) + (size_t)f0 * m->tensors[t].per_frame();
-  };
-  ConvArgs a{};
-  a.in = in_ptr(L.in_tensor, L.ih, L.iw);
-  a.w = L.d_w;
-  a.bias = L.d_b;
-  a.out = L.chained ? nullptr : tensor_ptr(m, L.out_tensor) + (size_t)f0 * m->tensors[L.out_tensor].per_frame();
-  a.res = L.res_tensor >= 0 ? in_ptr(L.res_tensor, 0, 0) : nullptr;
-  a.B = (int)count;
-  a.cin = L.spec.cin, a.cout = L.spec.cout;
-  a.ih = L.ih, a.iw = L.iw, a.oh = L.oh, a.ow = L.ow;
-  a.k = L.spec.k, a.stride = L.spec.stride, a.pad = L.spec.pad, a.dil = L.spec.dil;
-  a.depthwise = L.spec.groups > 1;
-  a.relu = L.spec.relu || i == kRfbShortcut;
-  a.in_ctotal = L.in_tensor < 0 ? 3 : m->tensors[L.in_tensor].c;
-  a.out_ctotal = m->tensors[L.out_tensor].c;
-  a.out_coff = L.out_coff;
-  *dw_stride = 1;
-  if (L.in_coff) a.in += (size_t)L.in_coff * L.ih * L.iw;  // a channel slice of a stacked tensor
-  if (L.stack[0] == i) {  // this launch computes the stacked output channels of all members
-    a.cout = m->tensors[L.out_tensor].c;
-    a.w = L.d_w_sum;
-    a.bias = L.d_b_sum;
-  }
-  if (L.sum_with >= 0) {  // two summed 1x1 convs: first the other conv's input channels, then this layer's
-    const Layer& O = m->layers[L.sum_with];
-    a.in2 = a.in;
-    a.in2_ctotal = a.in_ctotal;
-    a.in = in_ptr(O.in_tensor, O.ih, O.iw);
-    a.in_ctotal = O.in_tensor < 0 ? 3 : m->tensors[O.in_tensor].c;
-    a.ksplit = O.spec.cin >> 1;
-    a.cin = O.spec.cin + L.spec.cin;
-    a.w = L.d_w_sum;
-    a.bias = L.d_b_sum;
-  }
-  if (L.kind == kKindDwPw2) {  // second block of a chain: its input tensor does not exist
-    const Layer& D = m->layers[L.fused_dw];
-    a.in = nullptr;
-    a.ih = D.ih, a.iw = D.iw;
-    a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
-    *dw_stride = D.spec.stride;
-  }
-  if (L.kind == kKindDwPw) {
-    const Layer& D = m->layers[L.fused_dw];
-    a.in = in_ptr(D.in_tensor, D.ih, D.iw);
-    a.in_ctotal = D.in_tensor < 0 ? 3 : m->tensors[D.in_tensor].c;
-    a.ih = D.ih, a.iw = D.iw;
-    a.w2 = D.d_w_dwpack, a.bias2 = D.d_b;
-    *dw_stride = D.spec.stride;
-  }
-  return a;
-}
-
-// Issues conv layer i -- together with the layers merged into its launch (Layer::group: cls + reg
-// head pairs and the three RFB reduce convs share shapes and run as one launch, blockIdx.y
-// selecting the member).  Non-leading members are skipped when their turn comes.
-void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st);
-
-void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st);
-
-void enqueue_layer(ufd_model* m, int i, uint32_t count) {
-  hipStream_t st = tl_cur->stream;
-  enqueue_layer_launch(m, i, 0, count, st);
-  if (!m->tap_buf.empty() && tl_cur == &m->ctx[0]) tap_outputs(m, i, count, st);
-}
-
-// UFD_FLAG_TAP_LAYERS: copies every tensor the launch issued at layer i's turn has just written
-// (whole batch) to its tap buffer, before the arena recycles it.
-void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st) {
-  const Layer& L = m->layers[i];
-  if ((L.kind == kKindFusedAway && !L.materialize) || L.chained || L.leader != i) return;
-  int seen[3] = {-1, -1, -1}, n = 0;
-  for (int j : L.group) {
-    if (j < 0) continue;
-    const int t = m->layers[j].out_tensor;
-    if (t == seen[0] || t == seen[1]) continue;
-    seen[n++] = t;
-    (void)hipMemcpyAsync(m->tap_buf[t], tensor_ptr(m, t), sizeof(float) * m->tensors[t].per_frame() * count, hipMemcpyDeviceToDevice, st);
-  }
-}
-
-void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st) {
-  const Layer& L = m->layers[i];
-  if (L.kind == kKindFusedAway && !L.materialize) return;
-  if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
-  if (L.leader != i) return;  // issued with its group leader
-  if (L.ride >= 0 && !tl_force_rider) return;  // issued in (or right behind) the launch of the layer it rides with
-  if (i == 0 && tl_cur->stem_descs) {  // stem conv straight from the decoder's sample planes
-    int st_ = 1;
-    StemArgs sa;
-    sa.a = layer_args(m, 0, f0, count, &st_);
-    sa.a.w = L.d_w_rows;
-    sa.descs = tl_cur->stem_descs + f0;
-    sa.planes = tl_cur->d_planes + (size_t)f0 * m->plane_stride;
-    sa.plane_stride = m->plane_stride;
-    sa.lut = m->d_lut;
-    ProfScope ps(m, std::string("stem_planes_mfma:") + L.spec.name,
-                 (double)count * (1.5 * L.ih * L.iw + 4.0 * L.spec.cout * L.oh * L.ow) + L.weight_bytes, L.flops_per_frame * count, st);
-    launch_stem_planes_mfma(sa, st);
-    return;
-  }
-  if (i == kRfbShortcut && m->rfb_tail) {  // the three dilated convs + relu(ConvLinear(cat) + shortcut(x)) as one launch
-    int st_ = 1;
-    ConvArgs d3[3];
-    const int dil_layers[3] = {kRfbCatA, kRfbCatB, kRfbCatC};
-    std::string names;
-    for (int b = 0; b < 3; b++) {
-      d3[b] = layer_args(m, dil_layers[b], f0, count, &st_);
-      d3[b].w = m->layers[dil_layers[b]].d_w_rows;
-      names += std::string(m->layers[dil_layers[b]].spec.name) + "+";
-    }
-    ConvArgs fin = layer_args(m, i, f0, count, &st_);
-    fin.w = L.d_w_tail;
-    ProfScope ps(m, std::string("rfb_tail:") + names + L.spec.name,
-                 L.bytes_per_frame * count + L.weight_bytes, L.flops_per_frame * count, st);
-    launch_rfb_tail(d3, fin, st);
-    return;
-  }
-  if (L.kind == kKindDwPw2) {
-    int s1 = 1, s2 = 2;
-    const Layer& F = m->layers[L.chain_first];
-    const ConvArgs first = layer_args(m, L.chain_first, f0, count, &s1);
-    const ConvArgs second = layer_args(m, i, f0, count, &s2);
-    ProfScope ps(m, std::string("conv_dwpw2_mfma") + conv_dwpw2_instance(first, second) + ":" + F.spec.name + "+" + L.spec.name,
-                 L.bytes_per_frame * count + L.weight_bytes,
-                 L.flops_per_frame * count, st);
-    launch_conv_dwpw2_mfma(first, second, st);
-    return;
-  }
-  ConvArgs args[3];
-  int n = 0, dw_stride = 1;
-  std::string names;
-  double bytes = 0, flops = 0;
-  for (int j : L.group) {
-    if (j < 0) continue;
-    const Layer& M = m->layers[j];
-    args[n++] = layer_args(m, j, f0, count, &dw_stride);
-    names += (names.empty() ? "" : "+") + std::string(M.spec.name);
-    bytes += M.bytes_per_frame * count + M.weight_bytes;
-    flops += M.flops_per_frame * count;
-  }
-  ConvArgs& a = args[0];
-  bool use_rows = false;
-  const char* kind = "conv_direct_full";
-  switch (L.kind) {
-    case kKindPointwise: kind = "conv_pw_mfma"; break;
-    case kKindDwPw: kind = dwpw_uses_coop(args, n) ? "conv_dwpw_coop" : "conv_dwpw_mfma"; break;
-    case kKindDwPw2: break;  // issued above
-    case kKindConv3x3:
-      use_rows = true;
-      for (int j = 0; j < n; j++) use_rows = use_rows && conv3x3_rows_supported(args[j]);
-      kind = use_rows ? "conv3x3_rows_mfma" : "conv3x3_mfma";
-      break;
-    case kKindFusedAway: kind = "conv_direct_dw_debug"; break;
-    case kKindDirect: kind = a.depthwise ? "conv_direct_dw" : "conv_direct_full"; break;
-  }
-  if (L.rider >= 0 && L.kind == kKindDwPw) {  // dual launch with the rider's conv, when that pair of instances exists
-    const Layer& R = m->layers[L.rider];
-    int r_stride = 1;
-    const ConvArgs rb = layer_args(m, L.rider, f0, count, &r_stride);
-    const int rb_stride = R.kind == kKindDwPw ? r_stride : 0;
-    // (labelled with the device function and its template instance, like every other launch: "conv_dual_coop<1, 1, 2>")
-    if (const char* label = conv_dual_instance(args, n, dw_stride, &rb, rb_stride)) {
-      ProfScope ps(m, std::string(label) + ":" + names + "|" + R.spec.name, bytes + R.bytes_per_frame * count + R.weight_bytes,
-                   flops + R.flops_per_frame * count, st);
-      if (launch_conv_dual(args, n, dw_stride, &rb, rb_stride, st)) return;
-      ps.cancel();
-    }
-  }
-  const char* inst = L.kind == kKindPointwise ? conv_pointwise_instance(args, n)
-                     : (L.kind == kKindDwPw ? conv_dwpw_instance(args, n, dw_stride) : (use_rows ? conv3x3_rows_instance(args, n) : ""));
-  {
-  ProfScope ps(m, std::string(kind) + inst + ":" + names, bytes, flops, st);
-  switch (L.kind) {
-    case kKindPointwise: launch_conv_pointwise_mfma(args, n, st); break;
-    case kKindDwPw: launch_conv_dwpw_mfma(args, n, dw_stride, st); break;
-    case kKindConv3x3:
-      if (use_rows) {
-        int k = 0;
-        for (int j : L.group)
-          if (j >= 0) args[k++].w = m->layers[j].d_w_rows;
-        launch_conv3x3_rows_mfma(args, n, st);
-      } else {
-        launch_conv3x3_mfma(args, n, st);
-      }
-      break;
-    default: launch_conv_direct(a, st); break;
-  }
-  }
-  if (L.rider >= 0) {  // the pair is not compiled as one grid: the rider right behind its host, on its own
-    tl_force_rider = true;
-    enqueue_layer_launch(m, L.rider, f0, count, st);
-    tl_force_rider = false;
-  }
-}
-
 // [count][3][H][W] in d_input (or the sample planes, fused stem) -> every conv output the heads need.
 // Host statistics: the batch's first kernel is about to be enqueued on the context's stream (its H2D, if any, is already
 // waited for on that stream) -- the time between the previous batch's end event and this one is time the stream had
@@ -3044,39 +1967,6 @@ int ufd_debug_jpeg_coefficients(const uint8_t* jpeg, size_t len, int16_t* coef, 
     if (cap_i16 < d.coef_total) return UFD_E_ARG;
     st = jpeg_decode_coefficients(jpeg, len, &d, coef, cap_i16);
     return st == kJpegOk ? UFD_OK : (st == kJpegCorrupt ? UFD_E_DECODE : UFD_E_UNSUPPORTED);
-  } catch (...) {
-    return UFD_E_DEVICE;
-  }
-}
-
-int ufd_debug_plan(uint32_t variant, uint32_t max_batch, uint32_t flags, ufd_plan_layer* layers, uint32_t layer_cap, uint32_t* n_layers,
-                   ufd_plan_tensor* tensors, uint32_t tensor_cap, uint32_t* n_tensors, uint64_t* arena_floats) {
-  if ((variant != 640 && variant != 320) || !max_batch || !n_layers || !n_tensors) return UFD_E_ARG;
-  try {
-    std::unique_ptr<ufd_model> m(new ufd_model());
-    m->cfg.variant = variant, m->cfg.flags = flags, m->cfg.max_batch = max_batch;
-    m->W = variant == 640 ? 640 : 320, m->H = variant == 640 ? 480 : 240;
-    m->B = max_batch;
-    plan_tensors(m.get(), (flags & UFD_FLAG_KEEP_LAYERS) != 0);
-    *n_layers = (uint32_t)m->layers.size(), *n_tensors = (uint32_t)m->tensors.size();
-    if (arena_floats) *arena_floats = m->arena_floats;
-    for (uint32_t i = 0; i < *n_layers && i < layer_cap && layers; i++) {
-      const Layer& L = m->layers[i];
-      ufd_plan_layer& o = layers[i];
-      std::memset(&o, 0, sizeof(o));
-      std::snprintf(o.name, sizeof(o.name), "%s", L.spec.name);
-      o.kind = (int32_t)L.kind, o.leader = L.leader, o.ride = L.ride, o.chain_first = L.chain_first, o.fused_dw = L.fused_dw;
-      o.chained = L.chained ? 1 : 0, o.materialize = L.materialize ? 1 : 0;
-      o.in_tensor = L.in_tensor, o.out_tensor = L.out_tensor, o.out_coff = L.out_coff, o.tap_tensor = L.tap_tensor;
-      // issues a launch of its own at its turn: not computed inside another launch, not a non-leading member, not a rider
-      o.launches = !(L.kind == kKindFusedAway && !L.materialize) && !L.chained && L.leader == (int)i && L.ride < 0;
-      if ((int)i == kRfbShortcut && m->rfb_tail) o.rfb_tail = 1;
-    }
-    for (uint32_t t = 0; t < *n_tensors && t < tensor_cap && tensors; t++) {
-      const Tensor& T = m->tensors[t];
-      tensors[t] = ufd_plan_tensor{(uint64_t)T.off, (uint64_t)T.per_frame() * max_batch, T.c, T.h, T.w, T.first, T.last, T.stored ? 1 : 0};
-    }
-    return UFD_OK;
   } catch (...) {
     return UFD_E_DEVICE;
   }
