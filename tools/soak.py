@@ -75,6 +75,8 @@ print("host:", hs["per_batch_us"], hs["gpu_span_share"])
 m.close()
 per_batch = (end[1] - first[1]) * 1048576.0 / max(n - first[0], 1)
 print("host memory per batch: %.0f bytes" % per_batch)
-ok = per_batch < 300 and abs(end[2] - first[2]) < 64  # (round 4's runtime leak was 2.1 KB per batch)
+# (round 4's runtime leak was 2.1 KB per batch: 45 MB in 12 s.  A short run on a busy host sees a few MB of one-off growth --
+# late first touches of pinned pages, allocator arenas of threads that start late: the bar is per batch OR small in total)
+ok = (per_batch < 300 or end[1] - first[1] < 12) and abs(end[2] - first[2]) < 64
 print("ok" if ok else "GROWTH")
 sys.exit(0 if ok else 1)
