@@ -16,7 +16,7 @@ namespace {
 // Self-synchronising parallel decoder for streams WITHOUT restart markers (the common camera
 // case).  A Huffman bit stream has no random access, but a decoder started at a wrong bit offset
 // or in a wrong state falls into step with the true symbol sequence after a while.  The stream of
-// every frame is cut into subsequences of >= 64 bytes; the decoder state at a subsequence boundary
+// every frame is cut into subsequences of >= 64 bytes (>= 32 in a batch of a few frames); the decoder state at a subsequence boundary
 // is (bit position of the first symbol that starts inside, block inside the MCU, zigzag index).
 // Per subsequence the kernels keep a small cache of (entry state -> exit state, MCUs completed)
 // pairs, filled by speculation, and then look the true chain up in it:
@@ -42,7 +42,7 @@ namespace {
 //   k_dc_prefix     DC differences -> DC values, on a compact side array (one int16 per block) that k_idct reads.
 // Integer, latency-bound work spread over the whole chip in short launches.
 constexpr int kSyncThreads = 1024;
-constexpr int kSyncMinBytes = 64;  // shortest subsequence
+constexpr int kSyncMinBytes = 32;  // shortest subsequence (the host picks 32 or 64 bytes by batch size: model.cpp, sub_floor)
 
 struct SyncState {
   uint32_t p;   // bit position of the next symbol in the compacted stream

@@ -55,7 +55,7 @@ struct HuffScan {
   uint32_t lut_base;        // first of the 4 HuffLut of this frame: dc slot 0/1, ac slot 0/1
   // self-synchronising decoder: the frame's intervals ("segments": one without restart markers)
   uint32_t seg_base, nseg;  // range in the batch's interval array (nseg = 0: frame skipped)
-  uint32_t sub_bytes;       // subsequence length for this frame (multiple of 4, >= 64)
+  uint32_t sub_bytes;       // subsequence length for this frame (multiple of 4; >= 64, >= 32 in a batch of a few frames: model.cpp, sub_floor)
   uint32_t nsub;            // subsequence slots of the frame (sum over its segments)
   uint32_t pad;
   uint8_t blk_comp[12], blk_bx[12], blk_by[12], blk_dc[12], blk_ac[12];  // per block of the MCU

@@ -34,6 +34,31 @@ hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream) {
   return hipEventRecord(ev, stream);
 }
 
+// The staging block of a batch of a few frames (descriptors, scan plans, intervals, JPEG bytes: 60 KB for one 640x480
+// frame) is fetched from the slot's pinned host memory by a kernel ON THE CONTEXT'S STREAM instead of a copy-engine
+// transfer on the copy stream: no transfer set-up, no fence launch, no event between two streams in front of the first
+// decoder kernel -- for a lone frame those are a tenth of the whole latency, and there is nothing for the copy to overlap with.
+// The way back likewise: one launch writes the statuses, the detection counts and the detections each frame HAS (not 256
+// rows per frame) into the slot's pinned result arrays, instead of two copy-engine transfers.
+constexpr size_t kStageInMaxBytes = 256 * 1024;
+__global__ __launch_bounds__(256) void k_results_out(const uint32_t* __restrict__ d_status, const uint32_t* __restrict__ d_ndet,
+                                                     const float* __restrict__ d_dets, uint32_t det_stride_floats, uint32_t* h_status,
+                                                     uint32_t* h_ndet, float* h_dets, uint32_t max_rows) {
+  const uint32_t f = blockIdx.x;
+  const uint32_t n = d_ndet[f];
+  if (threadIdx.x == 0) {
+    h_ndet[f] = n;
+    if (d_status) h_status[f] = d_status[f];
+  }
+  const uint32_t words = min(n, max_rows) * (uint32_t)(sizeof(Det) / 4);
+  const float* src = d_dets + (size_t)f * det_stride_floats;
+  float* dst = h_dets + (size_t)f * max_rows * (sizeof(Det) / 4);
+  for (uint32_t i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- profiling
@@ -83,6 +108,10 @@ void prof_flush(ufd_model* m) {
 int alloc_slot(ufd_model* m, Slot& s) {
   if (s.h_descs) return UFD_OK;
   HIPC(m, hipHostMalloc(&s.h_stage, m->stage_cap, hipHostMallocDefault));
+  {
+    void* dp = nullptr;  // the same pages as the device sees them (k_stage_in)
+    s.h_stage_dev = hipHostGetDevicePointer(&dp, s.h_stage, 0) == hipSuccess ? static_cast<uint8_t*>(dp) : nullptr;
+  }
   s.h_descs = reinterpret_cast<JpegFrameDesc*>(s.h_stage);
   s.h_scans = reinterpret_cast<HuffScan*>(s.h_stage + m->scans_off);
   s.h_ivs = reinterpret_cast<HuffInterval*>(s.h_stage + m->ivs_off);
@@ -92,6 +121,11 @@ int alloc_slot(ufd_model* m, Slot& s) {
   // (decode status and detection counts side by side, as on the device: ONE copy brings both back)
   HIPC(m, hipHostMalloc(&s.h_gpu_status, sizeof(uint32_t) * 2 * m->B, hipHostMallocDefault));
   s.h_ndet = s.h_gpu_status + m->B;
+  {
+    void *ds = nullptr, *dd = nullptr;  // the result arrays as the device sees them (k_results_out)
+    s.h_status_dev = hipHostGetDevicePointer(&ds, s.h_gpu_status, 0) == hipSuccess ? static_cast<uint32_t*>(ds) : nullptr;
+    s.h_dets_dev = hipHostGetDevicePointer(&dd, s.h_dets, 0) == hipSuccess ? static_cast<Det*>(dd) : nullptr;
+  }
   s.plans.resize(m->B);
   HIPC(m, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.st.resize(m->B);
@@ -241,12 +275,20 @@ void enqueue_nms(ufd_model* m, Slot& s, uint32_t count) {
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   // [B decode statuses][B detection counts] are one allocation on both sides: one copy of B + count words (statuses past
   // `count` are stale and never read), or the counts alone when the host decoded the entropy stage
-  if (s.gpu_entropy)
-    HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * ((size_t)m->B + count), hipMemcpyDeviceToHost, tl_cur->stream));
-  else
-    HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
-  HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, s.d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
-                           hipMemcpyDeviceToHost, tl_cur->stream));
+  if (s.small_batch && s.h_status_dev && s.h_dets_dev) {
+    static_assert(sizeof(Det) % 4 == 0, "Det is copied as words");
+    hipLaunchKernelGGL(k_results_out, dim3(count), dim3(256), 0, tl_cur->stream, s.gpu_entropy ? tl_cur->d_status : nullptr, tl_cur->d_ndet,
+                       reinterpret_cast<const float*>(s.d_dets), (uint32_t)(sizeof(Det) / 4 * m->K), s.h_status_dev, s.h_status_dev + m->B,
+                       reinterpret_cast<float*>(s.h_dets_dev), kDetCopy);
+    tl_launches++;
+  } else {
+    if (s.gpu_entropy)
+      HIPC(m, hipMemcpyAsync(s.h_gpu_status, tl_cur->d_status, sizeof(uint32_t) * ((size_t)m->B + count), hipMemcpyDeviceToHost, tl_cur->stream));
+    else
+      HIPC(m, hipMemcpyAsync(s.h_ndet, tl_cur->d_ndet, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPC(m, hipMemcpy2DAsync(s.h_dets, sizeof(Det) * kDetCopy, s.d_dets, sizeof(Det) * m->K, sizeof(Det) * kDetCopy, count,
+                             hipMemcpyDeviceToHost, tl_cur->stream));
+  }
   span_end(s);
   HIPC(m, hipEventRecord(s.done, tl_cur->stream));
   s.ctx = tl_cur;
@@ -534,6 +576,12 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   s.h_blob = s.h_stage + p.blob_base;
   size_t blob_fill = 0;
   uint32_t k = 0;
+  // Shortest subsequence: 64 bytes when the batch fills the GPU with lanes anyway (one lane per subsequence and block of
+  // the MCU: 32 frames of 640x480 are 100 k lanes), 32 for a frame or a few at a time -- the launches of the chain last as
+  // long as their slowest lane walks, and half the symbols per lane is 167 -> 129 us for ONE 640x480 frame (24 bytes gain
+  // nothing more, 16 leave the true chain unspeculated in most frames: k_huff_resolve then decodes on the spot, 1 ms).
+  static const size_t small_bytes = std::getenv("UFD_SUB_SMALL_BYTES") ? (size_t)std::atol(std::getenv("UFD_SUB_SMALL_BYTES")) : 200u * 1024;
+  const uint32_t sub_floor = batch_bytes <= small_bytes ? 32u : 64u;
   for (uint32_t i = 0; i < count; i++) {
     std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
     if (s.st[i] != kJpegOk) continue;
@@ -558,7 +606,7 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
       size_t padded = 0;
       for (uint32_t j = 0; j < nseg; j++) padded += (size_t)(s.plans[i].iv[j].end - s.plans[i].iv[j].begin) + 32;
       uint32_t sub = (uint32_t)((padded + (kSyncMaxSub - nseg) - 1) / (kSyncMaxSub - nseg));
-      sub = std::max((sub + 3u) & ~3u, 64u);
+      sub = std::max((sub + 3u) & ~3u, sub_floor);
       uint32_t first = 0;
       for (uint32_t j = 0; j < nseg; j++) {
         HuffInterval iv = s.plans[i].iv[j];
@@ -627,6 +675,7 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
 int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size_t* lens, uint32_t count, int* buf_out,
                   bool* any_ok_out) {
   Ctx& c = *tl_cur;
+  s.small_batch = false;
   if (m->gpu_entropy_enabled) {
     const DevicePlan p = plan_device_entropy(m, s, jpegs, lens, count);
     if (p.ok) {
@@ -637,7 +686,15 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
       const int buf = c.flip;
       c.flip ^= 1;
       *buf_out = buf;
-      {
+      static const bool stage_by_kernel = !std::getenv("UFD_NO_STAGE_KERNEL");
+      s.small_batch = stage_by_kernel && p.stage_bytes <= kStageInMaxBytes && s.h_stage_dev;
+      if (s.small_batch) {
+        // (stream order protects the buffer: its last readers were kernels of an earlier batch on this stream)
+        ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.stream);
+        const uint32_t n16 = (uint32_t)((p.stage_bytes + 15) / 16);
+        hipLaunchKernelGGL(k_stage_in, dim3(std::min(256u, (n16 + 255) / 256)), dim3(256), 0, c.stream,
+                           reinterpret_cast<const uint4*>(s.h_stage_dev), reinterpret_cast<uint4*>(c.d_stage_buf[buf]), n16);
+      } else {
         // the handle's one copy stream carries the copies of all contexts: its enqueue order is
         // serialised here (descriptors + scan plans + intervals + JPEG bytes in ONE contiguous copy)
         std::lock_guard<std::mutex> lk(m->copy_mu);
@@ -645,8 +702,8 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.copy_stream);
         HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.copy_stream));
         HIPC(m, record_behind_copy(c.ev_copied[buf], c.copy_stream));
+        HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
       }
-      HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
       span_begin(s);
       uint8_t* ds = c.d_stage_buf[buf];
       return enqueue_device_entropy(m, c, p, count, ds + p.blob_base, c.d_descs_buf[buf], reinterpret_cast<const HuffScan*>(ds + m->scans_off),
@@ -849,6 +906,7 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
   std::memcpy(s.h_descs, g.h_descs.data(), sizeof(JpegFrameDesc) * count);
   for (uint32_t i = 0; i < count; i++) s.st[i] = g.st[i];
   s.gpu_entropy = true;
+  s.small_batch = false;
   s.coef_zigzag = true;
   int buf = 0;
   if (g.plan.any_ok) {
@@ -1945,7 +2003,7 @@ int ufd_debug_postproc(ufd_model* m, const float* scores, const float* boxes, ui
     launch_threshold(tl_cur->d_scores, m->K, count, m->cfg.min_confidence, tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->stream);
     enqueue_nms(m, *s, count);
     s->count = count, s->cap = cap, s->out = out, s->n = n, s->status = nullptr;
-    s->gpu_entropy = false;
+    s->gpu_entropy = false, s->small_batch = false;
     std::fill(s->st.begin(), s->st.begin() + count, UFD_OK);
     rc = enqueue_results_copy(m, *s, count);
     if (rc) return rc;

@@ -119,6 +119,10 @@ struct Slot {
   // One pinned block per slot, copied to the device with ONE hipMemcpyAsync:
   //   [frame descriptors][scan layouts][restart intervals (n_iv)][JPEG bytes, frames packed back to back]
   uint8_t* h_stage = nullptr;
+  uint32_t* h_status_dev = nullptr;  // h_gpu_status / h_dets as device addresses (k_results_out)
+  Det* h_dets_dev = nullptr;
+  bool small_batch = false;         // this batch: staging block in and results out by kernels on the context's stream
+  uint8_t* h_stage_dev = nullptr;   // h_stage as a device address (pinned host memory the GPU reads directly: k_stage_in)
   uint8_t* h_blob = nullptr;        // = h_stage + blob_base of the batch (set by plan_device_entropy)
   HuffScan* h_scans = nullptr;
   HuffInterval* h_ivs = nullptr;

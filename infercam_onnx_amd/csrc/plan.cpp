@@ -156,8 +156,11 @@ void plan_tensors(ufd_model* m, bool keep_all) {
   // RFB tail as ONE launch (k_rfb_tail, issued at the shortcut layer's turn): the three dilated 3x3 convs hand their
   // results to the summed 1x1 in registers, the 48-channel concat tensor never exists.  The dilated layers become
   // "chained" (no launch, no output of their own; ufd_debug_layer_output reports them absent in this plan).
+  // Handles for a few frames at a time keep the two launches: k_rfb_tail's wave walks three dilated convs and the 56-k-step
+  // sum one after the other (26 us for ONE 640x480 frame; the dilated launch + the split-K 1x1 take 8.8 + 10.6).
   m->rfb_tail = false;
-  if (!keep_all && !(flags & UFD_FLAG_NO_RFB_TAIL) && m->layers[kRfbShortcut].sum_with == kRfbLinear) {
+  const bool tail_pays = (long)m->B * m->layers[kRfbShortcut].oh * m->layers[kRfbShortcut].ow >= 4L * 60 * 80;
+  if (!keep_all && tail_pays && !(flags & UFD_FLAG_NO_RFB_TAIL) && m->layers[kRfbShortcut].sum_with == kRfbLinear) {
     const int dil_layers[3] = {kRfbCatA, kRfbCatB, kRfbCatC};
     ConvArgs d3[3]{}, fin{};
     bool ok = true;

@@ -1,10 +1,13 @@
 """GPU parity tests: every stage of the hot path through the C ABI against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
 from helpers import assert_dets_match, dets_array
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANT_WH = {640: (640, 480), 320: (320, 240)}
 
@@ -343,6 +346,43 @@ def test_device_sync_decoder_bit_exact(model320_dev, oracle_lib, size, subsampli
         assert b"\xff\xdd" not in jpeg  # no DRI
         got = model320_dev.debug_decode_jpeg(jpeg)
         assert np.array_equal(got, oracle_lib.jpeg_decode_rgb(jpeg)), (size, subsampling, kw)
+
+
+_FLOOR_SCRIPT = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from infercam_onnx_amd import nn, synth
+w = synth.synthetic_weights()
+m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=2,
+                      max_src=(1280, 960), device_entropy=True)
+h = hashlib.sha256()
+for i, (wd, ht, kw) in enumerate([(640, 480, {}), (640, 480, {"quality": 30}), (641, 479, {"quality": 100}), (320, 240, {"optimize": True}),
+                                  (17, 9, {}), (1280, 720, {"quality": 60})]):
+    jpeg = synth.encode_jpeg(synth.synth_frame(15, i, wd, ht), subsampling="4:2:0", **kw)
+    h.update(np.ascontiguousarray(m.debug_decode_jpeg(jpeg)).tobytes())
+smooth = synth.encode_jpeg(np.full((480, 640, 3), 117, np.uint8), subsampling="4:2:0")  # two-symbol blocks: the longest way back into step
+h.update(np.ascontiguousarray(m.debug_decode_jpeg(smooth)).tobytes())
+print("floor-hash", h.hexdigest())
+"""
+
+
+def test_sync_decoder_subsequence_floor_does_not_change_a_pixel():
+    """The self-synchronising decoder cuts a frame's stream into subsequences of >= 64 bytes when the batch fills the GPU
+    with lanes anyway, >= 32 bytes for a frame or a few at a time (model.cpp, sub_floor: 167 -> 129 us of entropy chain for
+    ONE 640x480 frame).  The same frames decoded one at a time under both floors (UFD_SUB_SMALL_BYTES forces either), each in a
+    process of its own: identical pixels (against the oracle: the single-frame tests above run under the 32-byte floor, the
+    batch tests and bench.py's `verified` under the 64-byte one)."""
+    import subprocess
+    import sys
+
+    hashes = []
+    for thr in ("0", "100000000"):
+        env = dict(os.environ, UFD_SUB_SMALL_BYTES=thr)
+        r = subprocess.run([sys.executable, "-c", _FLOOR_SCRIPT % ROOT], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "floor-hash" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        hashes.append(r.stdout.split("floor-hash")[1].split()[0])
+    assert hashes[0] == hashes[1], hashes
 
 
 def test_device_sync_decoder_grayscale_and_coefficients(model320_dev, oracle_lib):
@@ -709,14 +749,14 @@ def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracl
         fused_model.close()
 
 
-@pytest.mark.parametrize("variant,batch", [(640, 3), (320, 5), (640, 32)])
+@pytest.mark.parametrize("variant,batch", [(640, 4), (320, 17), (640, 32)])
 def test_rfb_tail_launch_matches_the_two_launch_form(weights, oracle_lib, variant, batch):
     """k_rfb_tail (round 4): the three dilated 3x3 convs of the RFB branches hand their results to
     relu(ConvLinear(cat) + shortcut(x)) in registers -- the 48-channel concat tensor never exists, one launch instead of
     two.  Same MFMA sequence for the 3x3 convs; the 1x1 takes the branch channels in the accumulators' order, so fp32
     rounding apart (<= 5e-6 on scores / boxes) from the two-launch form (UFD_FLAG_NO_RFB_TAIL), the RFB output within the
     usual 1e-5 of the oracle on every frame, at tile counts that end inside a frame (320: 30x40 maps) and at the bench's
-    batch."""
+    batch.  (Handles for fewer than four 60x80 maps' worth of pixels keep the two launches: plan.cpp, tail_pays.)"""
     from infercam_onnx_amd import nn, synth
 
     W, H = (640, 480) if variant == 640 else (320, 240)

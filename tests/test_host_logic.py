@@ -290,10 +290,12 @@ def test_planner_never_lets_two_live_tensors_share_arena_bytes(variant, flags):
         # 640: stem; m1->m2; m3->m4; m5; m6; RFB reduce stack, first 3x3s, b2 middle, tail; heads 0 (m8 rides); m9; m10; heads 1
         # (m11 rides); m12; heads 2 (extra.0 rides); extra.2 dw; extra.2 pw; heads 3.  320: its 8x10 maps (W = 10 is not a
         # multiple of 4) keep m11 ... heads 2 as depthwise + pointwise launches.
+        # (k_rfb_tail from four 60x80 maps' worth of pixels on: a handle for a frame or two keeps the two launches)
+        tail = flags == 0 and batch * (4800 if variant == 640 else 1200) >= 4 * 4800
         if flags == 0:
-            assert launches == (18 if variant == 640 else 25) and sum(L["rfb_tail"] for L in layers) == 1, launches
+            assert launches == (19 if variant == 640 else 26) - int(tail) and sum(L["rfb_tail"] for L in layers) == int(tail), launches
             gone = [li for li, L in enumerate(layers) if L["tap_tensor"] < 0]
-            for li in (2, 6, 15, 18, 22, 23):  # m1.pw, m3.pw (chained), the dilated RFB convs and rfb.linear (inside k_rfb_tail)
+            for li in (2, 6, 23) + ((15, 18, 22) if tail else ()):  # m1.pw, m3.pw (chained), rfb.linear (summed); the dilated RFB convs inside k_rfb_tail
                 assert li in gone, (li, gone)
         if flags == 2048:
             assert launches == (19 if variant == 640 else 26) and not any(L["rfb_tail"] for L in layers)
