@@ -42,7 +42,7 @@ namespace {
 //   k_dc_prefix     DC differences -> DC values, on a compact side array (one int16 per block) that k_idct reads.
 // Integer, latency-bound work spread over the whole chip in short launches.
 constexpr int kSyncThreads = 1024;
-constexpr int kSyncMinBytes = 32;  // shortest subsequence (the host picks 32 or 64 bytes by batch size: model.cpp, sub_floor)
+constexpr int kSyncMinBytes = 64;  // subsequence length written for a frame without a scan (the host picks the real one, >= 32 or >= 64 bytes by batch size: model.cpp, sub_floor)
 
 struct SyncState {
   uint32_t p;   // bit position of the next symbol in the compacted stream
