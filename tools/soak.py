@@ -1,7 +1,8 @@
 """Soak: the bench's submit / wait loop for a given time with the host and device memory of the process sampled -- leaks in
 the per-batch paths (event pools, table-set caches, staging) show as growth.  Every 50th batch carries a few corrupt frames
 and a stream with other Huffman tables, so the error and cache paths run too.
-Usage: python tools/soak.py [seconds] [clean] [spin] [staged] [hostentropy] [annot]"""
+Usage: python tools/soak.py [seconds] [clean] [spin] [staged] [hostentropy] [annot] [small]
+("small": batches of two frames -- the small-batch forms of the host plan: staging block in and results out by kernels)"""
 import os
 import sys
 import time
@@ -13,7 +14,7 @@ from infercam_onnx_amd import nn, synth
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 opts = sys.argv[2:]
-B = 32
+B = 2 if "small" in sys.argv[2:] else 32
 weights, pri = synth.synthetic_weights(), synth.gen_priors(640, 480)
 m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=pri, max_batch=B, max_src=(640, 480), det_cap=256,
                       extra_flags=nn.UFD_FLAG_SPIN_WAIT if "spin" in opts else 0, host_entropy="hostentropy" in opts)
@@ -22,9 +23,13 @@ odd = [synth.encode_jpeg(synth.synth_frame(7, i, 640, 480), optimize=True, quali
 batches = [m._prep_batch(jp[i * B:(i + 1) * B]) for i in range(6)]
 bad = list(jp[:B])
 for k in (3, 11, 19):
-    bad[k] = bad[k][: len(bad[k]) // 2]
+    if k < B:
+        bad[k] = bad[k][: len(bad[k]) // 2]
 for k in range(8):
-    bad[20 + k] = odd[k]
+    if 20 + k < B:
+        bad[20 + k] = odd[k]
+if B < 32:
+    bad[0], bad[B - 1] = jp[0][: len(jp[0]) // 2], odd[0]
 batches.append(m._prep_batch(bad))
 if "staged" in opts:
     batches = [m.stage_jpeg_batch(jp[i * B:(i + 1) * B]) for i in range(6)] + [batches[6]]
