@@ -285,8 +285,13 @@ class UltrafaceVariant(enum.Enum):
         return (640, 480) if self is UltrafaceVariant.W640H480 else (320, 240)
 
 
-def _dets_to_list(arr, n):
-    return [((arr[i].x_tl, arr[i].y_tl, arr[i].x_br, arr[i].y_br), arr[i].conf) for i in range(n)]
+def _dets_to_list(arr, n, first=0):
+    """[(bbox, conf)] of detections first .. first + n of a UfdDet array (five f32 each: one numpy view, no ctypes object
+    per detection or per field)."""
+    if n <= 0:
+        return []
+    a = np.frombuffer(arr, dtype=np.float32, count=int(n) * 5, offset=int(first) * 20).reshape(int(n), 5).tolist()
+    return [((r[0], r[1], r[2], r[3]), r[4]) for r in a]
 
 
 class UltrafaceModel(InferModel):
@@ -420,13 +425,13 @@ class UltrafaceModel(InferModel):
         cnt = (ctypes.c_uint32 * n)()
         self._check(self._lib.ufd_infer_rgb_batch(self._h, imgs.ctypes.data, w, h, w * 3, n, out, self.det_cap, cnt),
                     allow=(UFD_E_TRUNCATED,))
-        return [_dets_to_list(out[i * self.det_cap:(i + 1) * self.det_cap], min(cnt[i], self.det_cap)) for i in range(n)]
+        return [_dets_to_list(out, min(cnt[i], self.det_cap), i * self.det_cap) for i in range(n)]
 
     # -- Inferer::run decode -> infer (inferer.rs:35-37)
     def infer_jpeg(self, jpeg):
         out = (UfdDet * self.det_cap)()
         n, w, h = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
-        buf = (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)
+        buf = jpeg if isinstance(jpeg, bytes) else (ctypes.c_char * len(jpeg)).from_buffer_copy(jpeg)  # (bytes: passed as they lie)
         self._check(self._lib.ufd_infer_jpeg(self._h, buf, len(jpeg), out, self.det_cap, ctypes.byref(n),
                                              ctypes.byref(w), ctypes.byref(h)), allow=(UFD_E_TRUNCATED,))
         return _dets_to_list(out, min(n.value, self.det_cap))
@@ -449,7 +454,7 @@ class UltrafaceModel(InferModel):
         res = []
         for i in range(b.count):
             if b.status[i] in (UFD_OK, UFD_E_TRUNCATED):
-                res.append(_dets_to_list(b.out[i * self.det_cap:(i + 1) * self.det_cap], min(b.cnt[i], self.det_cap)))
+                res.append(_dets_to_list(b.out, min(b.cnt[i], self.det_cap), i * self.det_cap))
             else:
                 res.append(None)  # frame skipped (corrupt / unsupported)
         return res, list(b.status)
@@ -637,7 +642,7 @@ class UltrafaceModel(InferModel):
         out = (UfdDet * (n * cap))()
         cnt = (ctypes.c_uint32 * n)()
         self._check(self._lib.ufd_debug_postproc(self._h, s.ctypes.data, b.ctypes.data, n, out, cap, cnt))
-        return [_dets_to_list(out[i * cap:(i + 1) * cap], cnt[i]) for i in range(n)]
+        return [_dets_to_list(out, cnt[i], i * cap) for i in range(n)]
 
     # -- measurement
     def profile_reset(self):
