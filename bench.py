@@ -718,7 +718,7 @@ def main():
                 roof["alone"] = {"avg_launch_us": a["avg_launch_us"], "launches": a["launches"], "mfma_frac": a["mfma_frac"],
                                  "hbm_frac": a["hbm_frac"],
                                  "what": "one batch in flight: the kernel has the GPU to itself; `frac` above is with %d batches in "
-                                         "flight over three contexts, whose kernels share the GPU" % min(args.depth, nb)}
+                                         "flight over four contexts, whose kernels share the GPU" % min(args.depth, nb)}
             tsamp = agg_timed.get(dom)
             if loaded and tsamp and tsamp["ms"] > 0:
                 roof["timed_region_sample"] = {"launches": tsamp["launches"],

@@ -149,8 +149,8 @@ int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h
  * batches): ufd_submit_jpeg_batch copies/entropy-decodes on host workers and enqueues the GPU
  * work on one of the handle's streams, returning a ticket; ufd_wait blocks until that batch is done
  * and fills the outputs given at submit.  Input and output buffers must stay valid until then.
- * The handle runs three device contexts in rotation: keep a multiple of three batches in flight
- * (six is what bench.py uses) for full throughput; one at a time is the lowest-latency form. */
+ * The handle runs four device contexts in rotation (one stream each: the runtime's four hardware queues): keep six to
+ * eight batches in flight (six is what bench.py uses) for full throughput; one at a time is the lowest-latency form. */
 #define UFD_MAX_SLOTS 8
 int ufd_submit_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const size_t* lens, uint32_t count,
                           ufd_det* out, uint32_t cap, uint32_t* n, int32_t* status, uint32_t* ticket);
@@ -236,7 +236,7 @@ void* ufd_model_host_alloc(ufd_model* m, size_t bytes);
  *     cannot starve a 1 fps one;
  *   - a batch leaves when it is full, when its oldest frame has waited max_wait_us, or at once when the model has
  *     nothing in flight (a lone frame never waits for company);
- *   - up to max_inflight batches per model in flight (the handle overlaps them on its three device contexts).
+ *   - up to max_inflight batches per model in flight (the handle overlaps them on its four device contexts).
  * Results are delivered through on_result, per frame, in dispatch order per stream, on the completion thread of the
  * stream's replica: with several replicas on_result is called from several threads at once (never for one stream). */
 #define UFD_E_FULL (-9) /* ufd_sched_push: the stream's ring is full, the frame was dropped (router.rs:65) */

@@ -34,12 +34,18 @@ hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream) {
   return hipEventRecord(ev, stream);
 }
 
-// The staging block of a batch of a few frames (descriptors, scan plans, intervals, JPEG bytes: 60 KB for one 640x480
-// frame) is fetched from the slot's pinned host memory by a kernel ON THE CONTEXT'S STREAM instead of a copy-engine
-// transfer on the copy stream: no transfer set-up, no fence launch, no event between two streams in front of the first
-// decoder kernel -- for a lone frame those are a tenth of the whole latency, and there is nothing for the copy to overlap with.
-// The way back likewise: one launch writes the statuses, the detection counts and the detections each frame HAS (not 256
-// rows per frame) into the slot's pinned result arrays, instead of two copy-engine transfers.
+// NO COPY STREAM (round 4).  The runtime gives a process four hardware queues; a fifth stream shares one of them and its
+// work is serialised with a context's kernels.  With a copy stream three compute contexts were the most that paid; without
+// it there are four, and the pipeline runs 3.7 % (640x480, batch 32) to 20 % (UltraFace-320) faster.  So the staging block
+// of a batch (descriptors, scan plans, intervals, JPEG bytes: 60 KB for one 640x480 frame, 1.2 MB for 32) is fetched from
+// the slot's pinned host memory by a kernel ON THE CONTEXT'S STREAM: for a lone frame no transfer set-up, no fence launch
+// and no event between two streams in front of the first decoder kernel (a tenth of its latency); for full batches the
+// fetch is serial with the context's chain (idle gap per batch 18 -> 40 us) while the other three contexts compute.
+// The way back likewise: for a batch of a few frames one launch writes the statuses, the detection counts and the
+// detections each frame HAS (not 256 rows per frame) into the slot's pinned result arrays instead of two transfers, and an
+// annotate batch's finished streams are written to the caller's buffer by a launch at the end of the batch's own chain
+// (k_fetch_streams) when that buffer is pinned host memory (ufd_host_alloc / ufd_model_host_alloc) -- nothing is left to
+// copy in ufd_wait.
 constexpr size_t kStageInMaxBytes = 256 * 1024;
 __global__ __launch_bounds__(256) void k_results_out(const uint32_t* __restrict__ d_status, const uint32_t* __restrict__ d_ndet,
                                                      const float* __restrict__ d_dets, uint32_t det_stride_floats, uint32_t* h_status,
@@ -56,6 +62,12 @@ __global__ __launch_bounds__(256) void k_results_out(const uint32_t* __restrict_
   for (uint32_t i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
 }
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+// packed streams of an annotate batch (16-byte aligned pieces, *total bytes in all) -> the caller's pinned buffer of `cap` bytes
+__global__ __launch_bounds__(256) void k_fetch_streams(const uint4* __restrict__ src, const uint32_t* __restrict__ total, uint4* __restrict__ dst,
+                                                       uint32_t cap16) {
+  const uint32_t n16 = min((*total + 15u) >> 4, cap16);
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
@@ -295,8 +307,9 @@ int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   return UFD_OK;
 }
 
-// N1: the finished streams of the slot's batch -> the caller's buffer.  Their sizes are known only now, so this is the
-// second half of a two-step copy: one D2H of everything that fits, on the handle's copy stream.
+// N1: the finished streams of the slot's batch -> the caller's buffer: which frames hand theirs out, and where they lie.
+// The bytes are there already when the buffer is pinned (k_fetch_streams at the end of the batch's chain); otherwise
+// this is the second half of a two-step copy, one D2H of everything that fits.
 int fetch_streams(ufd_model* m, Slot& s) {
   const ufd_annotate& a = s.annot_args;
   for (uint32_t i = 0; i < s.count; i++) a.jpeg_off[i] = 0, a.jpeg_len[i] = 0;
@@ -319,12 +332,11 @@ int fetch_streams(ufd_model* m, Slot& s) {
     a.jpeg_off[i] = off[i], a.jpeg_len[i] = len[i];
     fit = std::max(fit, (size_t)off[i] + len[i]);
   }
-  if (fit) {
-    {
-      std::lock_guard<std::mutex> lk(m->copy_mu);
-      HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, m->copy_stream));
-      HIPC(m, record_behind_copy(s.enc_copied, m->copy_stream));
-    }
+  if (fit && !s.annot_fetched) {
+    // (the caller's buffer is not pinned host memory: a copy on the batch's own stream, behind whatever that context has
+    // queued since -- the price of pageable output)
+    HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, s.ctx->stream));
+    HIPC(m, record_behind_copy(s.enc_copied, s.ctx->stream));
     HIPC(m, hipEventSynchronize(s.enc_copied));
   }
   return rc;
@@ -686,23 +698,17 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
       const int buf = c.flip;
       c.flip ^= 1;
       *buf_out = buf;
-      static const bool stage_by_kernel = !std::getenv("UFD_NO_STAGE_KERNEL");
-      s.small_batch = stage_by_kernel && p.stage_bytes <= kStageInMaxBytes && s.h_stage_dev;
-      if (s.small_batch) {
-        // (stream order protects the buffer: its last readers were kernels of an earlier batch on this stream)
+      // (stream order protects the buffer: its last readers were kernels of an earlier batch on this stream)
+      s.small_batch = p.stage_bytes <= kStageInMaxBytes && s.h_stage_dev;
+      {
         ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.stream);
-        const uint32_t n16 = (uint32_t)((p.stage_bytes + 15) / 16);
-        hipLaunchKernelGGL(k_stage_in, dim3(std::min(256u, (n16 + 255) / 256)), dim3(256), 0, c.stream,
-                           reinterpret_cast<const uint4*>(s.h_stage_dev), reinterpret_cast<uint4*>(c.d_stage_buf[buf]), n16);
-      } else {
-        // the handle's one copy stream carries the copies of all contexts: its enqueue order is
-        // serialised here (descriptors + scan plans + intervals + JPEG bytes in ONE contiguous copy)
-        std::lock_guard<std::mutex> lk(m->copy_mu);
-        if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
-        ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.copy_stream);
-        HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.copy_stream));
-        HIPC(m, record_behind_copy(c.ev_copied[buf], c.copy_stream));
-        HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
+        if (s.h_stage_dev) {
+          const uint32_t n16 = (uint32_t)((p.stage_bytes + 15) / 16);
+          hipLaunchKernelGGL(k_stage_in, dim3(std::min(256u, (n16 + 255) / 256)), dim3(256), 0, c.stream,
+                             reinterpret_cast<const uint4*>(s.h_stage_dev), reinterpret_cast<uint4*>(c.d_stage_buf[buf]), n16);
+        } else {
+          HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.stream));
+        }
       }
       span_begin(s);
       uint8_t* ds = c.d_stage_buf[buf];
@@ -735,18 +741,15 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
   const int buf = c.flip;
   c.flip ^= 1;
   *buf_out = buf;
-  // copy stream: wait until the kernels of two batches ago have consumed this buffer
-  std::lock_guard<std::mutex> copy_lk(m->copy_mu);
-  if (c.consumed_valid[buf]) HIPC(m, hipStreamWaitEvent(c.copy_stream, c.ev_consumed[buf], 0));
-  HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.copy_stream));
+  // (on the context's own stream: the buffer's last readers were kernels of an earlier batch on it; the other contexts
+  // compute while these 29 MB per batch of 32 cross PCIe)
+  HIPC(m, hipMemcpyAsync(c.d_descs_buf[buf], s.h_descs, sizeof(JpegFrameDesc) * count, hipMemcpyHostToDevice, c.stream));
   {
-    ProfScope ps(m, "h2d_coef", 0, 0, c.copy_stream);
+    ProfScope ps(m, "h2d_coef", 0, 0, c.stream);
     // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
     HIPC(m, hipMemcpy2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
-                             hipMemcpyHostToDevice, c.copy_stream));
+                             hipMemcpyHostToDevice, c.stream));
   }
-  HIPC(m, record_behind_copy(c.ev_copied[buf], c.copy_stream));
-  HIPC(m, hipStreamWaitEvent(c.stream, c.ev_copied[buf], 0));
   span_begin(s);
   return UFD_OK;
 }
@@ -881,6 +884,21 @@ int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32
   }
   HIPC(m, hipMemcpyAsync(s.h_enc_meta, s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, c.stream));
   s.annot_ran = true;
+  s.annot_fetched = false;
+  if (s.annot_args.jpeg_out && s.annot_args.jpeg_cap >= 16) {
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, s.annot_args.jpeg_out) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer &&
+        (reinterpret_cast<uintptr_t>(at.devicePointer) & 15) == 0) {
+      const uint32_t cap16 = (uint32_t)std::min<size_t>(s.annot_args.jpeg_cap >> 4, 0xFFFFFFFFu);
+      ProfScope ps(m, "d2h_streams", 0, 0);
+      hipLaunchKernelGGL(k_fetch_streams, dim3(256), dim3(256), 0, c.stream, reinterpret_cast<const uint4*>(s.d_enc_out),
+                         s.d_enc_meta + 2 * m->B, static_cast<uint4*>(at.devicePointer), cap16);
+      s.annot_fetched = true;
+    } else {
+      (void)hipGetLastError();  // (pageable memory: hipPointerGetAttributes reports an error the next call must not see)
+    }
+  }
   return UFD_OK;
 }
 
@@ -912,8 +930,7 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
   if (g.plan.any_ok) {
     buf = c.flip;
     c.flip ^= 1;
-    // the slab is written on the context's own stream: ordered behind its previous readers; a
-    // host-path batch that reuses it later waits for ev_consumed as usual
+    // (the slab is written on the context's own stream: ordered behind its previous readers)
     span_begin(s);
     rc = enqueue_device_entropy(m, c, g.plan, count, g.d_blob, g.d_descs, g.d_scans, g.d_ivs, c.d_coef_buf[buf]);
     if (rc) return rc;
@@ -986,13 +1003,9 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
           launch_upsample_norm_420(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
         else
           launch_upsample_norm(d_descs, tl_cur->d_planes, m->plane_stride, m->d_lut, tl_cur->d_input, m->W, m->H, count, tl_cur->stream);
-        HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-        tl_cur->consumed_valid[buf] = true;
       }
     } else {
       enqueue_upsample_rgb(m, s, d_descs, mw, mh, count);
-      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-      tl_cur->consumed_valid[buf] = true;
       // one camera stream = one frame size: the whole batch in one launch (failed frames resample
       // stale pixels, their results are never reported); mixed sizes go frame by frame
       bool same_size = true;
@@ -1028,19 +1041,12 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       }
     }
     enqueue_forward(m, count);
-    if (fused_stem) {  // the stem was the last reader of the descriptors / planes of this buffer
-      tl_cur->stem_descs = nullptr;
-      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-      tl_cur->consumed_valid[buf] = true;
-    }
+    if (fused_stem) tl_cur->stem_descs = nullptr;  // (the stem was the last reader of the descriptors / planes of this buffer)
     enqueue_heads(m, count);
     enqueue_nms(m, s, count);
     if (s.annot) {
       rc = enqueue_annotate(m, s, d_descs, mw, mh, count);
       if (rc) return rc;
-      // the encoder was the last reader of this buffer's descriptors
-      HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-      tl_cur->consumed_valid[buf] = true;
     }
   }
   return enqueue_results_copy(m, s, count);
@@ -1228,7 +1234,6 @@ void destroy(ufd_model* m) {
     w.cv.notify_all();
     w.th.join();
   }
-  if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
   for (Ctx& c : m->ctx)
     if (c.stream) (void)hipStreamSynchronize(c.stream);
   auto dfree = [](void* p) {
@@ -1239,8 +1244,6 @@ void destroy(ufd_model* m) {
     dfree(c.d_arena), dfree(c.d_input), dfree(c.d_status);
     for (int i = 0; i < 2; i++) {
       dfree(c.d_stage_buf[i]), dfree(c.d_coef_buf[i]);
-      if (c.ev_copied[i]) (void)hipEventDestroy(c.ev_copied[i]);
-      if (c.ev_consumed[i]) (void)hipEventDestroy(c.ev_consumed[i]);
     }
     for (auto& pair : c.ev_span) {
       for (auto& e : pair)
@@ -1275,7 +1278,6 @@ void destroy(ufd_model* m) {
   for (Ctx& c : m->ctx) {
     if (c.stream) (void)hipStreamDestroy(c.stream);
   }
-  if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
   delete m;
 }
 
@@ -1338,18 +1340,9 @@ int create(const ufd_config* cfg, ufd_model** out) {
   }
   resolve_placement(m);
   m->pool.reset(new ThreadPool(std::min(threads, 8u), [m] { pin_this_thread(m); }));  // synchronous entry points and taps
-  // More than four live HSA queues cost throughput (host pipeline): if the process raised the
-  // runtime's cap, stay at two contexts = four streams (34 k instead of 30 k frames/s at GPU_MAX_HW_QUEUES=8).
-  if (const char* q = std::getenv("GPU_MAX_HW_QUEUES"))
-    if (std::atoi(q) > 4) m->num_ctx = 2;
-  for (int ci = 0; ci < m->num_ctx; ci++) {
-    Ctx& c = m->ctx[ci];
-    HIPB(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    // (3 compute streams + 1 copy stream = the runtime's 4 hardware queues: a copy stream per
-    // context made 6 streams share 4 queues, and the host-boundary rate fell to 0.69 of the staged one)
-    if (!m->copy_stream) HIPB(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-    c.copy_stream = m->copy_stream;
-  }
+  // Four contexts = four streams = the runtime's four hardware queues, one each (a fifth stream would share a queue with
+  // a context and serialise with its kernels: no copy stream, see k_stage_in above).
+  for (int ci = 0; ci < m->num_ctx; ci++) HIPB(hipStreamCreateWithFlags(&m->ctx[ci].stream, hipStreamNonBlocking));
 
   // ---- weights + priors
   std::vector<float> blob, priors;
@@ -1453,8 +1446,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
       HIPB(hipMalloc(&c.d_stage_buf[i], m->stage_cap));
       c.d_descs_buf[i] = reinterpret_cast<JpegFrameDesc*>(c.d_stage_buf[i]);
       HIPB(hipMalloc(&c.d_coef_buf[i], sizeof(int16_t) * m->coef_stride * B));
-      HIPB(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
-      HIPB(hipEventCreateWithFlags(&c.ev_consumed[i], hipEventDisableTiming));
     }
     for (auto& pair : c.ev_span)
       for (auto& e : pair) HIPB(hipEventCreate(&e));
@@ -1916,8 +1907,6 @@ int ufd_debug_decode_jpeg(ufd_model* m, const uint8_t* jpeg, size_t len, uint8_t
                 tl_cur->sync.dc_stride);
     launch_upsample_rgb(tl_cur->d_descs_buf[buf], tl_cur->d_planes, m->plane_stride, tl_cur->d_rgb, m->rgb_stride, d->width,
                         d->height, 1, tl_cur->stream);
-    HIPC(m, hipEventRecord(tl_cur->ev_consumed[buf], tl_cur->stream));
-    tl_cur->consumed_valid[buf] = true;
     if (s->gpu_entropy)
       HIPC(m, hipMemcpyAsync(s->h_gpu_status, tl_cur->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, tl_cur->stream));
     HIPC(m, hipMemcpyAsync(rgb, tl_cur->d_rgb, bytes, hipMemcpyDeviceToHost, tl_cur->stream));

@@ -144,6 +144,7 @@ struct Slot {
   // slot's own device buffer (it stays valid until the slot is released: the host fetches them in ufd_wait, when
   // their total size is known) -- the encoder's scratch belongs to the context.
   bool annot = false, annot_ran = false;
+  bool annot_fetched = false;  // the finished streams were written to the caller's pinned buffer by the batch's own chain (k_fetch_streams)
   ufd_annotate annot_args{};
   uint8_t* d_enc_out = nullptr;
   size_t enc_out_cap = 0;
@@ -176,7 +177,6 @@ struct Worker {
 // of one batch (small feature maps, NMS) overlap the bandwidth-bound stages of the other.
 struct Ctx {
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // the handle's one copy stream (shared by the contexts): H2D of the next batch overlaps kernels
   float* d_arena = nullptr;
   float* d_input = nullptr;
   JpegFrameDesc* d_descs_buf[2] = {nullptr, nullptr};  // double-buffered: copy(i+1) runs beside kernels(i)
@@ -187,8 +187,6 @@ struct Ctx {
   const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 sample planes (fused stem)
   SyncBuffers sync;
   uint32_t* d_status = nullptr;
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool consumed_valid[2] = {false, false};
   int flip = 0;
   uint8_t* d_planes = nullptr;
   uint8_t* d_rgb = nullptr;
@@ -258,11 +256,10 @@ struct ufd_model {
   Worker workers[kMaxCtx];
   std::atomic<uint64_t> ns_wait{0}, waits{0};
   uint64_t stats_t0 = 0;  // now_ns() of the last ufd_host_stats_reset (or of ufd_create)
-  int num_ctx = 3;  // measured: 2 -> 34.0 k, 3 -> 40-42 k, 4 -> 40-41 k frames/s; each has its own stream pair
+  int num_ctx = 4;  // one stream each = the runtime's four hardware queues (round 4: 3 contexts + a copy stream 55.5 k, 4 contexts and no copy stream 57.3 k frames/s)
   int next_ctx = 0;
   std::mutex shared_mu;  // profiling tables, resize-tap cache, Huffman table-set cache
   std::mutex err_mu;     // error string
-  std::mutex copy_mu;    // enqueue order on the shared copy stream
   std::unique_ptr<ThreadPool> pool;
   unsigned host_threads = 1;
 
@@ -315,7 +312,6 @@ struct ufd_model {
   SyncLutImage* d_sync_luts = nullptr;  // same table sets, with the state-only step tables
   size_t blob_stride = 0;   // bytes reserved per frame for JPEG bytes
   size_t scans_off = 0, ivs_off = 0, stage_cap = 0;  // layout of the staging block (descriptors at 0)
-  hipStream_t copy_stream = nullptr;
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool rfb_tail = false;              // the three dilated RFB convs + the summed 1x1 run as ONE launch (k_rfb_tail)

@@ -24,7 +24,7 @@ class Inferer:
         self.infer_rx = infer_rx
         self.max_batch = max_batch
         self.annotate = annotate
-        # batches in flight: the handle runs three device contexts, two batches each keep them fed
+        # batches in flight: the handle runs four device contexts; six to eight batches keep them fed
         self.depth = max(1, min(depth, 8))
         # reference default: UltrafaceModel::new(W320H240, 0.5, 0.5) (inferer.rs:23)
         self.model = model or UltrafaceModel(UltrafaceVariant.W320H240, 0.5, 0.5, max_batch=max_batch, **model_kw)

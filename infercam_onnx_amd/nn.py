@@ -516,8 +516,9 @@ class UltrafaceModel(InferModel):
                 owner.ufd_host_free(mem)
                 self.jpeg_mem = None
 
-    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True):
-        """Buffers of one annotate batch (reusable): pinned output memory from ufd_host_alloc.  label_size = the
+    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True, pinned=True):
+        """Buffers of one annotate batch (reusable): pinned output memory from ufd_host_alloc (the batch's own chain writes
+        the finished streams there); pinned=False: ordinary memory, fetched by a copy in ufd_wait.  label_size = the
         slot's (width, height) -- 1280 x 720 in the reference's router, whatever the JPEG's size (router.rs:66-67)."""
         base = self._prep_batch(jpegs)
         b = UltrafaceModel._AnnotBatch()
@@ -534,17 +535,21 @@ class UltrafaceModel(InferModel):
                 out_bytes_per_frame = max(out_bytes_per_frame, self._lib.ufd_encode_bound(w, h))
         cap = max(int(out_bytes_per_frame), 1024) * b.count
         b.owner = self._lib
-        b.jpeg_mem = self._lib.ufd_host_alloc(cap)
-        if not b.jpeg_mem:
-            raise MemoryError("ufd_host_alloc(%d)" % cap)
-        b.jpeg_buf = (ctypes.c_ubyte * cap).from_address(b.jpeg_mem)
+        if pinned:
+            b.jpeg_mem = self._lib.ufd_host_alloc(cap)
+            if not b.jpeg_mem:
+                raise MemoryError("ufd_host_alloc(%d)" % cap)
+            b.jpeg_buf = (ctypes.c_ubyte * cap).from_address(b.jpeg_mem)
+        else:
+            b.jpeg_mem = None
+            b.jpeg_buf = (ctypes.c_ubyte * cap)()
         b.jpeg_off = (ctypes.c_size_t * b.count)()
         b.jpeg_len = (ctypes.c_size_t * b.count)()
         a = UfdAnnotate()
         a.struct_size = ctypes.sizeof(UfdAnnotate)
         a.label_width, a.label_height = float(label_size[0]), float(label_size[1])
         a.quality, a.flags = int(quality), (UFD_ANNOT_MULTIPART if multipart else 0) | (0 if text else UFD_ANNOT_NO_TEXT)
-        a.jpeg_out, a.jpeg_cap = b.jpeg_mem, cap
+        a.jpeg_out, a.jpeg_cap = (b.jpeg_mem if pinned else ctypes.addressof(b.jpeg_buf)), cap
         a.jpeg_off, a.jpeg_len = ctypes.addressof(b.jpeg_off), ctypes.addressof(b.jpeg_len)
         b.annot = a
         return b

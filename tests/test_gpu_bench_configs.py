@@ -1,6 +1,6 @@
 """GPU parity at the configurations bench.py measures (BASELINE.json configs C1, C3, C5), through
 the exact submission paths the bench uses: staged (HBM-resident) and host-bytes batches, six in
-flight over the handle's three device contexts, at the bench's batch sizes, on the bench's own
+flight over the handle's device contexts, at the bench's batch sizes, on the bench's own
 frame pool (which holds frames with > 256 and > 2048 NMS candidates).  Every frame's detection
 list is compared with the CPU oracle (inferer.rs:35-37 + nn.rs:178-186)."""
 import hashlib
@@ -91,7 +91,7 @@ def refs_c3(pool_c3, oracle_lib, weights):
 
 def test_c3_batch32_bench_pipeline_matches_oracle(pool_c3, refs_c3, weights):
     """BASELINE C3 exactly as bench.py runs it: UltraFace-640, 640x480 stream, batch 32, the 256-frame
-    bench pool, staged + host-bytes submission, 6 batches in flight over 3 contexts; detections of
+    bench pool, staged + host-bytes submission, 6 batches in flight over the handle's contexts; detections of
     every frame (1 ... > 2000 NMS candidates) against the oracle.  det_cap 512 also exercises the
     tail copy of frames with more than 256 detections under pipelining."""
     cands = sorted(len(r) for r in refs_c3)

@@ -165,7 +165,7 @@ def test_annotate_batch_end_to_end_640(weights):
 
 
 def test_annotate_pipelined_with_a_corrupt_frame(weights):
-    """Six annotate batches in flight over the three contexts; a corrupt slot yields status DECODE and no stream,
+    """Six annotate batches in flight over the handle's contexts; a corrupt slot yields status DECODE and no stream,
     the other frames of its batch are unaffected (inferer.rs:35-36 would panic the task)."""
     W, H = 320, 240
     pool = synth.synth_jpeg_pool(3, 24, W, H, quality=90, subsampling="4:2:0")
@@ -212,6 +212,30 @@ def test_annotate_without_text_flag(weights):
         for j, d, s in zip(jpegs, dets, streams):
             frame = oracle.draw_hollow_rects(oracle.jpeg_decode_rgb(j), dets_array(d), W, H)
             assert s == oracle.jpeg_encode_rgb(frame, 95)
+
+
+def test_annotate_streams_into_pinned_and_into_ordinary_memory(weights):
+    """The finished streams reach a PINNED caller buffer (ufd_host_alloc) by a launch at the end of the batch's own chain
+    (k_fetch_streams: nothing left to copy in ufd_wait); an ordinary buffer is filled by a copy in ufd_wait.  Same bytes,
+    with six batches in flight and one frame per batch corrupt."""
+    from infercam_onnx_amd import synth
+
+    W, H = 640, 480
+    with _model(640, weights, max_batch=4, max_src=(W, H), det_cap=512) as m:
+        sets = []
+        for k in range(6):
+            js = [synth.encode_jpeg(synth.synth_frame(61, 4 * k + i, W, H), subsampling="4:2:0", quality=90) for i in range(4)]
+            js[k % 4] = js[k % 4][: len(js[k % 4]) // 3]
+            sets.append(js)
+        got = {}
+        for pinned in (True, False):
+            bs = [m.prep_annotate_batch(js, (1280, 720), pinned=pinned) for js in sets]
+            tickets = [m.submit_annotate_batch(b) for b in bs]
+            got[pinned] = [m.wait(t) for t in tickets]
+        for k in range(6):
+            (d0, s0, j0), (d1, s1, j1) = got[True][k], got[False][k]
+            assert s0 == s1 and s0[k % 4] != 0 and d0 == d1 and j0 == j1
+            assert j0[k % 4] is None and all(j is not None and j[:2] == b"\xff\xd8" for i, j in enumerate(j0) if i != k % 4)
 
 
 def test_annotate_output_buffer_too_small(weights):

@@ -34,7 +34,7 @@ batches.append(m._prep_batch(bad))
 if "staged" in opts:
     batches = [m.stage_jpeg_batch(jp[i * B:(i + 1) * B]) for i in range(6)] + [batches[6]]
 if "annot" in opts:  # the whole Inferer::run iteration: + rectangles, labels, re-encode, streams copied back
-    batches = [m.prep_annotate_batch(jp[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=640 * 480) for i in range(7)]
+    batches = [m.prep_annotate_batch(jp[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=640 * 480) for i in range(6)]
 submit = (lambda b: m.submit_annotate_batch(b) if getattr(b, "annot", None) is not None else
           (m.submit_staged(b) if getattr(b, "staged", None) else m.submit_jpeg_batch(b)))
 
