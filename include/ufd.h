@@ -205,7 +205,8 @@ typedef struct ufd_annotate {
   float label_height;
   uint32_t quality;       /* inferer.rs:39 passes 95 */
   uint32_t flags;         /* UFD_ANNOT_* */
-  uint8_t* jpeg_out;      /* output for the whole batch; pinned memory (ufd_host_alloc) avoids a staging copy */
+  uint8_t* jpeg_out;      /* output for the whole batch; into pinned memory (ufd_host_alloc) the batch's own chain writes the
+                           * streams, nothing is left to copy in ufd_wait; ordinary memory is filled by a copy there */
   size_t jpeg_cap;
   size_t* jpeg_off;       /* [count] */
   size_t* jpeg_len;       /* [count] */
