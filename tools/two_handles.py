@@ -1,26 +1,52 @@
-"""Experiment: do two handles (two independent stream sets) on one GPU overlap each other's
-latency-bound kernels?"""
-import sys, time, os
+"""Two (three) handles on ONE GPU, each fed by its own thread with six batches in flight -- a server that runs both model
+variants, or two schedulers in one process: their streams share the runtime's four hardware queues.
+    python tools/two_handles.py [mixed]      (mixed: the second handle is UltraFace-320 on 320x240 frames)"""
+import os
+import sys
+import threading
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from infercam_onnx_amd import nn, synth
-W,H,B=640,480,32
-weights=synth.synthetic_weights(); pri=synth.gen_priors(W,H)
-jpegs=synth.synth_jpeg_pool(0,128,W,H)
-for nh in (1,2,3):
-  for thr in (16,32):
-    ms=[nn.UltrafaceModel(nn.UltrafaceVariant.W640H480,0.5,0.5,max_batch=B,weights=weights,priors=pri,max_src=(W,H),host_threads=thr,det_cap=256) for _ in range(nh)]
-    bs=[[m._prep_batch(jpegs[i*B:(i+1)*B]) for i in range(4)] for m in ms]
-    for m,b in zip(ms,bs):
-        for _ in range(3): m.wait(m.submit_jpeg_batch(b[0]),collect=False)
-    N=60
-    t00=time.perf_counter()
-    infl=[]
-    for s in range(N):
-        if len(infl)>=2*nh:
-            mm,t=infl.pop(0); mm.wait(t,collect=False)
-        m=ms[s%nh]; infl.append((m,m.submit_jpeg_batch(bs[s%nh][(s//nh)%4])))
-    for mm,t in infl: mm.wait(t,collect=False)
-    el=time.perf_counter()-t00
-    print('handles',nh,'threads',thr,'fps %.0f'%(N*B/el), 'ms/batch %.3f'%(el/N*1e3))
-    for m in ms: m.close()
+
+B, STEPS = 32, 300
+weights = synth.synthetic_weights()
+mixed = "mixed" in sys.argv[1:]
+
+
+def make(k):
+    v = nn.UltrafaceVariant.W320H240 if (mixed and k % 2) else nn.UltrafaceVariant.W640H480
+    W, H = v.width_height()
+    m = nn.UltrafaceModel(v, 0.5, 0.5, max_batch=B, weights=weights, priors=synth.gen_priors(W, H), max_src=(W, H), det_cap=256)
+    jp = synth.synth_jpeg_pool(k, 128, W, H)
+    return m, [m._prep_batch(jp[i * B:(i + 1) * B]) for i in range(4)]
+
+
+def drive(m, bs, steps, out, k):
+    infl = []
+    t0 = time.perf_counter()
+    for s in range(steps):
+        if len(infl) >= 6:
+            m.wait(infl.pop(0), collect=False)
+        infl.append(m.submit_jpeg_batch(bs[s % 4]))
+    for t in infl:
+        m.wait(t, collect=False)
+    out[k] = steps * B / (time.perf_counter() - t0)
+
+
+for nh in (1, 2, 3):
+    hs = [make(k) for k in range(nh)]
+    for m, bs in hs:
+        drive(m, bs, 12, {}, 0)
+    out = {}
+    th = [threading.Thread(target=drive, args=(m, bs, STEPS, out, k)) for k, (m, bs) in enumerate(hs)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    print("handles %d%s: total %.0f frames/s (%s)" % (nh, " mixed 640/320" if mixed else "", nh * STEPS * B / el,
+                                                      ", ".join("%.0f" % out[k] for k in range(nh))), flush=True)
+    for m, _ in hs:
+        m.close()
