@@ -221,7 +221,7 @@ def test_annotate_streams_into_pinned_and_into_ordinary_memory(weights):
     from infercam_onnx_amd import synth
 
     W, H = 640, 480
-    with _model(640, weights, max_batch=4, max_src=(W, H), det_cap=512) as m:
+    with _model(640, weights, max_batch=4, max_src=(W, H), det_cap=512, profile=True) as m:
         sets = []
         for k in range(6):
             js = [synth.encode_jpeg(synth.synth_frame(61, 4 * k + i, W, H), subsampling="4:2:0", quality=90) for i in range(4)]
@@ -230,8 +230,11 @@ def test_annotate_streams_into_pinned_and_into_ordinary_memory(weights):
         got = {}
         for pinned in (True, False):
             bs = [m.prep_annotate_batch(js, (1280, 720), pinned=pinned) for js in sets]
+            m.profile_reset()
             tickets = [m.submit_annotate_batch(b) for b in bs]
             got[pinned] = [m.wait(t) for t in tickets]
+            launched = {p["name"] for p in m.profile_read() if p["launches"]}
+            assert ("d2h_streams" in launched) == pinned, (pinned, sorted(launched))  # the path taken is the one meant
         for k in range(6):
             (d0, s0, j0), (d1, s1, j1) = got[True][k], got[False][k]
             assert s0 == s1 and s0[k % 4] != 0 and d0 == d1 and j0 == j1
