@@ -888,8 +888,10 @@ int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32
   if (s.annot_args.jpeg_out && s.annot_args.jpeg_cap >= 16) {
     hipPointerAttribute_t at;
     std::memset(&at, 0, sizeof(at));
+    // (pinned host memory this handle's GPU can write: allocated portable -- ufd_host_alloc, ufd_model_host_alloc -- or on this device)
     if (hipPointerGetAttributes(&at, s.annot_args.jpeg_out) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer &&
-        (reinterpret_cast<uintptr_t>(at.devicePointer) & 15) == 0) {
+        (reinterpret_cast<uintptr_t>(at.devicePointer) & 15) == 0 &&
+        ((at.allocationFlags & hipHostMallocPortable) || at.device == m->cfg.device_id)) {
       const uint32_t cap16 = (uint32_t)std::min<size_t>(s.annot_args.jpeg_cap >> 4, 0xFFFFFFFFu);
       ProfScope ps(m, "d2h_streams", 0, 0);
       hipLaunchKernelGGL(k_fetch_streams, dim3(256), dim3(256), 0, c.stream, reinterpret_cast<const uint4*>(s.d_enc_out),
@@ -1668,7 +1670,7 @@ size_t ufd_encode_bound(uint32_t w, uint32_t h) { return enc_frame_bound(w, h) +
 
 void* ufd_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;  // (every GPU of the process may write it)
   return p;
 }
 void* ufd_model_host_alloc(ufd_model* m, size_t bytes) {
