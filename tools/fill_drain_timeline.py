@@ -2,7 +2,8 @@
 """Per-batch device timeline of bench.py's timed region from a rocprofv3 kernel trace: for each of the last K batches the
 queue (= context) it ran on, the start of its first kernel and the end of its last, relative to the first batch of the
 region -- where the 20-step sample's time goes beyond K x the steady-state period (pipeline fill, lockstep start, drain).
-Usage: fill_drain_timeline.py <kernel_trace.csv> [K]"""
+Usage: fill_drain_timeline.py <kernel_trace.csv> [K] [SKIP]     (SKIP given: batches SKIP .. SKIP + K of the trace in start
+order -- the timed region behind bench.py's warm-up steps; otherwise the last K batches of the trace)"""
 import csv
 import re
 import sys
@@ -31,7 +32,8 @@ for q, lst in per_q.items():
     if cur:
         batches.append(cur)
 batches.sort(key=lambda b: b[1])
-last = batches[-K:]
+SKIP = int(sys.argv[3]) if len(sys.argv) > 3 else None
+last = batches[-K:] if SKIP is None else batches[SKIP:SKIP + K]
 t0 = last[0][1]
 print("%-6s %-8s %10s %10s %10s %12s" % ("batch", "queue", "start us", "end us", "span us", "kernels us"))
 for i, (q, s, e, busy) in enumerate(last):
