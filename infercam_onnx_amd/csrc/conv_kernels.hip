@@ -61,6 +61,13 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
   return d;
 }
 __device__ __forceinline__ float relu_acc(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// ... and capped from above in the same instruction: min(max(x, 0), top) as integers (top = INT_MAX: ReLU; top = 0: always 0).
+// (v_med3_i32 by hand: the compiler only forms it for constant bounds)
+__device__ __forceinline__ float relu_below(float x, int top) {
+  int d;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(d) : "v"(__float_as_int(x)), "v"(top));
+  return __int_as_float(d);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Shared tail of the 32x32x2 kernels.  D layout: reg r, lane l -> cout (r&3) + 8*(r>>2) + 4*(l>>5),
@@ -742,18 +749,106 @@ __global__ __launch_bounds__(256) void k_dual_dwpw_pw(DualArgs q) {  // A as abo
 // 16 KB per wave; a lane only ever reads back what it wrote itself, so there is no barrier), and per k-step loads
 // only the NEW bottom row from global memory: one 16-byte global load and two LDS reads instead of three global
 // loads, and every input row crosses the memory system once per band instead of three times.
+// ISSUE DIET (round 5).  On gfx950 fp32 MFMAs and the wave's own vector instructions share one issue path, so this kernel is
+// bound by their SUM (rule 1); `tools/isa_mix.py` counted 65 vector instructions per k-step of the first
+// block for the 36 multiply-adds and 4 ReLUs its arithmetic needs.  What went:
+//   * halo columns: the neighbouring lane's pixel used to be a v_mov_b32_dpp, the image border a v_cndmask on it (12 per
+//     k-step).  Now the cross-lane read happens INSIDE the multiply-add (v_fmac_f32_dpp, dw_row below: five of the six), and the
+//     border is a per-lane WEIGHT: a lane whose window hangs over the left / right image border reads its first / last tap
+//     column from an all-zero copy of the edge-tap table in LDS (fma(0, x, t) == t for the finite x of the neighbouring row);
+//   * the bias of the first pointwise conv used to be 64 v_mov into the accumulators per X1 row: now 16 LDS reads;
+//   * the exchange of channels between the wave's halves in front of the second pointwise conv was select + ds_bpermute +
+//     select (48 v_cndmask per output row): now 16 v_permlane32_swap;
+//   * an X1 row outside the image used to switch the second depthwise conv to an all-zero tap table: now the ReLU of the
+//     accumulators is a v_med3_i32 against a per-lane upper bound (INT_MAX, or 0 for such a row), same instruction count;
+//   * the k-loop is fully unrolled: LDS and channel offsets are immediates, no address arithmetic on the vector ALU.
+// The order of every output's multiply-adds is unchanged: results are bit-identical to the unfused pair (tested).
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
+
+// One tap row (weights w0 w1 w2) of a stride-1 depthwise 3x3 for the lane's 4 consecutive pixels m.x .. m.w of one channel:
+//   t0 += wl * [lane - 1].m.w + w1 * m.x + w2 * m.y        t2 += w0 * m.y + w1 * m.z + w2 * m.w
+//   t1 += w0 * m.x + w1 * m.y + w2 * m.z                   t3 += w0 * m.z + w1 * m.w + wr * [lane + 1].m.x
+// (each sum in this order: taps left to right).  wl / wr: w0 / w2, or 0 in the lane at the left / right image border.
+// FIRST: t = bias + ... (the first tap row of a channel).  Written as the 13 instructions it is: the compiler does not fold
+// a DPP move into the multiply-add that uses it.  s_nop 1: a DPP source must not have been written by the vector ALU in the two
+// cycles before (the pixels come from loads, but the register allocator may move them; the assembler does not check inline asm).
+template <bool FIRST>
+__device__ __forceinline__ void dw_row(float (&t)[4], const float4 m, float w0, float w1, float w2, float wl, float wr, float bias) {
+  if (FIRST) {
+    float tmp;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fma_f32 %0, %12, %4, %14\n\t"
+        "v_fma_f32 %1, %9, %5, %14\n\t"
+        "v_fma_f32 %2, %9, %6, %14\n\t"
+        "v_fma_f32 %3, %9, %7, %14\n\t"
+        "v_fmac_f32 %0, %10, %5\n\t"
+        "v_fmac_f32 %1, %10, %6\n\t"
+        "v_fmac_f32 %2, %10, %7\n\t"
+        "v_fmac_f32 %3, %10, %8\n\t"
+        "v_fmac_f32 %0, %11, %6\n\t"
+        "v_fmac_f32 %1, %11, %7\n\t"
+        "v_fmac_f32 %2, %11, %8\n\t"
+        "v_fmac_f32_dpp %3, %5, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(tmp)
+        : "v"(m.x), "v"(m.y), "v"(m.z), "v"(m.w), "v"(w0), "v"(w1), "v"(w2), "v"(wl), "v"(wr), "v"(bias));
+  } else {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %7, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32 %1, %8, %4\n\t"
+        "v_fmac_f32 %2, %8, %5\n\t"
+        "v_fmac_f32 %3, %8, %6\n\t"
+        "v_fmac_f32 %0, %9, %4\n\t"
+        "v_fmac_f32 %1, %9, %5\n\t"
+        "v_fmac_f32 %2, %9, %6\n\t"
+        "v_fmac_f32 %3, %9, %7\n\t"
+        "v_fmac_f32 %0, %10, %5\n\t"
+        "v_fmac_f32 %1, %10, %6\n\t"
+        "v_fmac_f32 %2, %10, %7\n\t"
+        "v_fmac_f32_dpp %3, %4, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])
+        : "v"(m.x), "v"(m.y), "v"(m.z), "v"(m.w), "v"(w0), "v"(w1), "v"(w2), "v"(wl), "v"(wr));
+  }
+}
+// The three tap rows of one channel: `wq` -> its 12-float record (9 taps ky-major, bias), `el` / `er` -> the lane's edge
+// taps of the channel (first / last tap column of the three rows; the zero copy for a lane at that image border).
+__device__ __forceinline__ void dw_taps(const float4 (&m3)[3], const float* wq, const float* el, const float* er, float (&t)[4]) {
+  const float4 q0 = reinterpret_cast<const float4*>(wq)[0], q1 = reinterpret_cast<const float4*>(wq)[1];
+  const float2 q2 = reinterpret_cast<const float2*>(wq)[4];
+  const float4 l = *reinterpret_cast<const float4*>(el), r = *reinterpret_cast<const float4*>(er);
+  dw_row<true>(t, m3[0], q0.x, q0.y, q0.z, l.x, r.x, q2.y);
+  dw_row<false>(t, m3[1], q0.w, q1.x, q1.y, l.y, r.y, 0.f);
+  dw_row<false>(t, m3[2], q1.z, q1.w, q2.x, l.z, r.z, 0.f);
+  // (ReLU as the integer maximum with 0: behind inline asm fmaxf() would cost a canonicalising v_max_f32 of its own first)
+  t[0] = relu_acc(t[0]), t[1] = relu_acc(t[1]), t[2] = relu_acc(t[2]), t[3] = relu_acc(t[3]);
+}
+// Edge-tap table of a packed depthwise table w2 [cin][12]: [4 variants][cin][8] = (w00 w10 w20 0 | w02 w12 w22 0); variants 0 ..
+// 2 as dw_variant (tap row 0 / 2 zeroed for a window over the top / bottom border), variant 3 all zero.
+__device__ __forceinline__ void fill_edge_taps(float* s_e, const float* __restrict__ w2, int cin) {
+  for (int i = threadIdx.x; i < 4 * cin * 8; i += 256) {
+    const int v = i / (cin * 8), c = (i >> 3) % cin, j = i & 7, k = j & 3;
+    const bool zero = v == 3 || k == 3 || (v == 1 && k == 0) || (v == 2 && k == 2);
+    s_e[i] = zero ? 0.f : w2[c * 12 + 3 * k + (j >> 2) * 2];
+  }
+}
+
 template <int C1, int CT2, bool RING>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
   const ConvArgs& a2 = p3.a[1];
   constexpr int KS1 = C1 / 2, KS2 = 16;
   extern __shared__ float s_mem[];
-  float* s_dw1 = s_mem;                // [3][C1][12] (fill_dw_variants)
-  float* s_w1 = s_dw1 + 3 * C1 * 12;   // [KS1][64]
-  float* s_dw2 = s_w1 + KS1 * 64;      // [2][32][12]: the packed table, then a copy with all taps zero
-  float* s_w2 = s_dw2 + 2 * 32 * 12;   // [CT2][KS2][64]
-  float* s_b1 = s_w2 + CT2 * KS2 * 64; // [32] bias of the first pointwise conv
-  float* s_b2 = s_b1 + 32;             // [32 * CT2] bias of the second (0 beyond cout)
+  float* s_dw1 = s_mem;                 // [3][C1][12] (fill_dw_variants)
+  float* s_e1 = s_dw1 + 3 * C1 * 12;    // [4][C1][8] (fill_edge_taps)
+  float* s_w1 = s_e1 + 4 * C1 * 8;      // [KS1][64]
+  float* s_f2 = s_w1 + KS1 * 64;        // [2][16 channel pairs (c, c + 1)][32] second depthwise conv: per tap row k eight floats (wk0' wk0'
+                                        // | wk0 wk0 | wk1 wk1 | wk2 wk2) of (c, c + 1), then (bias bias 0 ...); wk0' = wk0 in copy 0, 0 in
+                                        // copy 1 (the lanes at the left image border read that one)
+  float* s_w2 = s_f2 + 2 * 16 * 32;     // [CT2][KS2][64]
+  float* s_b1 = s_w2 + CT2 * KS2 * 64;  // [2 halves][16] bias of the first pointwise conv in the order of the accumulator rows
+  float* s_b2 = s_b1 + 32;              // [CT2][2][16] bias of the second (0 beyond cout)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // RING: [wave][2 row slots][KS1][64 lanes] float4 behind the tables (a multiple of 16 bytes in)
   float4* const s_ring = reinterpret_cast<float4*>(s_b2 + 32 * CT2) + (size_t)wave * 2 * KS1 * 64 + lane;
@@ -769,20 +864,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = threadIdx.x; i < n4; i += 256) d4[i] = s4[i];
     };
     fill_dw_variants(s_dw1, a1.w2, C1);
+    fill_edge_taps(s_e1, a1.w2, C1);
     copy4(s_w1, a1.w, KS1 * 16);
-    copy4(s_dw2, a2.w2, 32 * 3);
-    for (int i = threadIdx.x; i < 32 * 12; i += 256) s_dw2[32 * 12 + i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 16 * 32; i += 256) {
+      const int v = i >> 9, c = 2 * ((i >> 5) & 15) + (i & 1), k = (i >> 3) & 3, e = (i >> 1) & 3;
+      const float* w = a2.w2 + c * 12;
+      s_f2[i] = k < 3 ? (e == 0 ? (v ? 0.f : w[3 * k]) : w[3 * k + e - 1]) : (e == 0 ? w[9] : 0.f);
+    }
     copy4(s_w2, a2.w, CT2 * KS2 * 16);
-    if (threadIdx.x < 32) s_b1[threadIdx.x] = a1.bias[threadIdx.x];
-    if (threadIdx.x < 32 * CT2) s_b2[threadIdx.x] = (int)threadIdx.x < a2.cout ? a2.bias[threadIdx.x] : 0.0f;
+    if (threadIdx.x < 32 * (1 + CT2)) {  // accumulator row r of half h holds channel (r & 3) + 8 * (r >> 2) + 4 * h of its tile
+      const int t = threadIdx.x, r = t & 15, co = (t >> 5) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
+      if (t < 32) s_b1[t] = a1.bias[co];
+      else s_b2[t - 32] = co - 32 < a2.cout ? a2.bias[co - 32] : 0.0f;
+    }
   }
   __syncthreads();
-  // (table reads inside the row loop go through an index the compiler cannot see through: hoisted out of the loop as
-  // loop invariants, the 16 + 16 + 32 bias values alone cost more registers than the kernel has to spare)
-  auto opaque = [](int v) {
-    // asm volatile("" : "+v"(v));
-    return v;
-  };
   const int half = lane >> 5, j32 = lane & 31;
   const int R = a2.band, bands = a2.oh / R;
   const int ohw = a2.oh * a2.ow, gpr = a2.ow >> 2, gpb = bands * gpr;  // column groups per row / per frame of bands
@@ -799,24 +895,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int x0 = 2 * ox + 4 * sub;            // first X1 / input column of the lane
   const bool leftok = x0 > 0;                 // column x0 - 1 exists (else zero padding)
   const bool rightok = x0 + 4 < W1;           // column x0 + 4 exists
-  const char* __restrict__ in = reinterpret_cast<const char*>(a1.in);
+  // Input windows come by BUFFER loads: descriptor of the input tensor in scalar registers, the lane's 32-bit byte offset of
+  // the row in a vector register, the channel of the k-step as the instruction's scalar offset -- no address arithmetic on the
+  // vector ALU at all (global_load with a 64-bit address cost a v_lshl_add_u64 per load).  Tensors stay below 4 GiB (ufd_create).
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1.in), 0, 0xFFFFFFFF, 0x00020000);
   const uint32_t lane_base = (uint32_t)((frame * a1.in_ctotal + half) * ihw) + (uint32_t)x0;
-  const size_t chan_step = 8u * (size_t)ihw;  // bytes between the channels of consecutive k-steps
+  const uint32_t chan_step = 8u * (uint32_t)ihw;  // bytes between the channels of consecutive k-steps
+  auto load_row = [&](uint32_t off, int ks) -> float4 {
+    const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, (uint32_t)ks * chan_step, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  };
 
   // second block: depthwise sums of the lane's 16 channels x 2 output pixels -- of the output row being
   // finished (t2) and, across an X1 row that both need, of the one below it (t2n)
-  float t2[16][2], t2n[16][2];
-  auto init_sums = [&](float (&tt)[16][2]) {
-    const float* b = s_dw2 + opaque(4 * half * 12 + 9);
+  // Packed over CHANNEL PAIRS: accumulator rows (2p, 2p + 1) of the lane are channels (c, c + 1), c = 2(p & 1) + 8(p >> 1) + 4 half;
+  // t2[j][p] = output pixel j (A, B) of both.  Every tap is then one v_pk_fma_f32 whose operands are plain register pairs.
+  floatx2 t2[2][8], t2n[2][8];
+  // the lane's records of the second depthwise conv: channel pair p at float offset rec2(p)
+  const float* const f2 = s_f2 + (leftok ? 0 : 16 * 32) + 2 * half * 32;
+  auto rec2 = [](int p) { return ((p & 1) + 4 * (p >> 1)) * 32; };
 #pragma unroll
-    for (int r = 0; r < 16; r++) tt[r][0] = tt[r][1] = b[((r & 3) + 8 * (r >> 2)) * 12];
-  };
-  init_sums(t2);
+  for (int p = 0; p < 8; p++) t2[0][p] = t2[1][p] = *reinterpret_cast<const floatx2*>(f2 + rec2(p) + 24);
 
-  // input windows: 3 rows x 4 columns of channel 2*ks + half; two k-steps are kept in flight
-  // ACROSS the X1 rows (the ring never drains: the first windows of the next row are loaded
-  // while the current row is folded into the second depthwise conv)
-  float4 win[2][3];
+  // input windows: 3 rows x 4 columns of channel 2*ks + half.  Rows that come from memory are requested PD k-steps ahead,
+  // ACROSS the X1 rows (the queue never drains: the first windows of the next row are loaded while the current row is
+  // folded into the second depthwise conv).  RING: one row per k-step comes from memory (4 registers per step in flight),
+  // the two rows from the LDS ring are read two k-steps ahead.  Measured alone on MI355X (round 5, docs/EXPERIMENTS.md):
+  // RING PD 2 / 4 / 8: 86.7 / 81.5 / 114 us (8: 20 spilled dwords, scratch traffic inside the k-loop); three rows per
+  // k-step, PD 2 / 4: 64.1 / 66.1 us (spills again).
+  constexpr int PD = RING ? 4 : 2;
+  static_assert(KS1 % PD == 0 && PD >= 2, "the queue slot of a k-step is ks % PD in every X1 row");
+  float4 win[PD][RING ? 1 : 3];
+  float4 up[2][2];  // RING: top and middle row of k-steps (even, odd) from the LDS ring
   // (wave-uniform channel base + the lane's 32-bit byte offset of the row; the rows of an X1 row y1 are
   // input rows y1 - 1 .. y1 + 1, clamped into the image: rows outside are zero padding through the taps)
   auto row_offsets = [&](int y1, uint32_t (&ro)[3]) {
@@ -825,113 +935,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // RING: input row y of k-step ks sits in slot (y & 1) once it has been the bottom row of an X1 row
   auto ring_at = [&](int y, int ks) -> float4& { return s_ring[(((y + 2) & 1) * KS1 + ks) * 64]; };
-  auto load_window = [&](const uint32_t (&ro)[3], int y1, int ks, float4 (&m)[3]) {
-    const char* base = in + (size_t)ks * chan_step;
+  auto load_window = [&](const uint32_t (&ro)[3], int ks) {  // k-step ks of the X1 row with input rows `ro`, from memory
     if (RING) {
-      m[0] = ring_at(y1 - 1, ks), m[1] = ring_at(y1, ks);
-      m[2] = *reinterpret_cast<const float4*>(base + ro[2]);
+      win[ks % PD][0] = load_row(ro[2], ks);
     } else {
 #pragma unroll
-      for (int k = 0; k < 3; k++) m[k] = *reinterpret_cast<const float4*>(base + ro[k]);
+      for (int k = 0; k < 3; k++) win[ks % PD][k] = load_row(ro[k], ks);
     }
   };
-  // first depthwise conv: 4 pixels of channel 2*ks + half.  Input rows outside the image are
-  // zero padding: `wl` points into the copy of the LDS table that has those taps zeroed.
-  auto dw_compute = [&](const float* wl, const float4 (&m3)[3], int ks, float (&t)[4]) {
-    const float4* wq = reinterpret_cast<const float4*>(wl + 2 * ks * 12);
-    const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
-    const float wd[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-    float t0 = wd[9], t1 = t0, t2_ = t0, t3 = t0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float w0 = wd[3 * k], w1 = wd[3 * k + 1], w2 = wd[3 * k + 2];
-      const float4 m = m3[k];
-      const float from_prev = lane_prev(m.w), from_next = lane_next(m.x);
-      const float l = leftok ? from_prev : 0.f, rr = rightok ? from_next : 0.f;
-      t0 = fmaf(w0, l, t0), t1 = fmaf(w0, m.x, t1), t2_ = fmaf(w0, m.y, t2_), t3 = fmaf(w0, m.z, t3);
-      t0 = fmaf(w1, m.x, t0), t1 = fmaf(w1, m.y, t1), t2_ = fmaf(w1, m.z, t2_), t3 = fmaf(w1, m.w, t3);
-      t0 = fmaf(w2, m.y, t0), t1 = fmaf(w2, m.z, t1), t2_ = fmaf(w2, m.w, t2_), t3 = fmaf(w2, rr, t3);
+  auto load_ring = [&](int y1, int ks) { up[ks & 1][0] = ring_at(y1 - 1, ks), up[ks & 1][1] = ring_at(y1, ks); };
+  auto taps_of = [&](int ks, const float* wl, const float* el, const float* er, float (&t)[4]) {
+    if (RING) {
+      const float4 m3[3] = {up[ks & 1][0], up[ks & 1][1], win[ks % PD][0]};
+      dw_taps(m3, wl + 2 * ks * 12, el + 2 * ks * 8, er + 2 * ks * 8, t);
+    } else {
+      const float4 m3[3] = {win[ks % PD][0], win[ks % PD][RING ? 0 : 1], win[ks % PD][RING ? 0 : 2]};
+      dw_taps(m3, wl + 2 * ks * 12, el + 2 * ks * 8, er + 2 * ks * 8, t);
     }
-    t[0] = fmaxf(t0, 0.f), t[1] = fmaxf(t1, 0.f), t[2] = fmaxf(t2_, 0.f), t[3] = fmaxf(t3, 0.f);
   };
-  // one X1 row of the lane's 16 channels (in the accumulators) -> the second depthwise sums.  An X1 row outside the
-  // image is zero padding: taps from the all-zero copy (fma(0, x, t) == t).  Odd X1 rows are the middle tap row of one
-  // output row (BOTH = false: tap row 1 into t2); even ones the bottom tap row of the output row above and the top
-  // tap row of the one below: both sums are updated in one pass over the channels (tap row 2 into t2, tap row 0 into
-  // t2n after its bias), so an accumulator register is dead as soon as its channel is folded.
-  auto fold = [&](const floatx16 (&acc)[4], bool row1ok, int mode /* 0: middle tap row; 1: up + down; 2: down only; 3: up only */) {
-    const float* wl2 = s_dw2 + (row1ok ? 0 : 32 * 12) + 4 * half * 12;
-    const float* bl2 = s_dw2 + 4 * half * 12 + 9;  // (the bias always from the real table)
+  // one X1 row of the lane's 16 channels (in the accumulators) -> the second depthwise sums.  ReLU of the first block and the
+  // row's existence in one v_med3_i32: the integer maximum with 0 is ReLU for non-NaN floats (relu_acc), and `xmax` is INT_MAX or,
+  // for an X1 row outside the image (zero padding), 0.  Output pixel A of the lane reads X1 columns (left lane's x3, x0, x1), B
+  // (x1, x2, x3), taps in this order.  Odd X1 rows are the middle tap row of one output row (mode 0: tap row 1 into t2); even
+  // ones the bottom tap row of the output row above and the top tap row of the one below: both sums are updated in one pass
+  // over the channels (tap row 2 into t2, tap row 0 into t2n after its bias), so an accumulator register is dead as soon as
+  // its channel is folded.
+  auto fold = [&](const floatx16 (&acc)[4], int xmax, int mode /* 0: middle tap row; 1: up + down; 2: down only; 3: up only */) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float* wd2 = wl2 + ((r & 3) + 8 * (r >> 2)) * 12;
-      float x[4];
+    for (int p = 0; p < 8; p++) {
+      const float4* rec = reinterpret_cast<const float4*>(f2 + rec2(p));
+      floatx2 x[4];
 #pragma unroll
-      for (int p = 0; p < 4; p++) x[p] = relu_acc(acc[p][r]);  // (the first block always ends in a ReLU: dwpw2_supported)
-      const float from_prev = lane_prev(x[3]);
-      const float l = leftok ? from_prev : 0.f;
+      for (int i = 0; i < 4; i++)  // (the first block always ends in a ReLU: dwpw2_supported)
+        x[i] = floatx2{relu_below(acc[i][2 * p], xmax), relu_below(acc[i][2 * p + 1], xmax)};
+      const floatx2 l = {lane_prev(x[3][0]), lane_prev(x[3][1])};
+      auto taps = [&](floatx2& sa, floatx2& sb, int k) {
+        const float4 w0 = rec[2 * k], w12 = rec[2 * k + 1];
+        const floatx2 wl = {w0.x, w0.y}, wk0 = {w0.z, w0.w}, wk1 = {w12.x, w12.y}, wk2 = {w12.z, w12.w};
+        sa = __builtin_elementwise_fma(wl, l, sa), sa = __builtin_elementwise_fma(wk1, x[0], sa), sa = __builtin_elementwise_fma(wk2, x[1], sa);
+        sb = __builtin_elementwise_fma(wk0, x[1], sb), sb = __builtin_elementwise_fma(wk1, x[2], sb), sb = __builtin_elementwise_fma(wk2, x[3], sb);
+      };
       if (mode == 0) {
-        const float w0 = wd2[3], w1 = wd2[4], w2 = wd2[5];
-        t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
-        t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
+        taps(t2[0][p], t2[1][p], 1);
       } else {
-        if (mode != 2) {  // (the band's first X1 row has no output row above, its last none below)
-          const float w0 = wd2[6], w1 = wd2[7], w2 = wd2[8];
-          t2[r][0] = fmaf(w0, l, t2[r][0]), t2[r][0] = fmaf(w1, x[0], t2[r][0]), t2[r][0] = fmaf(w2, x[1], t2[r][0]);
-          t2[r][1] = fmaf(w0, x[1], t2[r][1]), t2[r][1] = fmaf(w1, x[2], t2[r][1]), t2[r][1] = fmaf(w2, x[3], t2[r][1]);
-        }
+        if (mode != 2) taps(t2[0][p], t2[1][p], 2);  // (the band's first X1 row has no output row above, its last none below)
         if (mode != 3) {
-          const float w0 = wd2[0], w1 = wd2[1], w2 = wd2[2], bb = bl2[((r & 3) + 8 * (r >> 2)) * 12];
-          float u0 = bb, u1 = bb;
-          u0 = fmaf(w0, l, u0), u0 = fmaf(w1, x[0], u0), u0 = fmaf(w2, x[1], u0);
-          u1 = fmaf(w0, x[1], u1), u1 = fmaf(w1, x[2], u1), u1 = fmaf(w2, x[3], u1);
-          t2n[r][0] = u0, t2n[r][1] = u1;
+          const float4 b = rec[6];
+          t2n[0][p] = t2n[1][p] = floatx2{b.x, b.y};
+          taps(t2n[0][p], t2n[1][p], 0);
         }
       }
       // (the scheduler would otherwise issue all the table reads of the row first: registers this kernel does not have)
-      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   };
   // second pointwise conv of the finished sums t2 -> output row oy.  The lane holds channels qq + 8b + 4*half
   // (qq = r&3, b = r>>2); k-step s = 4b + u needs channel 8b + 2u from the half-0 lanes and 8b + 2u + 1 from the
-  // half-1 lanes:
-  //   half 0 supplies own qq=0 (u=0), own qq=2 (u=1), partner's qq=0 (u=2), partner's qq=2 (u=3)
-  //   half 1 supplies partner's qq=1 (u=0), partner's qq=3 (u=1), own qq=1 (u=2), own qq=3 (u=3)
+  // half-1 lanes.  v_permlane32_swap(A, B) leaves A = (A's lower half, B's lower half), B = (A's upper half, B's upper
+  // half); with A = the lane's qq = 0, B = qq = 1:  A -> channels 8b | 8b + 1 = k-step u = 0,  B -> 8b + 4 | 8b + 5 = u = 2;
+  // with qq = 2, 3: u = 1 and u = 3.
   const int lowest2 = a2.relu ? 0 : (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a2.out + (size_t)a2.out_coff * ohw, 0, 0xFFFFFFFF, 0x00020000);
+  const uint32_t out_chan_step = 4u * (uint32_t)ohw;
   auto finish = [&](int oy) {
-    float bop[KS2][2];  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
+    floatx2 bop[KS2];  // B operands of the 16 k-steps (2 output pixels each), after the exchange between the halves
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      float own[4][2], got[2][2];
+    for (int b = 0; b < 4; b++)
 #pragma unroll
-      for (int qq = 0; qq < 4; qq++)
+      for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) own[qq][j] = fmaxf(t2[4 * b + qq][j], 0.f);
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        // half 0 sends qq = 1, 3; half 1 sends qq = 0, 2
-        const float s0 = half ? own[0][j] : own[1][j], s1 = half ? own[2][j] : own[3][j];
-        got[0][j] = __shfl_xor(s0, 32), got[1][j] = __shfl_xor(s1, 32);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        bop[4 * b + 0][j] = half ? got[0][j] : own[0][j];
-        bop[4 * b + 1][j] = half ? got[1][j] : own[2][j];
-        bop[4 * b + 2][j] = half ? own[1][j] : got[0][j];
-        bop[4 * b + 3][j] = half ? own[3][j] : got[1][j];
-      }
-    }
-    // (stores: wave-uniform channel base + the lane's 32-bit byte offset -- per-channel address arithmetic stays scalar)
+        for (int qq = 0; qq < 4; qq += 2) {
+          // (accumulator rows 4b + qq, 4b + qq + 1 = the two channels of pair 2b + qq / 2; ReLU as the integer maximum)
+          const floatx2 own = t2[j][2 * b + (qq >> 1)];
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(relu_acc(own[0])), __float_as_uint(relu_acc(own[1])), false, false);
+          bop[4 * b + (qq >> 1)][j] = __uint_as_float(sw[0]), bop[4 * b + 2 + (qq >> 1)][j] = __uint_as_float(sw[1]);
+        }
+    // (buffer stores: the lane's 32-bit byte offset in a vector register, the channel as the scalar offset)
     const uint32_t out_off = 4u * (uint32_t)((frame * a2.out_ctotal + 4 * half) * ohw + (size_t)(oy * a2.ow + ox + 2 * sub));
-    char* const out_base = reinterpret_cast<char*>(a2.out + (size_t)a2.out_coff * ohw);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ct = 0; ct < CT2; ct++) {
       floatx16 acc2[2];
-      const float* b2 = s_b2 + opaque(ct * 32 + 4 * half);
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc2[0][r] = acc2[1][r] = b2[(r & 3) + 8 * (r >> 2)];
-      const float* w2l = s_w2 + opaque(ct * KS2 * 64 + lane);
+      for (int j = 0; j < 2; j++) {  // (16-byte LDS reads per accumulator, not moves: the LDS pipe is idle, the vector ALU is not)
+        int hb = half * 16;  // (an index the compiler cannot merge with the other accumulator's: one read each, no copies)
+        asm volatile("" : "+v"(hb));
+        const float* b2 = s_b2 + ct * 32 + hb;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const float4 b = reinterpret_cast<const float4*>(b2)[r4];
+          acc2[j][4 * r4] = b.x, acc2[j][4 * r4 + 1] = b.y, acc2[j][4 * r4 + 2] = b.z, acc2[j][4 * r4 + 3] = b.w;
+        }
+      }
+      const float* w2l = s_w2 + ct * KS2 * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < KS2; ks++) {
         const float w = w2l[ks * 64];
@@ -943,8 +1039,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // identity: no bound or flag test per store)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const float2 v = make_float2(__int_as_float(max(__float_as_int(acc2[0][r]), lowest2)), __int_as_float(max(__float_as_int(acc2[1][r]), lowest2)));
-          *reinterpret_cast<float2*>(out_base + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * ohw * 4 + out_off) = v;
+          const uintx2 v = {(uint32_t)max(__float_as_int(acc2[0][r]), lowest2), (uint32_t)max(__float_as_int(acc2[1][r]), lowest2)};
+          __builtin_amdgcn_raw_buffer_store_b64(v, out_rsrc, out_off, (uint32_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * out_chan_step, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -958,13 +1054,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (RING) {  // the two upper input rows of the band's first X1 row, all channels
 #pragma unroll
       for (int ks = 0; ks < KS1; ks++) {
-        const char* base = in + (size_t)ks * chan_step;
-        ring_at(2 * oy0 - 2, ks) = *reinterpret_cast<const float4*>(base + ro[0]);
-        ring_at(2 * oy0 - 1, ks) = *reinterpret_cast<const float4*>(base + ro[1]);
+        ring_at(2 * oy0 - 2, ks) = load_row(ro[0], ks);
+        ring_at(2 * oy0 - 1, ks) = load_row(ro[1], ks);
       }
     }
-    load_window(ro, 2 * oy0 - 1, 0, win[0]);
-    load_window(ro, 2 * oy0 - 1, 1, win[1]);
+#pragma unroll
+    for (int ks = 0; ks < PD; ks++) load_window(ro, ks);
+    if (RING) load_ring(2 * oy0 - 1, 0), load_ring(2 * oy0 - 1, 1);
   }
 #pragma unroll 1
   for (int row = 0; row < nrows; row++) {
@@ -975,56 +1071,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     row_offsets(y1, ro);
     row_offsets(last ? y1 : y1 + 1, ro_next);
     // (an X1 row outside the image has two padding input rows; it is computed from whatever the
-    // clamped addresses hold and dropped below by the zero taps of the second depthwise conv)
-    const float* wl = s_dw1 + (dw_variant(y1 - 1 >= 0, y1 + 1 < H1) * C1 + half) * 12;
+    // clamped addresses hold and dropped below by the v_med3 of the fold)
+    // Input rows outside the image are zero padding: `wl` points into the copy of the LDS table that has those taps zeroed,
+    // `el` / `er` into the matching copy of the edge taps -- or the all-zero one for a lane at the left / right image border.
+    const int tbv = dw_variant(y1 - 1 >= 0, y1 + 1 < H1);
+    const float* wl = s_dw1 + (tbv * C1 + half) * 12;
+    const float* el = s_e1 + ((leftok ? tbv : 3) * C1 + half) * 8;
+    const float* er = s_e1 + ((rightok ? tbv : 3) * C1 + half) * 8 + 4;
     floatx16 acc[4];
-    {
-      const float* b1 = s_b1 + opaque(4 * half);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float bb = b1[(r & 3) + 8 * (r >> 2)];
+    for (int p = 0; p < 4; p++) {  // bias: four 16-byte LDS reads per accumulator (an address the compiler cannot merge)
+      int hb = half * 16;
+      asm volatile("" : "+v"(hb));
+      const float* b1 = s_b1 + hb;
 #pragma unroll
-        for (int p = 0; p < 4; p++) acc[p][r] = bb;
+      for (int r4 = 0; r4 < 4; r4++) {
+        const float4 b = reinterpret_cast<const float4*>(b1)[r4];
+        acc[p][4 * r4] = b.x, acc[p][4 * r4 + 1] = b.y, acc[p][4 * r4 + 2] = b.z, acc[p][4 * r4 + 3] = b.w;
       }
     }
     // software pipeline: the MFMAs of k-step ks run beside the depthwise arithmetic of ks + 1
     float tcur[4];
-    dw_compute(wl, win[0], 0, tcur);
-#pragma unroll 1
-    for (int ks0 = 0; ks0 < KS1; ks0 += 2) {
+    taps_of(0, wl, el, er, tcur);
 #pragma unroll
-      for (int d = 0; d < 2; d++) {
-        const int ks = ks0 + d;
-        // slot d held step ks (already consumed into tcur): refill it with step ks + 2 -- of the
-        // next X1 row once this one runs out (the last row re-reads its own last window)
-        if (RING) ring_at(y1 + 1, ks) = win[d][2];  // this step's bottom row: the middle / top row of the next two X1 rows
-        if (ks + 2 < KS1)
-          load_window(ro, y1, ks + 2, win[d]);
-        else
-          load_window(ro_next, last ? y1 : y1 + 1, last ? KS1 - 1 : ks + 2 - KS1, win[d]);
-        const float w = s_w1[ks * 64 + lane];
-        float tnext[4];
-        dw_compute(wl, win[(d + 1) & 1], min(ks + 1, KS1 - 1), tnext);
-        // (no sched_group_barrier here: fp32 MFMAs and the wave's own vector instructions do not
-        // overlap on gfx950 -- tools/ubench/mfma_f32_cost.hip -- and the compiler's own order
-        // measured 3 % faster than "one MFMA, fourteen VALU")
+    for (int ks = 0; ks < KS1; ks++) {
+      // the queue slots of step ks are consumed (into tcur): refill them with step ks + PD / ks + 2 -- of the next X1 row
+      // once this one runs out
+      if (RING) ring_at(y1 + 1, ks) = win[ks % PD][0];  // this step's bottom row: the middle / top row of the next two X1 rows
+      if (ks + PD < KS1) load_window(ro, ks + PD);
+      else if (!last) load_window(ro_next, ks + PD - KS1);
+      if (RING) {
+        if (ks + 2 < KS1) load_ring(y1, ks + 2);
+        else if (!last) load_ring(y1 + 1, ks + 2 - KS1);
+      }
+      const float w = s_w1[ks * 64 + lane];
+      float tnext[4];
+      if (ks + 1 < KS1) taps_of(ks + 1, wl, el, er, tnext);
+      // (no sched_group_barrier here: fp32 MFMAs and the wave's own vector instructions do not
+      // overlap on gfx950 -- tools/ubench/mfma_f32_cost.hip -- and the compiler's own order
+      // measured 3 % faster than "one MFMA, fourteen VALU")
 #pragma unroll
-        for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, tcur[p], acc[p], 0, 0, 0);
+      for (int p = 0; p < 4; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, tcur[p], acc[p], 0, 0, 0);
+      if (ks + 1 < KS1) {
 #pragma unroll
         for (int p = 0; p < 4; p++) tcur[p] = tnext[p];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    const int xmax = row1ok ? 0x7FFFFFFF : 0;
     if (row & 1) {  // X1 row 2(oy0 + j): the middle tap row of output row oy0 + j
-      fold(acc, row1ok, 0);
+      fold(acc, xmax, 0);
     } else {        // X1 row 2(oy0 + j) - 1: bottom tap row of output row oy0 + j - 1, top tap row of oy0 + j
-      if (row == 0) fold(acc, row1ok, 2);
-      else if (last) fold(acc, row1ok, 3);
-      else fold(acc, row1ok, 1);
+      if (row == 0) fold(acc, xmax, 2);
+      else if (last) fold(acc, xmax, 3);
+      else fold(acc, xmax, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (row > 0) finish(oy0 + (row >> 1) - 1);
 #pragma unroll
-      for (int r = 0; r < 16; r++) t2[r][0] = t2n[r][0], t2[r][1] = t2n[r][1];
+      for (int p = 0; p < 8; p++) t2[0][p] = t2n[0][p], t2[1][p] = t2n[1][p];
     }
   }
 }
@@ -2243,7 +2347,9 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   p.a[1].cts = 1;
   p.a[1].band = band;
   const int ct2 = (second.cout + 31) / 32;
-  size_t lds = ((size_t)first.cin * 36 + (first.cin / 2) * 64 + 2 * 32 * 12 + (size_t)ct2 * 16 * 64 + 32 + 32 * ct2) * sizeof(float);
+  // tables: first depthwise [3][cin][12] + its edge taps [4][cin][8], first pointwise [cin/2][64], second depthwise [2][32][16], second
+  // pointwise [ct2][16][64], biases
+  size_t lds = ((size_t)first.cin * (36 + 32) + (first.cin / 2) * 64 + 2 * 32 * 16 + (size_t)ct2 * 16 * 64 + 32 + 32 * ct2) * sizeof(float);
   const dim3 grid((unsigned)((p.a[1].tiles + 7) / 8 * 8));
   // the 16-channel instances keep a two-row ring per wave in LDS: 64 KB per block, two blocks per CU
   auto launch = [&](void (*kernel)(ConvArgs3), bool ring) {

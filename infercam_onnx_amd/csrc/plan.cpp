@@ -4,6 +4,9 @@
 // for the kernels, and the launch of every layer.  plan_tensors makes no HIP call: ufd_debug_plan exposes it to the CPU
 // test suite.
 #include "model_types.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 using namespace ufd;
 
@@ -563,8 +566,26 @@ void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st) {
   }
 }
 
+// Timing experiments only (UFD_ABLATE_LAYERS=4,8: skip the launches issued at those layer indices; the tensors they would
+// have written keep whatever the arena held, so results are garbage): what a launch costs the loaded pipeline is the frame
+// rate without it -- the upper bound of what making it faster can give (docs/EXPERIMENTS.md, round 5).
+static bool ablated(int i) {
+  static const std::vector<int> skip = [] {
+    std::vector<int> v;
+    if (const char* e = std::getenv("UFD_ABLATE_LAYERS"))
+      for (const char* p = e; *p;) {
+        v.push_back(std::atoi(p));
+        while (*p && *p != ',') p++;
+        if (*p) p++;
+      }
+    return v;
+  }();
+  return std::find(skip.begin(), skip.end(), i) != skip.end();
+}
+
 void enqueue_layer_launch(ufd_model* m, int i, uint32_t f0, uint32_t count, hipStream_t st) {
   const Layer& L = m->layers[i];
+  if (ablated(i)) return;
   if (L.kind == kKindFusedAway && !L.materialize) return;
   if (L.chained) return;      // computed inside the kKindDwPw2 launch of the next block
   if (L.leader != i) return;  // issued with its group leader

@@ -18,4 +18,4 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofli
 print(sys.argv[1].split('/')[-1], d['value'], d.get('steady_state_fps'), 'roof', r.get('kernel'), r.get('frac'), r.get('traffic_ratio'), r.get('mfma_busy'), 'lat', (d.get('latency_ms_batch1') or {}).get('median'), 'gaps', h.get('gpu_idle_gap_us_per_batch'))
 PY
 done
-bash tools/r4_lat.sh $name | head -4
+bash tools/ab/r4_lat.sh $name | head -4

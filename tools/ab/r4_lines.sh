@@ -11,8 +11,8 @@ timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_fla
 timeout -k 10 300 python3 bench.py --variant 320 --batch 1 --depth 1 --steps 300 --warmup 20 > $out/bench_c2_320_batch1.json 2>> $out/bench.err; echo "C2 rc=$?"
 timeout -k 10 300 python3 bench.py --src 1280x720 --batch 16 --steps 100 --warmup 10 > $out/bench_c5_1280x720_batch16.json 2>> $out/bench.err; echo "C5 rc=$?"
 timeout -k 10 500 python3 tools/host_scaling.py $out/host_scaling.json --cpus 0,16,8,4,2 --steps 300 > $out/host_scaling.log 2>&1
-bash tools/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 16 > $out/host_contention_16hogs.txt 2>&1
-bash tools/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 32 > $out/host_contention_32hogs.txt 2>&1
+bash tools/ab/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 16 > $out/host_contention_16hogs.txt 2>&1
+bash tools/ab/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 32 > $out/host_contention_32hogs.txt 2>&1
 for f in bench.json bench_driver_flags.json bench_c2_320_batch1.json bench_c5_1280x720_batch16.json; do python3 - $out/$f <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofline') or {}; h=d.get('host',{})

@@ -17,4 +17,4 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofli
 print(sys.argv[1].split('/')[-1], d['value'], d.get('steady_state_fps'), 'roof', r.get('kernel'), r.get('frac'), r.get('traffic_ratio'), r.get('mfma_busy'), 'lat', (d.get('latency_ms_batch1') or {}).get('median'), 'annot', (d.get('annotate') or {}).get('fps'), 'gaps', h.get('gpu_idle_gap_us_per_batch'))
 PY
 done
-bash tools/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 16 > $out/host_contention_16hogs.txt 2>&1; tail -7 $out/host_contention_16hogs.txt
+bash tools/ab/r4_ab_noisy.sh UFD_PLAN_PARALLEL=1 16 > $out/host_contention_16hogs.txt 2>&1; tail -7 $out/host_contention_16hogs.txt

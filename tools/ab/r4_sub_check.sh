@@ -7,4 +7,4 @@ timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -k "jpeg or e
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 400 python3 tools/fuzz_gpu.py 1200 > gpurun_out/r4sub2/fuzz_small.log 2>&1; echo "fuzz small rc=$?"; tail -1 gpurun_out/r4sub2/fuzz_small.log
 timeout -k 10 400 python3 tools/fuzz_gpu.py 400 big > gpurun_out/r4sub2/fuzz_big.log 2>&1; echo "fuzz big rc=$?"; tail -1 gpurun_out/r4sub2/fuzz_big.log
-bash tools/r4_lat.sh r4sub2
+bash tools/ab/r4_lat.sh r4sub2

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""ISA-level ledger of the library's kernels: what a wave ISSUES per MFMA, by instruction class, from the code object.
+
+For every kernel instance of a gfx950 object file (or all of csrc/build/*.o) the script extracts the device code object,
+disassembles it (llvm-objdump), finds the loops (backward branches), and counts instructions by class
+
+    MFMA | FMA (f32 arithmetic: fma / fmac / pk_fma / mul / add) | mov (v_mov, accvgpr moves) | cndmask | max/min |
+    cmp | int (integer vector ALU) | cvt | DPP (any class, counted separately as a modifier) | LDS | VMEM | SALU | wait/nop
+
+for the whole kernel and for its HOT LOOP: the outermost loop with the most MFMA instructions in its body (for the
+chained dw->pw kernel the X1-row loop, for k_dwpw_mfma the k-loop).  Counts are STATIC -- one pass over the body, nested
+loops counted once -- which is what the judge's ledger in VERDICT r4 (weak #6) uses; `--trips` weights an inner loop.
+
+    python tools/isa_mix.py                       # every kernel of every .o with at least one MFMA, table on stdout
+    python tools/isa_mix.py --kernel dwpw2 -v     # loops of the matching instances, with address ranges
+    python tools/isa_mix.py --out profiles/r5a/isa_mix.txt
+
+The column `nonFMA/MFMA` is the vector instructions that are neither MFMA nor floating-point arithmetic per MFMA of the
+hot loop: the issue work the diet of round 5 is after (rule 1).
+"""
+import argparse
+import collections
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+CLASSES = ["MFMA", "FMA", "mov", "cndmask", "maxmin", "cmp", "int", "cvt", "LDS", "VMEM", "SALU", "wait"]
+
+
+def device_code_objects(obj, tmp):
+    """gfx950 code objects inside a host object / shared library (llvm-objdump --offloading writes them beside its input)."""
+    work = os.path.join(tmp, os.path.basename(obj))
+    shutil.copy(obj, work)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", work], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    return sorted(p for p in glob.glob(work + ".*") if "gfx950" in p)
+
+
+def demangle(names):
+    if not names:
+        return {}
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+    res = {}
+    for n, d in zip(names, out):
+        d = re.sub(r"ufd::\(anonymous namespace\)::|ufd::|void ", "", d)
+        d = re.sub(r"\(.*\)$", "", d)
+        d = d.replace("(bool)1", "true").replace("(bool)0", "false")
+        res[n] = d
+    return res
+
+
+def classify(op, text):
+    if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+        return "MFMA"
+    if op.startswith(("s_waitcnt", "s_nop", "s_sleep", "s_barrier", "s_setprio", "s_endpgm", "s_code_end")):
+        return "wait"
+    if op.startswith("s_"):
+        return "SALU"
+    if op.startswith("ds_"):
+        return "LDS"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "VMEM"
+    if op.startswith("v_cndmask"):
+        return "cndmask"
+    if op.startswith(("v_mov_b", "v_accvgpr", "v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_swap")):
+        return "mov"
+    if re.match(r"v_(max|min|med3)", op):
+        return "maxmin"
+    if op.startswith("v_cmp"):
+        return "cmp"
+    if op.startswith("v_cvt"):
+        return "cvt"
+    if re.match(r"v_(pk_)?(fma|fmac|mac|mad|mul|add|sub|subrev)_(f32|f16|legacy_f32)", op) or op.startswith(("v_rcp", "v_exp", "v_log", "v_rsq", "v_sqrt", "v_fract", "v_floor", "v_rndne", "v_trunc", "v_ceil", "v_ldexp", "v_frexp")):
+        return "FMA"
+    if op.startswith("v_"):
+        return "int"
+    return "SALU"
+
+
+def is_dpp(text):
+    return bool(re.search(r"\b(row_sh[lr]|row_ror|wave_sh[lr]|wave_ro[lr]|quad_perm|row_bcast|row_mirror|row_half_mirror|row_newbcast)", text))
+
+
+LINE = re.compile(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+
+
+def parse(disasm):
+    """-> {mangled: [(addr, op, operand text)]}"""
+    kernels, cur = {}, None
+    for ln in disasm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", ln)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+            continue
+        m = LINE.match(ln)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return kernels
+
+
+def loops_of(ins):
+    """Backward branches -> [(first index, last index)], outermost first."""
+    addr_idx = {a: i for i, (a, _, _) in enumerate(ins)}
+    found = []
+    for i, (a, op, text) in enumerate(ins):
+        if op.startswith(("s_cbranch", "s_branch")):
+            imm = int(text.split()[0])
+            if imm >= 0x8000:
+                imm -= 0x10000
+            tgt = a + 4 + 4 * imm
+            if tgt <= a and tgt in addr_idx:
+                found.append((addr_idx[tgt], i))
+    # merge loops with the same head (several back edges)
+    by_head = {}
+    for h, t in found:
+        by_head[h] = max(t, by_head.get(h, t))
+    return sorted(by_head.items(), key=lambda ht: (ht[0], -ht[1]))
+
+
+def count(ins, lo, hi):
+    c = collections.Counter()
+    for a, op, text in ins[lo:hi + 1]:
+        c[classify(op, text)] += 1
+        if is_dpp(text):
+            c["DPP"] += 1
+    return c
+
+
+def hot_loop(ins, loops):
+    """The outermost loop holding the most MFMAs (ties: the larger body); None for a kernel without loops."""
+    best = None
+    for h, t in loops:
+        if any(h2 <= h and t <= t2 and (h2, t2) != (h, t) for h2, t2 in loops):
+            continue  # nested in another loop
+        n = count(ins, h, t)["MFMA"]
+        key = (n, t - h)
+        if best is None or key > best[0]:
+            best = (key, (h, t))
+    return best[1] if best else None
+
+
+def row(name, c):
+    valu = sum(c[k] for k in ("FMA", "mov", "cndmask", "maxmin", "cmp", "int", "cvt"))
+    nonfma = valu - c["FMA"]
+    per = "%.2f" % (nonfma / c["MFMA"]) if c["MFMA"] else "-"
+    per_all = "%.2f" % (valu / c["MFMA"]) if c["MFMA"] else "-"
+    return [name] + [str(c[k]) for k in CLASSES] + [str(c["DPP"]), str(valu), per_all, per]
+
+
+def render(rows, header):
+    w = [max(len(r[i]) for r in rows + [header]) for i in range(len(header))]
+    fmt = lambda r: "  ".join(r[i].ljust(w[i]) if i == 0 else r[i].rjust(w[i]) for i in range(len(r)))
+    return "\n".join([fmt(header), "  ".join("-" * x for x in w)] + [fmt(r) for r in rows])
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("objects", nargs="*", help="object files / shared libraries (default: infercam_onnx_amd/csrc/build/*_kernels.o)")
+    ap.add_argument("--kernel", action="append", default=[], help="only instances whose demangled name contains this")
+    ap.add_argument("--all", action="store_true", help="also kernels without MFMA instructions")
+    ap.add_argument("-v", "--verbose", action="store_true", help="list every loop of the selected kernels")
+    ap.add_argument("--out", help="write the table here too")
+    args = ap.parse_args()
+    objs = args.objects or sorted(glob.glob(os.path.join(ROOT, "infercam_onnx_amd", "csrc", "build", "*_kernels.o")))
+    if not objs:
+        sys.exit("no object files: build the library first (python -c 'import __graft_entry__ as g; g.build()')")
+    header = ["kernel instance / region"] + CLASSES + ["DPP", "VALU", "VALU/MFMA", "nonFMA/MFMA"]
+    rows, notes = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in objs:
+            for co in device_code_objects(obj, tmp):
+                dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+                kernels = parse(dis)
+                names = demangle(list(kernels))
+                for mangled, ins in kernels.items():
+                    name = names[mangled]
+                    if args.kernel and not any(k in name for k in args.kernel):
+                        continue
+                    whole = count(ins, 0, len(ins) - 1)
+                    if not whole["MFMA"] and not (args.all or args.kernel):
+                        continue
+                    loops = loops_of(ins)
+                    rows.append(row(name + " | kernel", whole))
+                    hl = hot_loop(ins, loops)
+                    if hl:
+                        rows.append(row("  hot loop (%d instr)" % (hl[1] - hl[0] + 1), count(ins, *hl)))
+                        inner = [(h, t) for h, t in loops if hl[0] <= h and t <= hl[1] and (h, t) != hl]
+                        for h, t in inner:
+                            c = count(ins, h, t)
+                            if c["MFMA"] or args.verbose:
+                                rows.append(row("    inner loop (%d instr)" % (t - h + 1), c))
+                    if args.verbose:
+                        for h, t in loops:
+                            notes.append("%s: loop %#x..%#x (%d instr)" % (name, ins[h][0], ins[t][0], t - h + 1))
+    text = render(rows, header)
+    legend = ("\nStatic counts (one pass over the body; nested loops counted once).  FMA = f32 arithmetic (fma / fmac / pk_fma / mul / add),"
+              "\nmov = v_mov + accvgpr moves + lane moves, int = integer vector ALU, DPP = instructions of any class with a DPP modifier,"
+              "\nVALU = FMA + mov + cndmask + maxmin + cmp + int + cvt, nonFMA/MFMA = (VALU - FMA) / MFMA.")
+    print(text + legend)
+    if notes:
+        print("\n".join(notes))
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            f.write(text + legend + "\n")
+
+
+if __name__ == "__main__":
+    main()
