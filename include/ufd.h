@@ -146,9 +146,10 @@ int ufd_infer_rgb_batch(ufd_model* m, const uint8_t* rgb, uint32_t w, uint32_t h
                         ufd_det* out, uint32_t cap, uint32_t* n);
 
 /* Asynchronous form (the 10-slot StaticImage ring of lib.rs:32-37 becomes `slots` in-flight
- * batches): ufd_submit_jpeg_batch copies/entropy-decodes on host workers and enqueues the GPU
- * work on one of the handle's streams, returning a ticket; ufd_wait blocks until that batch is done
- * and fills the outputs given at submit.  Input and output buffers must stay valid until then.
+ * batches): ufd_submit_jpeg_batch only QUEUES the batch for one of the handle's four issue workers and returns a
+ * ticket -- the worker scans the JPEG headers, copies the bytes into its pinned staging block and enqueues the GPU work
+ * on its context's stream later, so nothing of the inputs has been read when the call returns; ufd_wait blocks until
+ * that batch is done and fills the outputs given at submit.  Input and output buffers must stay valid until then.
  * The handle runs four device contexts in rotation (one stream each: the runtime's four hardware queues): keep six to
  * eight batches in flight (six is what bench.py uses) for full throughput; one at a time is the lowest-latency form. */
 #define UFD_MAX_SLOTS 8
@@ -310,7 +311,10 @@ int ufd_sched_debug_table(ufd_sched* s, uint32_t* live, uint32_t* allocated);
 int ufd_sched_push(ufd_sched* s, uint32_t stream, const uint8_t* jpeg, size_t len, uint64_t tag);
 /* The same for `count` frames of one stream in one call (a router thread that drained several frames off its socket):
  * they are taken in order while the ring has free slots, *accepted (optional) = how many were queued, the rest are
- * dropped exactly as single pushes would be (UFD_E_FULL unless all were accepted).  tags may be NULL (all 0). */
+ * dropped exactly as single pushes would be (UFD_E_FULL unless all were accepted).  tags may be NULL (all 0).
+ * ufd_sched_stats counts every frame a call did not take as `dropped` (and `pushed`) -- per ATTEMPT: a caller that
+ * offers the unaccepted tail again (bench.py --one-process does) counts such a frame once per call, so `accepted` and
+ * `delivered` are the numbers to balance, not `pushed`. */
 int ufd_sched_push_batch(ufd_sched* s, uint32_t stream, const uint8_t* const* jpegs, const size_t* lens, const uint64_t* tags,
                          uint32_t count, uint32_t* accepted);
 /* Blocks until every frame pushed before the call has been delivered. */

@@ -235,7 +235,7 @@ struct Det {
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
                      unsigned long long* d_mat, uint32_t B, hipStream_t s);
-size_t nms_matrix_bytes(uint32_t B);
+size_t nms_matrix_bytes(uint32_t B, uint32_t K);
 
 // ---------------- N1: rectangles + JPEG re-encode (encode_kernels.hip, encode_host.cpp) ----------------
 // inferer.rs:38-40 on frames resident in HBM as tight RGB8 (pitch 3 * width, frame stride rgb_stride).  Frames whose

@@ -1,8 +1,8 @@
 // model.cpp -- host side of libufacehip.so: the C ABI of include/ufd.h and the per-batch pipeline that replaces the
-// reference's single Inferer task (infer_server/src/inferer.rs:29-50).  A handle owns three device contexts (a compute
-// stream and a working set each; one shared copy stream) and an issue worker per context:
-//   worker: header + marker scan of the batch's JPEGs, their bytes into one pinned block, one H2D, then every launch --
-//           device entropy decoding -> IDCT -> upsample / colour / normalise (fused into the stem) [-> Triangle resize] ->
+// reference's single Inferer task (infer_server/src/inferer.rs:29-50).  A handle owns four device contexts (a stream and a
+// working set each = the runtime's four hardware queues; NO copy stream, see below) and an issue worker per context:
+//   worker: header + marker scan of the batch's JPEGs, their bytes into one pinned block, fetched by a kernel on the
+//           context's own stream (k_stage_in), then every launch -- device entropy decoding -> IDCT -> upsample / colour / normalise (fused into the stem) [-> Triangle resize] ->
 //           the network (plan.cpp) -> softmax / prior decode / threshold -> sort + greedy NMS [-> rectangles + re-encode]
 //   ufd_wait: a few hundred bytes of detections per frame come back (and the annotated streams).
 // Weights (1.1 MB) and priors stay resident in HBM for the life of the handle.  State and shared helpers: model_types.hpp.
@@ -336,6 +336,13 @@ int fetch_streams(ufd_model* m, Slot& s) {
     // (the caller's buffer is not pinned host memory: a copy on the batch's own stream, behind whatever that context has
     // queued since -- the price of pageable output)
     HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, s.ctx->stream));
+    HIPC(m, record_behind_copy(s.enc_copied, s.ctx->stream));
+    HIPC(m, hipEventSynchronize(s.enc_copied));
+  } else if (fit > (a.jpeg_cap & ~(size_t)15)) {
+    // k_fetch_streams writes whole 16-byte pieces only: a buffer whose size is no multiple of 16 and whose last stream ends in
+    // the ragged tail gets those 1..15 bytes (the EOI marker or the multipart trailer) by a copy of their own.
+    const size_t done = a.jpeg_cap & ~(size_t)15;
+    HIPC(m, hipMemcpyAsync(a.jpeg_out + done, s.d_enc_out + done, fit - done, hipMemcpyDeviceToHost, s.ctx->stream));
     HIPC(m, record_behind_copy(s.enc_copied, s.ctx->stream));
     HIPC(m, hipEventSynchronize(s.enc_copied));
   }
@@ -749,6 +756,9 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
     // frames are equally sized in a stream: copy the used prefix of every slab in one 2-D copy
     HIPC(m, hipMemcpy2DAsync(c.d_coef_buf[buf], m->coef_stride * 2, s.h_coef, m->coef_stride * 2, used * 2, count,
                              hipMemcpyHostToDevice, c.stream));
+    // (span_begin records an event: never directly behind an asynchronous copy -- ROCm 7.2's runtime keeps ~2 KB of host memory
+    // per such event, record_behind_copy above)
+    hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, c.stream);
   }
   span_begin(s);
   return UFD_OK;
@@ -1464,7 +1474,7 @@ int create(const ufd_config* cfg, ufd_model** out) {
     HIPB(hipMalloc(&c.d_counts, B * sizeof(uint32_t)));
     HIPB(hipMemset(c.d_counts, 0, B * sizeof(uint32_t)));
     HIPB(hipMalloc(&c.d_spill, B * m->K * sizeof(float4)));
-    HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B)));
+    HIPB(hipMalloc(&c.d_nms_mat, nms_matrix_bytes((uint32_t)B, (uint32_t)m->K)));
   }
   if (cfg->flags & UFD_FLAG_TAP_LAYERS) {
     m->tap_buf.assign(m->tensors.size(), nullptr);

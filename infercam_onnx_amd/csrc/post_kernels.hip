@@ -28,6 +28,8 @@ constexpr int kMatHalf = 2048;            // the scan walks the matrix in square
 constexpr int kMatMax = 8192;             // frames up to this many candidates take it (round 4; 4096 before: the reference has no cap,
                                           // nn.rs:198-224, and a low threshold on a crowd picture reaches thousands)
 constexpr int kMatWords = kMatMax / 64;   // 64-bit words per matrix row
+// rows of a frame's matrix: a frame has at most K candidates (UltraFace-320: 4420, 4.5 MB per frame instead of 8)
+__host__ __device__ constexpr int mat_rows(int K) { return K < kMatMax ? K : kMatMax; }
 constexpr int kHalfWords = kMatHalf / 64;
 constexpr int kMatGridRows = 64;          // row blocks in k_nms_matrix's grid: a frame with more than 4096 candidates takes two passes
 constexpr int kSortLdsHeavy = 4096;       // a frame with more than kSortLds candidates leaves for the matrix path after its
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void k_nms_matrix(const uint32_t* __restrict__
           const bool hit = iou_exceeds(s_col[wave][b], s_area[wave][b], bi, max_iou);  // (wave-uniform j: the ballot inside sees all rows)
           word |= (hit && j > i) ? (1ull << b) : 0ull;
         }
-        if (i < n) mat[((size_t)frame * kMatMax + i) * kMatWords + cb] = word;
+        if (i < n) mat[((size_t)frame * mat_rows(K) + i) * kMatWords + cb] = word;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // own reads of s_col before the next column half's stores
   }
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, word = lane & 31;
   const int Q = (n + kMatHalf - 1) / kMatHalf;
   if (Q == 1 && wave > 0) return;  // (no barrier on this path)
-  const unsigned long long* fmat = mat + (size_t)frame * kMatMax * kMatWords;
+  const unsigned long long* fmat = mat + (size_t)frame * mat_rows(K) * kMatWords;
   const unsigned long long* fkeys = gkeys + (size_t)frame * key_stride;
   const float4* fsp = spill + (size_t)frame * K;
   Det* fd = dets + (size_t)frame * det_stride;
@@ -686,6 +688,6 @@ void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_
   hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
                      d_ndet);
 }
-size_t nms_matrix_bytes(uint32_t B) { return (size_t)B * kMatMax * kMatWords * sizeof(unsigned long long); }
+size_t nms_matrix_bytes(uint32_t B, uint32_t K) { return (size_t)B * mat_rows((int)K) * kMatWords * sizeof(unsigned long long); }
 
 }  // namespace ufd

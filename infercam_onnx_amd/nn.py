@@ -516,7 +516,8 @@ class UltrafaceModel(InferModel):
                 owner.ufd_host_free(mem)
                 self.jpeg_mem = None
 
-    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True, pinned=True):
+    def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True, pinned=True,
+                            cap_bytes=None):
         """Buffers of one annotate batch (reusable): pinned output memory from ufd_host_alloc (the batch's own chain writes
         the finished streams there); pinned=False: ordinary memory, fetched by a copy in ufd_wait.  label_size = the
         slot's (width, height) -- 1280 x 720 in the reference's router, whatever the JPEG's size (router.rs:66-67)."""
@@ -525,7 +526,7 @@ class UltrafaceModel(InferModel):
         for k in UltrafaceModel._Batch.__slots__:
             if hasattr(base, k):
                 setattr(b, k, getattr(base, k))
-        if out_bytes_per_frame is None:  # worst case of the largest frame in the batch
+        if out_bytes_per_frame is None and cap_bytes is None:  # worst case of the largest frame in the batch
             out_bytes_per_frame = 0
             for x in b.bufs:
                 try:
@@ -533,7 +534,7 @@ class UltrafaceModel(InferModel):
                 except UfdError:
                     continue
                 out_bytes_per_frame = max(out_bytes_per_frame, self._lib.ufd_encode_bound(w, h))
-        cap = max(int(out_bytes_per_frame), 1024) * b.count
+        cap = max(int(out_bytes_per_frame), 1024) * b.count if cap_bytes is None else int(cap_bytes)  # (cap_bytes: the exact size, tests)
         b.owner = self._lib
         if pinned:
             b.jpeg_mem = self._lib.ufd_host_alloc(cap)

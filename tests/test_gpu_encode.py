@@ -241,6 +241,29 @@ def test_annotate_streams_into_pinned_and_into_ordinary_memory(weights):
             assert j0[k % 4] is None and all(j is not None and j[:2] == b"\xff\xd8" for i, j in enumerate(j0) if i != k % 4)
 
 
+def test_annotate_pinned_buffer_of_exactly_the_packed_size(weights):
+    """A pinned output buffer whose size is the packed total of the batch's streams and no multiple of 16: the launch that
+    writes the streams (k_fetch_streams) moves whole 16-byte pieces, so the last stream's ragged tail -- its EOI marker --
+    comes by a copy of its own in ufd_wait (advisor finding, round 4: it used to be lost with the frame reported UFD_OK)."""
+    W, H = 320, 240
+    with _model(320, weights, max_batch=2, max_src=(W, H), det_cap=512, profile=True) as m:
+        for seed in range(8):
+            jpegs = synth.synth_jpeg_pool(40 + seed, 2, W, H, quality=90, subsampling="4:2:0")
+            ref_d, ref_st, ref_s = m.annotate_jpeg_batch(jpegs, (W, H))
+            total = ((len(ref_s[0]) + 15) & ~15) + len(ref_s[1])  # streams are packed at 16-byte boundaries
+            if total % 16:
+                break
+        assert total % 16, "no batch with a ragged packed size among the seeds"
+        b = m.prep_annotate_batch(jpegs, (W, H), cap_bytes=total, pinned=True)
+        m.profile_reset()
+        dets, status, streams = m.wait(m.submit_annotate_batch(b))
+        assert "d2h_streams" in {p["name"] for p in m.profile_read() if p["launches"]}  # the pinned path is the one tested
+        assert status == [0, 0] and streams == ref_s and streams[1][-2:] == b"\xff\xd9" and dets == ref_d
+        b = m.prep_annotate_batch(jpegs, (W, H), cap_bytes=total - 1, pinned=True)  # one byte short: the last frame is truncated
+        dets, status, streams = m.wait(m.submit_annotate_batch(b))
+        assert status == [0, nn.UFD_E_TRUNCATED] and streams[0] == ref_s[0] and streams[1] is None
+
+
 def test_annotate_output_buffer_too_small(weights):
     W, H = 320, 240
     jpegs = synth.synth_jpeg_pool(2, 4, W, H, quality=90, subsampling="4:2:0")

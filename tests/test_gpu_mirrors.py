@@ -187,14 +187,15 @@ def test_concurrent_callers_on_one_handle(weights):
         m.close()
 
 
-@pytest.mark.parametrize("args", [["16", "clean"], ["8", "small"]])
+@pytest.mark.parametrize("args", [["16", "clean"], ["8", "small"], ["8", "hostentropy"]])
 def test_soak_host_memory_does_not_grow_per_batch(args):
     """tools/soak.py, 16 s of the bench's submit / wait loop on the host-bytes path (~25 000 batches): the process's resident
     set must not grow with the batch count.  Round 4 found ROCm 7.2's runtime keeping ~2 KB of host memory per event recorded
     directly behind an asynchronous copy (12 GB per hour at the bench's rate); the library now puts an empty kernel between
     the two (model.cpp: record_behind_copy; tools/ubench/leak_probe2.hip shows the runtime's behaviour on its own).
     "small": 8 s of two-frame batches (~45 000, every 50th with a truncated frame and other Huffman tables) -- the forms a
-    batch of a few frames takes: staging block in and results out by kernels on the context's stream, no copy-engine transfer."""
+    batch of a few frames takes: staging block in and results out by kernels on the context's stream, no copy-engine transfer.
+    "hostentropy": the coefficient slabs of host-decoded batches are copied on the context's stream with an event behind them."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py")] + args, cwd=root, capture_output=True, text=True,
                        timeout=300)
