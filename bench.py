@@ -108,6 +108,11 @@ def parse_args():
     ap.add_argument("--no-extras", "--no-variants", dest="no_extras", action="store_true",
                     help="skip the side measurements (other boundary, stage breakdown, batch-1 latency, verification)")
     ap.add_argument("--restart-rows", type=int, default=0, help="JPEG restart interval in MCU rows (0 = none)")
+    ap.add_argument("--subsampling", choices=["4:2:0", "4:2:2", "4:4:4"], default="4:2:0",
+                    help="chroma subsampling of the synthetic stream (SURVEY 8d: 4:2:0 primary, 4:2:2 = UVC-MJPG-like, what the "
+                         "reference's sender captures, cam_sender/src/sensors.rs:18-68)")
+    ap.add_argument("--no-dht", action="store_true",
+                    help="MJPG flavour without DHT segments (cameras omit the Annex-K tables, SURVEY A1): every frame of the pool is stripped")
     ap.add_argument("--host-threads", type=int, default=0, help="host workers of the handle (0: hardware threads / ranks, <= 32)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,7 +283,9 @@ def main_one_process(args):
         if torch.cuda.device_count() < N:
             raise SystemExit("bench.py --one-process --gpus %d: only %d devices visible" % (N, torch.cuda.device_count()))
         models = nn.UltrafaceModel.create_replicas(variant, 0.5, 0.5, list(range(N)), **kw)
-    pools = [synth.synth_jpeg_pool(r, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows) for r in range(N)]
+    pools = [synth.synth_jpeg_pool(r, args.pool, SW, SH, quality=90, subsampling=args.subsampling, restart_rows=args.restart_rows) for r in range(N)]
+    if args.no_dht:
+        pools = [[synth.strip_dht(j) for j in pool] for pool in pools]
     nb = max(1, args.pool // B)
     batches = [[models[0]._prep_batch(pools[r][i * B:(i + 1) * B]) for i in range(nb)] for r in range(N)]
     sch = scheduler.Scheduler(models_640=models if args.variant == 640 else None, models_320=models if args.variant == 320 else None,
@@ -326,8 +333,9 @@ def main_one_process(args):
         "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": Wm,
         "ms_per_step": round(el / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "UltraFace-%d, one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct frames), batch=%d, seeded "
-                               "synthetic weights" % (args.variant, SW, SH, args.pool, B),
+        "config": {"workload": "UltraFace-%d, one %dx%d synthetic JPEG stream per GPU (q90 %s%s, %d distinct frames), batch=%d, seeded "
+                               "synthetic weights" % (args.variant, SW, SH, args.subsampling, ", no DHT segments (MJPG)" if args.no_dht else "",
+                                                      args.pool, B),
                    "global_batch": N * B,
                    "parallelism": "ONE process: ufd_create_replicas x%d (RCCL weight broadcast) + one ufd_sched over the replicas, "
                                   "stream i -> GPU i mod %d" % (N, N),
@@ -358,6 +366,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
+        if "RANK" not in os.environ and args.gpus > 1:
+            # no launcher: the one-process form of the same configuration (ufd_create_replicas + one scheduler over the
+            # replicas; what the reference's single server process would run) instead of refusing
+            print("bench.py --gpus %d without torch.distributed.run: running the --one-process form" % args.gpus, file=sys.stderr)
+            args.one_process = True
+            if args.cpus > 0:
+                cur = sorted(os.sched_getaffinity(0))
+                os.sched_setaffinity(0, cur[:max(1, min(args.cpus, len(cur)))])
+            return main_one_process(args)
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run --nproc-per-node N"
                          % (args.gpus, world))
     if args.cpus > 0:  # before torch / HIP start their threads: they inherit the mask
@@ -394,7 +411,9 @@ def main():
 
     # ---- this rank's camera stream: pool of distinct synthetic frames (baseline JPEG q90 4:2:0)
     SW, SH = (int(v) for v in args.src.lower().split("x")) if args.src else (W, H)
-    jpegs = synth.synth_jpeg_pool(rank, args.pool, SW, SH, quality=90, subsampling="4:2:0", restart_rows=args.restart_rows)
+    jpegs = synth.synth_jpeg_pool(rank, args.pool, SW, SH, quality=90, subsampling=args.subsampling, restart_rows=args.restart_rows)
+    if args.no_dht:
+        jpegs = [synth.strip_dht(j) for j in jpegs]
     device_entropy = args.entropy == "device"
     if args.input == "hbm" and not device_entropy:
         raise SystemExit("--input hbm needs the device entropy decoder")
@@ -623,19 +642,26 @@ def main():
             got += [(arr[i, :min(b.cnt[i], model.det_cap)].copy(), int(b.cnt[i])) for i in range(b.count)]
         with ThreadPoolExecutor(min(32, usable_cpus())) as ex:
             refs = list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jpegs[:nver * B]))
-        max_err, bad = 0.0, 0
+        from oracle.compare import match_detections
+
+        max_err, bad, excused, unexplained = 0.0, 0, 0, 0
         for (g, n), r in zip(got, refs):
-            if n != len(r):
-                bad += 1
-                continue
-            r = r[:len(g)]
-            if len(g):
-                # set distance: detections whose confidences differ by less than fp32 rounding may swap places
-                d = np.abs(g[:, None, :] - r[None, :, :]).max(2)
-                max_err = max(max_err, float(d.min(1).max()), float(d.min(0).max()))
-        verified = {"frames": len(got), "max_abs_err": max_err, "count_mismatch_frames": bad,
-                    "against": "CPU oracle (oracle/) on the same JPEG bytes, every detection of every frame; tolerance 1e-3 (north_star)"}
-        if max_err > 1e-3 or bad > max(1, len(got) // 50):
+            if n > model.det_cap:  # (more detections than the bench's output rows hold: compare what was returned)
+                r = r[:len(g)]
+            # matched as sets (detections whose confidences differ by less than fp32 rounding may swap places); a detection
+            # without a partner is excused only when its decision provably sat on a threshold at fp32 resolution -- the
+            # rule of tests/helpers.py:assert_dets_match (oracle/compare.py)
+            c = match_detections(g, r, 0.5, 0.5, atol=1e-3)
+            max_err = max(max_err, c["max_err"])
+            bad += len(g) != len(r)
+            excused += len(c["left_got"]) + len(c["left_ref"]) - len(c["not_borderline"])
+            unexplained += len(c["not_borderline"])
+        verified = {"frames": len(got), "max_abs_err": max_err, "count_mismatch_frames": bad, "borderline_detections_excused": excused,
+                    "unexplained_detections": unexplained,
+                    "against": "CPU oracle (oracle/) on the same JPEG bytes, every detection of every frame; tolerance 1e-3 (north_star); "
+                               "a count mismatch passes only when every unmatched detection sits within the tolerance of the "
+                               "confidence or IoU threshold"}
+        if max_err > 1e-3 or unexplained:
             raise SystemExit("bench.py: detections differ from the CPU oracle: %s" % verified)
 
     if rank == 0:
@@ -648,17 +674,22 @@ def main():
         agg = aggregate(loaded if loaded else stats)
         agg_timed = aggregate(stats)
         kern = {k: v for k, v in agg.items() if not k.startswith(("h2d_", "host_"))}
+        # Counter files are per WORKLOAD as well as per build: bytes and busy shares collected on C3 (UltraFace-640, 640x480
+        # 4:2:0, batch 32) say nothing about a batch-1 or 1280x720 line, so they are attached only to a line whose own
+        # workload is the one they were collected on (the stamp tools/finish_profiles.py writes; files without one are C3's).
+        my_workload = {"variant": args.variant, "src": "%dx%d" % (SW, SH), "batch": B, "subsampling": args.subsampling}
+        c3_workload = {"variant": 640, "src": "640x480", "batch": 32, "subsampling": "4:2:0"}
         pmc, pmc_ok = {}, False
         try:  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised by tools/pmc_traffic.py
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            pmc_ok = pmc.get("kernel_source_sha") == kernel_source_sha()
+            pmc_ok = pmc.get("kernel_source_sha") == kernel_source_sha() and pmc.get("workload", c3_workload) == my_workload
         except Exception:
             pass
 
         sq, sq_ok = {}, False
         try:  # rocprofv3 --pmc SQ passes summarised by tools/sq_table.py (tools/pmc_kernel.sh), stamped like the traffic
             sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")))
-            sq_ok = sq.get("kernel_source_sha") == kernel_source_sha()
+            sq_ok = sq.get("kernel_source_sha") == kernel_source_sha() and sq.get("workload", c3_workload) == my_workload
         except Exception:
             pass
 
@@ -706,10 +737,10 @@ def main():
                              "timed region, every %d-th step sampled" % args.profile_every
             roof["sq_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY at commit %s, same "
                                  "kernel sources, kernels alone (tools/pmc_kernel.sh, tools/sq_table.py)" % sq.get("commit", "?")) if sq_ok else \
-                                "not collected for this build of the kernels"
+                                "not collected for this build of the kernels on this workload"
             roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, FETCH x2 on gfx950) at commit %s, "
                                       "same kernel sources, per template instance" % pmc.get("commit", "?")) if pmc_ok else \
-                                     "not measured for this build of the kernels (tools/collect_profiles.sh refreshes it)"
+                                     "not measured for this build of the kernels on this workload (tools/collect_profiles.sh refreshes it)"
             # every template instance of the same kernel function, each with its own flops / bytes / traffic
             roof["instances"] = [roof_of(k, v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]) if base_label(k) == fam]
             alone = aggregate(extras.get("kernel_stats_alone", [])).get(dom)
@@ -730,10 +761,10 @@ def main():
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UltraFace-" + str(args.variant) + ", one %dx%d synthetic JPEG stream per GPU (q90 4:2:0, %d distinct "
+            "config": {"workload": "UltraFace-" + str(args.variant) + ", one %dx%d synthetic JPEG stream per GPU (q90 %s%s, %d distinct "
                                    "frames, %s), batch=%d, seeded synthetic weights" % (
-                                       SW, SH, args.pool, "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows
-                                       else "no restart markers", B),
+                                       SW, SH, args.subsampling, ", no DHT segments (MJPG)" if args.no_dht else "", args.pool,
+                                       "DRI = %d MCU row(s)" % args.restart_rows if args.restart_rows else "no restart markers", B),
                        "global_batch": world * B, "parallelism": "streams x%d (one per GPU), RCCL weight broadcast only" % world,
                        "entropy_decode": "GPU kernels" if device_entropy else "host worker threads",
                        "timed_region": ("JPEG bytes resident in HBM (headers parsed at staging) -> detections in host memory"

@@ -34,8 +34,10 @@ def pytest_terminal_summary(terminalreporter):
         return
     terminalreporter.write_line("assert_dets_match: borderline excuse fired for %d detections in %d frames" %
                                 (EXCUSED["detections"], EXCUSED["frames"]))
-    from helpers import REFERENCE_PINS
+    from helpers import REFERENCE_PINS, SESSION_NOTES
 
+    for k, v in sorted(SESSION_NOTES.items()):
+        terminalreporter.write_line("note %s: %s" % (k, v))
     for k, v in sorted(REFERENCE_PINS.items()):
         # (the only results the reference's own tests pin need the zoo .onnx files, a run-time download: nn.rs:21-22,155-162)
         terminalreporter.write_line("reference pin %s: %s" % (k, v))

