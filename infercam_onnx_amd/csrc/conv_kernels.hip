@@ -1712,10 +1712,11 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem conv (3 -> 16, 3x3, stride 2) reading the decoder's 4:2:0 sample planes directly: the
-// fancy h2v2 chroma upsampling, the fixed-point YCbCr -> RGB conversion and the (v/255 - mean)/std
-// table of k_upsample_norm_420 run inside the kernel, so the normalised f32 input tensor (3.7 MB per
-// frame, written by one kernel and read by the next) never exists.
+// Stem conv (3 -> 16, 3x3, stride 2) reading the decoder's sample planes directly: the fancy chroma upsampling -- h2v2
+// for 4:2:0 frames, h2v1 for 4:2:2 ones (the UVC-MJPG flavour the reference's sender captures, sensors.rs:18-68), chosen
+// per FRAME from its descriptor --, the fixed-point YCbCr -> RGB conversion and the (v/255 - mean)/std table of
+// k_upsample_norm[_420] run inside the kernel, so the normalised f32 input tensor (3.7 MB per frame, written by one kernel
+// and read by the next) never exists.
 // Same lane layout and MFMA sequence as k_conv3x3_rows_mfma<2, 1> (quad q = input channel R/G/B,
 // lane = group of 4 output pixels = 8 input columns; the left halo column from the previous group),
 // same integer formulas as jpeg_kernels.hip, hence bit-identical to the two-kernel path.
@@ -1773,6 +1774,11 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   // (Lane 0's left and lane 63's right neighbour lie outside the wave: they only enter pixels of the two halo groups
   // that nobody reads -- group 0 provides its LAST column, group 15 nothing.)
   const bool has_prev = cc > 0, has_next = cc + 1 <= c_dw - 1;
+  // h2v1 (4:2:2: chroma at full height) through the h2v2 arithmetic: near row = far row = the pixel's own chroma row makes
+  // the column sums 4c, and jdsample.c's h2v1 outputs (3c + l + 1) >> 2 | (3c + r + 2) >> 2 are (3 * 4c + 4l + 4) >> 4 |
+  // (3 * 4c + 4r + 8) >> 4: only the two rounding terms differ from h2v2's 8 | 7.
+  const bool c_v2 = dcv.v[0] == 2;
+  const int bias_l = c_v2 ? 8 : 4, bias_r = c_v2 ? 7 : 8;
   float* xb = s_x + wave * 512;                        // [4][16][8]
   const float* xr = xb + q * 128 + j16 * 8;            // what this MFMA lane reads back
   const int xl = max(q * 128 + j16 * 8 - 1, 0);        // the column left of them (group j16 - 1's last)
@@ -1791,7 +1797,8 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     const int iy = 2 * c_oy0 + k;
     const bool ok = c_frame_ok && iy >= 0 && iy < a.ih;
     const int yc = min(max(iy, 0), a.ih - 1);
-    const int cy = yc >> 1, ny = max(0, min(c_dh - 1, (yc & 1) ? cy + 1 : cy - 1));  // h2v2 fancy upsampling: near / far row
+    const int cy = c_v2 ? yc >> 1 : yc;  // h2v2 fancy upsampling: near / far row; h2v1: both the pixel's own
+    const int ny = c_v2 ? max(0, min(c_dh - 1, (yc & 1) ? cy + 1 : cy - 1)) : cy;
     uint32_t yy = 0, cbn = 0, cbf = 0, crn = 0, crf = 0;
     if (c_frame_ok) {
       const uint32_t ro = (uint32_t)__mul24(cy, c_cpitch), fo = (uint32_t)__mul24(ny, c_cpitch);
@@ -1801,8 +1808,8 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     const int scb = mad24(3, (int)cbn, (int)cbf), scr = mad24(3, (int)crn, (int)crf);  // column sums 3 * near + far
     const int pcb = dpp_prev(scb), ncb = dpp_next(scb), pcr = dpp_prev(scr), ncr = dpp_next(scr);
     const int lcb = has_prev ? pcb : scb, rcb = has_next ? ncb : scb, lcr = has_prev ? pcr : scr, rcr = has_next ? ncr : scr;
-    const int cb0 = (mad24(scb, 3, lcb) + 8) >> 4, cb1 = (mad24(scb, 3, rcb) + 7) >> 4;
-    const int cr0 = (mad24(scr, 3, lcr) + 8) >> 4, cr1 = (mad24(scr, 3, rcr) + 7) >> 4;
+    const int cb0 = (mad24(scb, 3, lcb) + bias_l) >> 4, cb1 = (mad24(scb, 3, rcb) + bias_r) >> 4;
+    const int cr0 = (mad24(scr, 3, lcr) + bias_l) >> 4, cr1 = (mad24(scr, 3, rcr) + bias_r) >> 4;
     const int y0 = (int)(yy & 255u), y1 = (int)(yy >> 8);
     auto clamp255 = [](int x) { return min(255, max(0, x)); };
     const int r0 = clamp255(y0 + (mad24(kRv, cr0, kRc) >> 16)), r1 = clamp255(y1 + (mad24(kRv, cr1, kRc) >> 16));

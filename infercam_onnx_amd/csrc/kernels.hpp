@@ -192,7 +192,7 @@ size_t rfb_tail_packed_floats();
 void pack_rfb_tail_weights(const float* w_lin /*[64][48]*/, const float* w_short /*[64][64]*/, float* packed);
 bool rfb_tail_supported(const ConvArgs* dil3, const ConvArgs& fin);
 void launch_rfb_tail(const ConvArgs* dil3, const ConvArgs& fin, hipStream_t s);
-// Stem conv straight from the decoder's 4:2:0 sample planes (every frame of the batch at the model
+// Stem conv straight from the decoder's 4:2:0 / 4:2:2 sample planes (every frame of the batch at the model
 // size): a = the stem's ConvArgs with the row packing of its weights (pack_conv3x3_rows_weights);
 // frames whose descriptor does not match (failed frames) read as zero input.
 struct StemArgs {

@@ -951,6 +951,18 @@ int submit_staged(ufd_model* m, Slot& s, const ufd_staged& g) {
 }
 
 // Every decodable frame of the batch is 3-component YCbCr 4:2:0 (what the fancy-upsampling fast paths take).
+// ... or 4:2:2 (h2v1, chroma at full height): what the fused stem takes besides 4:2:0, frame by frame
+bool batch_is_h2(const Slot& s, uint32_t count) {
+  for (uint32_t i = 0; i < count; i++) {
+    if (s.st[i] != UFD_OK) continue;
+    const JpegFrameDesc& d = s.h_descs[i];
+    if (!(d.ncomp == 3 && d.color == kColorYCbCr && d.h[0] == 2 && (d.v[0] == 2 || d.v[0] == 1) && d.h[1] == 1 && d.v[1] == 1 &&
+          d.h[2] == 1 && d.v[2] == 1 && d.dw[1] > 2))
+      return false;
+  }
+  return true;
+}
+
 bool batch_is_420(const Slot& s, uint32_t count) {
   for (uint32_t i = 0; i < count; i++) {
     if (s.st[i] != UFD_OK) continue;
@@ -1003,9 +1015,9 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
       // failed frames keep stale input; their results are never reported
       // camera streams are 4:2:0 YCbCr: specialised kernel when every decoded frame qualifies
       const bool all_420 = (m->W % 8) == 0 && batch_is_420(s, count);
-      // 4:2:0 frames at the model size: the stem conv reads the sample planes itself (no f32 input
+      // 4:2:0 and 4:2:2 frames at the model size: the stem conv reads the sample planes itself (no f32 input
       // tensor); UFD_NO_STEM_FUSE=1 at ufd_create keeps the two-kernel path
-      if (all_420 && m->stem_fusable) {
+      if ((m->W % 8) == 0 && m->stem_fusable && (all_420 || batch_is_h2(s, count))) {
         tl_cur->stem_descs = d_descs;
         fused_stem = true;
       } else {

@@ -184,7 +184,7 @@ struct Ctx {
   // device entropy decoding: JPEG bytes, scan layouts and restart intervals of the batch
   uint8_t* d_stage_buf[2] = {nullptr, nullptr};  // device image of Slot::h_stage (d_descs_buf points at its head)
   uint8_t* d_sync = nullptr;  // scratch of the self-synchronising entropy decoder
-  const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 sample planes (fused stem)
+  const JpegFrameDesc* stem_descs = nullptr;  // non-null: the next forward reads the 4:2:0 / 4:2:2 sample planes (fused stem)
   SyncBuffers sync;
   uint32_t* d_status = nullptr;
   int flip = 0;

@@ -114,6 +114,27 @@ def test_c3_batch32_bench_handle_det_cap_256(pool_c3, refs_c3, weights):
         m.close()
 
 
+def test_c3_422_mjpg_stream_batch32_matches_oracle(oracle_lib, weights):
+    """The second synthetic input SURVEY 8(d) names, as `bench.py --subsampling 4:2:2 --no-dht --restart-rows 1` runs it:
+    UltraFace-640, a 640x480 4:2:2 stream WITHOUT DHT segments and with one restart interval per MCU row (what a UVC camera's
+    MJPG looks like: cam_sender/src/sensors.rs:18-68), batch 32, six batches in flight, staged + host-bytes submission; the
+    fused stem (round 5: h2v1 per frame) is the path taken; detections of every frame against the oracle."""
+    from infercam_onnx_amd import synth
+
+    pool = [synth.strip_dht(j) for j in synth.synth_jpeg_pool(0, 128, 640, 480, quality=90, subsampling="4:2:2", restart_rows=1)]
+    pri = synth.gen_priors(640, 480)
+    refs = oracle_many(lambda j: oracle_lib.infer_jpeg(j, 640, 480, weights, pri, 0.5, 0.5), pool)
+    m = _model(640, weights, max_batch=32, max_src=(640, 480), det_cap=512, profile=True)
+    try:
+        excused = _check_pool(m, pool, 32, refs)
+        names = {p["name"] for p in m.profile_read() if p["launches"]}
+        assert any(n.startswith("stem_planes_mfma:") for n in names) and not any(n.startswith("upsample_norm") for n in names), names
+        assert "huff_write" in names  # the device entropy decoder took the table-less streams
+    finally:
+        m.close()
+    print("C3 4:2:2 MJPG: excused borderline detections: %d" % excused)
+
+
 def test_host_stats_account_for_every_batch(pool_c3, weights):
     """ufd_host_stats (bench.py's `host` object): 24 batches through the bench's submit / wait loop are all counted, each
     with its launches, a device-time span on its context and (between consecutive batches of a context) a gap; a reset

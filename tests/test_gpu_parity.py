@@ -749,6 +749,42 @@ def test_stem_from_planes_is_bit_identical_to_the_two_kernel_path(weights, oracl
         fused_model.close()
 
 
+def test_stem_from_422_planes_is_bit_identical_to_the_two_kernel_path(weights, oracle_lib):
+    """The twin for 4:2:2 (h2v1: chroma at full height, horizontal fancy upsampling only -- the UVC-MJPG flavour the
+    reference's sender captures, cam_sender/src/sensors.rs:18-68), round 5: the fused stem picks the upsampling per FRAME
+    from its descriptor, so a batch may mix 4:2:2 and 4:2:0 frames; without DHT segments, with restart markers, and with a
+    failed frame in the batch.  Detections bit-identical to k_upsample_norm + the row kernel, and equal to the oracle's."""
+    from infercam_onnx_amd import synth
+
+    def enc(i, **kw):
+        return synth.encode_jpeg(synth.synth_frame(93, i, 640, 480), **kw)
+
+    jpegs = [enc(0, subsampling="4:2:2"), enc(1, subsampling="4:2:2", restart_rows=1), synth.strip_dht(enc(2, subsampling="4:2:2")),
+             enc(3, subsampling="4:2:0"), enc(4, subsampling="4:2:2", quality=35), enc(5, subsampling="4:2:2", quality=98)]
+    jpegs.insert(2, jpegs[0][: len(jpegs[0]) // 2])  # a frame that fails to decode
+    ref_model = make_model(640, weights, max_batch=7, profile=True, no_stem_fuse=True)
+    ref, st_ref = ref_model.infer_jpeg_batch(jpegs)
+    fused_model = make_model(640, weights, max_batch=7, profile=True)
+    try:
+        got, st = fused_model.infer_jpeg_batch(jpegs)
+        assert st == st_ref and st[2] != 0 and got == ref
+        names_ref = {p["name"] for p in ref_model.profile_read() if p["launches"]}
+        names = {p["name"] for p in fused_model.profile_read() if p["launches"]}
+        assert any(n.startswith("stem_planes_mfma:") for n in names) and not any(n.startswith("upsample_norm") for n in names), names
+        assert "upsample_norm" in names_ref and not any(n.startswith("stem_planes_mfma:") for n in names_ref)
+        pri = synth.gen_priors(640, 480)
+        for i, j in enumerate(jpegs):
+            if st[i] == 0:
+                assert_dets_match(dets_array(got[i]), oracle_lib.infer_jpeg(j, 640, 480, weights, pri, 0.5, 0.5), what="frame %d" % i)
+        # all frames 4:2:2 (a camera stream has one flavour): same path
+        only422 = [j for i, j in enumerate(jpegs) if i not in (2, 4)]
+        got2, st2 = fused_model.infer_jpeg_batch(only422)
+        assert st2 == [0] * 5 and got2 == [g for i, g in enumerate(got) if i not in (2, 4)]
+    finally:
+        ref_model.close()
+        fused_model.close()
+
+
 @pytest.mark.parametrize("variant,batch", [(640, 4), (320, 17), (640, 32)])
 def test_rfb_tail_launch_matches_the_two_launch_form(weights, oracle_lib, variant, batch):
     """k_rfb_tail (round 4): the three dilated 3x3 convs of the RFB branches hand their results to
