@@ -683,6 +683,12 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
     };
     launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_nsub, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
                         c.sync, c.d_status, c.stream, &hook, p.used_coef);
+    // Timing experiments only (UFD_REPEAT_ENTROPY=n: the decoder chain n more times, same results): what the stage costs the
+    // LOADED pipeline is the frame rate it takes away when it runs twice (docs/EXPERIMENTS.md, round 5).
+    static const int repeat = std::getenv("UFD_REPEAT_ENTROPY") ? std::atoi(std::getenv("UFD_REPEAT_ENTROPY")) : 0;
+    for (int r = 0; r < repeat; r++)
+      launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_nsub, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
+                          c.sync, c.d_status, c.stream, nullptr, p.used_coef);
   }
   return UFD_OK;
 }

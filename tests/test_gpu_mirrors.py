@@ -21,10 +21,17 @@ def test_cpp_integration_test(tmp_path, weights):
                            "-o", exe, "-L" + lib_dir, "-lufacehip", "-Wl,-rpath," + lib_dir])
     wfile = str(tmp_path / "w.f32")
     np.asarray(weights, np.float32).tofile(wfile)
-    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test_pics"), wfile], capture_output=True, text=True,
-                         timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.strip().endswith("ok") and out.stdout.count("faces=") == 8
+    # (output to a file, unbuffered: if the process ever hangs, the assertion shows how far it got)
+    log = str(tmp_path / "out.txt")
+    with open(log, "w") as f:
+        try:
+            rc = subprocess.run(["stdbuf", "-o0", exe, os.path.join(ROOT, "tests", "golden", "test_pics"), wfile], stdout=f,
+                                stderr=subprocess.STDOUT, timeout=300).returncode
+        except subprocess.TimeoutExpired:
+            rc = "timeout"
+    text = open(log).read()
+    assert rc == 0, "rc %s\n%s" % (rc, text)
+    assert text.strip().endswith("ok") and text.count("faces=") == 8
 
 
 def _real_model_path(variant):

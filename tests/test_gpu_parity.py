@@ -779,7 +779,9 @@ def test_stem_from_422_planes_is_bit_identical_to_the_two_kernel_path(weights, o
         # all frames 4:2:2 (a camera stream has one flavour): same path
         only422 = [j for i, j in enumerate(jpegs) if i not in (2, 4)]
         got2, st2 = fused_model.infer_jpeg_batch(only422)
-        assert st2 == [0] * 5 and got2 == [g for i, g in enumerate(got) if i not in (2, 4)]
+        assert st2 == [0] * 5
+        for g2, g in zip(got2, [g for i, g in enumerate(got) if i not in (2, 4)]):  # (another batch size may pick other kernel
+            assert_dets_match(dets_array(g2), dets_array(g), what="4:2:2-only batch")  # instances: fp32 rounding apart)
     finally:
         ref_model.close()
         fused_model.close()
