@@ -693,6 +693,13 @@ def main():
         except Exception:
             pass
 
+        ea, ea_ok = {}, False
+        try:  # rocprofv3 --pmc TCC_EA0_RDREQ* passes summarised by tools/pmc_ea.sh, stamped like the traffic
+            ea = json.load(open(os.path.join(ROOT, "profiles", "ea_reads_latest.json")))
+            ea_ok = ea.get("kernel_source_sha") == kernel_source_sha() and ea.get("workload", c3_workload) == my_workload
+        except Exception:
+            pass
+
         def roof_of(key, d):
             """Roofline figures of one kernel instance from its aggregated launches."""
             sec = d["ms"] * 1e-3
@@ -721,6 +728,12 @@ def main():
             e = sq.get("instances", {}).get(device_name(key)) if sq_ok else None
             for f in ("mfma_busy", "valu_busy", "waves_per_simd", "wait_share"):
                 r[f] = e.get(f) if e else None
+            # of `traffic`'s reads, the bytes whose requests were ADDRESSED to local memory (TCC_EA0_RDREQ_DRAM x 128 B).  The
+            # Infinity Cache sits behind that address decode and rocprofv3 has no counter for hits in it on this box, so this is
+            # an upper bound of the HBM reads, not a measurement of them; beside it the average fabric read latency in L2 clocks
+            e = ea.get("instances", {}).get(device_name(key)) if ea_ok else None
+            r["dram_bytes"] = e.get("dram_bytes") if e else None
+            r["ea_read_latency_clk"] = e.get("ea_read_latency_clk") if e else None
             return r
 
         roof = None

@@ -77,4 +77,16 @@ if os.path.exists(sq_json) and os.path.exists(os.path.join(sq_dir, "source_sha.t
         print("profiles/%s/sq_counters.{txt,json} filed (%s)" % (name, sq_sha))
     else:
         print("gpurun_out/pmc_kernel was measured on other kernel sources (%s): SQ table NOT filed" % sq_sha)
+# fabric read requests per kernel (tools/pmc_ea.sh collected into gpurun_out/pmc_ea/): same stamp rule
+ea_dir = os.path.join(ROOT, "gpurun_out", "pmc_ea")
+if os.path.exists(os.path.join(ea_dir, "ea_reads.json")) and os.path.exists(os.path.join(ea_dir, "source_sha.txt")):
+    ea_sha = open(os.path.join(ea_dir, "source_sha.txt")).read().split()[0]
+    if ea_sha == current or "--keep-stale" in sys.argv:
+        q = json.load(open(os.path.join(ea_dir, "ea_reads.json")))
+        q["kernel_source_sha"], q["commit"], q["profile"], q["workload"] = ea_sha, d["commit"], name, workload
+        json.dump(q, open(os.path.join(dst, "ea_reads.json"), "w"), indent=1, sort_keys=True)
+        json.dump(q, open(os.path.join(ROOT, "profiles", "ea_reads_latest.json"), "w"), indent=1, sort_keys=True)
+        print("profiles/%s/ea_reads.json filed (%s)" % (name, ea_sha))
+    else:
+        print("gpurun_out/pmc_ea was measured on other kernel sources (%s): NOT filed" % ea_sha)
 print("profiles/%s ready; pmc_traffic_latest.json stamped %s @ %s" % (name, d["kernel_source_sha"], d["commit"]))
