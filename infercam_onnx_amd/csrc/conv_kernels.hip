@@ -1379,11 +1379,20 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   // or are masked by the column tests) instead of each of the 12 operands made from it, and the column tests are compiled
   // in only where they can fail: left of pixel j < DIL, right of pixel j > 3 - DIL.  54 selects per chunk became 18.
   auto zero_if = [](bool keep, const float4& m) { return keep ? m : make_float4(0.f, 0.f, 0.f, 0.f); };
+  // Rows (and, when they come from memory, the nine weights) of chunk kc + 1 are requested before chunk kc's MFMAs, into the
+  // other half of a register ping-pong -- the loop runs two chunks per iteration so that no copy is needed, and the
+  // sched_barrier keeps the requests where they are written (round 5: with `cur = nxt` copies at the loop's end hipcc sank the
+  // loads down to the copies and waited for them there, one exposed memory round trip per 36 MFMAs).
   auto run = [&](auto in_lds) {
-    Rows cur, nxt;
-    load_rows(0, cur);
-    for (int kc = 0; kc < cin4; kc++) {
-      load_rows(min(kc + 1, cin4 - 1), nxt);
+    constexpr bool kLds = decltype(in_lds)::value;
+    Rows rows[2];
+    float wts[2][9];
+    auto load_wts = [&](int kc, float (&w)[9]) {
+      if (kLds) return;
+#pragma unroll
+      for (int t = 0; t < 9; t++) w[t] = wg[(kc * 9 + t) * 64];
+    };
+    auto chunk = [&](int kc, const Rows& cur, const float (&wcur)[9]) {
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         const bool ok = rowok[r];
@@ -1408,13 +1417,22 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
         }
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
-          const int widx = (kc * 9 + r * 3 + kx) * 64;
-          const float w = decltype(in_lds)::value ? s_w[widx + lane] : wg[widx];
+          const float w = kLds ? s_w[(kc * 9 + r * 3 + kx) * 64 + lane] : wcur[r * 3 + kx];
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
         }
       }
-      cur = nxt;
+    };
+    load_rows(0, rows[0]);
+    load_wts(0, wts[0]);
+    for (int kc = 0; kc < cin4; kc += 2) {
+      if (kc + 1 < cin4) load_rows(kc + 1, rows[1]), load_wts(kc + 1, wts[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(kc, rows[0], wts[0]);
+      if (kc + 1 >= cin4) break;
+      if (kc + 2 < cin4) load_rows(kc + 2, rows[0]), load_wts(kc + 2, wts[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(kc + 1, rows[1], wts[1]);
     }
   };
   if (w_in_lds) run(std::true_type{});
@@ -1520,10 +1538,26 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) m[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c));
   };
-  float4 cur[3], nxt[3];
-  load_rows(0, cur);
-  for (int kc = 0; kc < cin4; kc++) {
-    load_rows(min(kc + 1, cin4 - 1), nxt);
+  // Rows AND weights of chunk kc + 1 are requested before chunk kc's MFMAs and held in the other half of a register ping-pong
+  // (the loop is fully unrolled: cin = 16, rfb_tail_supported); the sched_barrier keeps the requests where they are written.
+  // Round 5: with `cur = nxt` copies at the loop's end hipcc sank the next rows' loads down to the copies and waited for them
+  // there, and the nine weights of a chunk were requested at the top of the chunk that multiplies them -- two exposed memory
+  // round trips per 36 MFMAs, SQ_WAIT_INST_ANY 73 % of the kernel's wave-cycles.
+  auto load_wts = [&](int kc, float (&w)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) w[t] = wsrc[(kc * 9 + t) * 64 + lane];
+  };
+  constexpr int kChunks = 4;
+  float4 rows[2][3];
+  float wts[2][9];
+  load_rows(0, rows[0]);
+  load_wts(0, wts[0]);
+  (void)cin4;
+#pragma unroll
+  for (int kc = 0; kc < kChunks; kc++) {
+    const float4 (&cur)[3] = rows[kc & 1];
+    if (kc + 1 < kChunks) load_rows(kc + 1, rows[(kc + 1) & 1]), load_wts(kc + 1, wts[(kc + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const float4 m = rowok[r] ? cur[r] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1537,16 +1571,16 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
       }
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
-        const float w = wsrc[(kc * 9 + r * 3 + kx) * 64 + lane];
+        const float w = wts[kc & 1][r * 3 + kx];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x[kx][j], acc[j], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int r = 0; r < 3; r++) cur[r] = nxt[r];
   }
 }
 
+// (capped at 168 registers for three waves per SIMD, round 5: 150 registers, no spill, 69.9 -> 68.9 us alone, frame rate
+// unchanged -- left to the compiler)
 __global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
   const ConvArgs& fin = t.fin;
   extern __shared__ float s_tail[];
@@ -1728,7 +1762,7 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   extern __shared__ float s_sh[];
   float* s_w = s_sh;                 // packed weights [1][9][64]
   float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table, then 256 zeros (the "table" of a padding row)
-  float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][16 groups][8 columns] of one input row
+  float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][2 column halves][16 groups][4 columns] of one input row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
@@ -1779,9 +1813,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   // (3 * 4c + 4r + 8) >> 4: only the two rounding terms differ from h2v2's 8 | 7.
   const bool c_v2 = dcv.v[0] == 2;
   const int bias_l = c_v2 ? 8 : 4, bias_r = c_v2 ? 7 : 8;
-  float* xb = s_x + wave * 512;                        // [4][16][8]
-  const float* xr = xb + q * 128 + j16 * 8;            // what this MFMA lane reads back
-  const int xl = max(q * 128 + j16 * 8 - 1, 0);        // the column left of them (group j16 - 1's last)
+  // Layout [channel][columns 0-3 | 4-7][group][4] (round 5): an MFMA lane's two 16-byte reads are then 16 bytes apart from its
+  // neighbours' -- with [channel][group][8] they were 32 apart, groups j, j + 4, j + 8, j + 12 on the same banks, and
+  // SQ_LDS_BANK_CONFLICT of this kernel stood at 106 % of its LDS-active cycles.
+  float* xb = s_x + wave * 512;                        // [4][2][16][4]
+  const float* xr = xb + q * 128 + j16 * 4;            // what this MFMA lane reads back: columns 0-3 here, 4-7 64 floats on
+  const int xl = max(q * 128 + 64 + j16 * 4 - 1, 0);   // the column left of them (group j16 - 1's last: its column 7)
   const bool left_ok = j16 > 0 && ix0 > 0;             // else: zero padding at the row start (or a halo lane)
   *reinterpret_cast<float2*>(xb + 384 + 2 * lane) = make_float2(0.f, 0.f);  // channel 3: zeros, written once
   auto dpp_prev = [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); };
@@ -1818,12 +1855,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     // (a padding row reads the table's row of zeros: two selects per row instead of a branch around the six reads)
     const float* l0 = s_lut + (ok ? 0 : 768);
     const int lstep = ok ? 256 : 0;
-    float* xw = xb + cg * 8 + 2 * cp;
+    float* xw = xb + (cp >> 1) * 64 + cg * 4 + 2 * (cp & 1);
     *reinterpret_cast<float2*>(xw) = make_float2(l0[r0], l0[r1]);
     *reinterpret_cast<float2*>(xw + 128) = make_float2(l0[lstep + g0], l0[lstep + g1]);
     *reinterpret_cast<float2*>(xw + 256) = make_float2(l0[2 * lstep + b0], l0[2 * lstep + b1]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's stores before the wave's loads (in-order LDS)
-    const float4 va = *reinterpret_cast<const float4*>(xr), vb = *reinterpret_cast<const float4*>(xr + 4);
+    const float4 va = *reinterpret_cast<const float4*>(xr), vb = *reinterpret_cast<const float4*>(xr + 64);
     const float left = xb[xl];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and these loads before the next row's stores
     v[0] = va.x, v[1] = va.y, v[2] = va.z, v[3] = va.w, v[4] = vb.x, v[5] = vb.y, v[6] = vb.z, v[7] = vb.w;
@@ -2218,6 +2255,7 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     return;
   }
   if (stride == 1) {
+    // (four k-steps of windows in flight instead of two, round 5: 31.1 -> 30.6 us alone, frame rate unchanged -- not kept)
     if (c.deep) launch(k_dwpw_mfma<1, 1, 2, 1>);
     else launch(k_dwpw_mfma<1, 1, 1, 1>);
   } else {

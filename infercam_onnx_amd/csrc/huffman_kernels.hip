@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 
 namespace ufd {
 namespace {
@@ -1006,11 +1007,16 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
   const dim3 gext((nsub * kHypSlots + kSyncLaneThreads - 1) / kSyncLaneThreads, frames);  // k_huff_link: 16 subsequences per block
   const dim3 gext2((nsub * kHypSlots + kExtendThreads - 1) / kExtendThreads, frames);     // k_huff_extend: 64
   const dim3 ext_threads(kExtendThreads);
-  stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_a, cnt_b); });
-  stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_b, cnt_a); });
-  stage("huff_link", [&] { hipLaunchKernelGGL(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_a); });
+  // speculation rounds (UFD_EXTEND_ROUNDS while measuring; 2 is what ships: docs/EXPERIMENTS.md rounds 4 and 5)
+  static const int rounds = std::getenv("UFD_EXTEND_ROUNDS") ? std::max(0, std::min(4, std::atoi(std::getenv("UFD_EXTEND_ROUNDS")))) : 2;
+  uint8_t *cnt_in = cnt_a, *cnt_out = cnt_b;
+  for (int r = 0; r < rounds; r++) {
+    stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_in, cnt_out); });
+    std::swap(cnt_in, cnt_out);
+  }
+  stage("huff_link", [&] { hipLaunchKernelGGL(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_in); });
   stage("huff_resolve", [&] {
-    hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_a, d_status);
+    hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_in, d_status);
   });
   stage("huff_write", [&] {
     hipLaunchKernelGGL(k_huff_write, dim3((nsub * kWriteParts + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
