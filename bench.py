@@ -129,6 +129,9 @@ def parse_args():
                     help="config C4 in ONE process (the reference server is one process, infer_server.rs:39-68): "
                          "ufd_create_replicas over --gpus devices (RCCL broadcast of the weights) and ONE ufd_sched over the "
                          "replicas, one producer thread per camera stream; no torch.distributed launcher")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="--one-process: camera streams per GPU (the reference server serves many cameras from one Inferer, "
+                         "infer_server.rs:48-50; 8 = VERDICT r4 #6b)")
     ap.add_argument("--no-rfb-tail", action="store_true", help="UFD_FLAG_NO_RFB_TAIL: A/B of k_rfb_tail against the two-launch form")
     ap.add_argument("--spin-wait", action="store_true", help="UFD_FLAG_SPIN_WAIT: ufd_wait always spins in the runtime (A/B of the sleeping wait)")
     ap.add_argument("--host-only", action="store_true",
@@ -137,7 +140,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
+def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480, annotate=False):
     """The CPU oracle (oracle/, a plain-C port of the reference path; the reference's own tract-onnx
     path cannot be built here) timed on this host on a bounded sample of the bench's frames:
     (a) one thread -- the reference's operating point is a single Inferer task (infer_server.rs:48-50);
@@ -146,6 +149,23 @@ def cpu_baseline(jpegs, weights, priors, budget_s, W=640, H=480):
 
     oracle.build()
     oracle.infer_jpeg(jpegs[0], W, H, weights, priors)  # warm
+
+    def one_frame(j):  # the whole Inferer::run iteration when annotate (inferer.rs:35-40), else decode -> NMS
+        d = oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5)
+        if annotate:
+            oracle.jpeg_encode_rgb(oracle.draw_labels(oracle.jpeg_decode_rgb(j), d, 1280, 720), 95)
+
+    if annotate:  # (one thread only: the reference's operating point; the all-cores leg times decode -> NMS)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one_frame(jpegs[n % len(jpegs)])
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 4 * len(jpegs):
+                break
+        return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d of the bench's JPEG frames, decode -> infer at %dx%d -> rectangles + labels -> JPEG q95 re-encode "
+                          "(the whole Inferer::run iteration), 1 thread, %.1f s" % (n, W, H, el)}
     n, t0 = 0, time.perf_counter()
     while True:
         oracle.infer_jpeg(jpegs[n % len(jpegs)], W, H, weights, priors, 0.5, 0.5)
@@ -283,14 +303,20 @@ def main_one_process(args):
         if torch.cuda.device_count() < N:
             raise SystemExit("bench.py --one-process --gpus %d: only %d devices visible" % (N, torch.cuda.device_count()))
         models = nn.UltrafaceModel.create_replicas(variant, 0.5, 0.5, list(range(N)), **kw)
-    pools = [synth.synth_jpeg_pool(r, args.pool, SW, SH, quality=90, subsampling=args.subsampling, restart_rows=args.restart_rows) for r in range(N)]
+    S = max(1, args.streams)  # camera streams per GPU; stream r lives on replica r mod N (round-robin placement)
+    NS = N * S
+    pools = [synth.synth_jpeg_pool(r, args.pool, SW, SH, quality=90, subsampling=args.subsampling, restart_rows=args.restart_rows) for r in range(NS)]
     if args.no_dht:
         pools = [[synth.strip_dht(j) for j in pool] for pool in pools]
     nb = max(1, args.pool // B)
-    batches = [[models[0]._prep_batch(pools[r][i * B:(i + 1) * B]) for i in range(nb)] for r in range(N)]
+    batches = [[models[0]._prep_batch(pools[r][i * B:(i + 1) * B]) for i in range(nb)] for r in range(NS)]
+    enc_bytes = models[0]._lib.ufd_encode_bound(SW, SH) if args.annotate else 0
     sch = scheduler.Scheduler(models_640=models if args.variant == 640 else None, models_320=models if args.variant == 320 else None,
-                              on_result=False, ring_slots=8 * B, max_wait_us=2000, max_inflight=args.depth, det_cap=256)
-    hs = [sch.add_stream(1000 + r, args.variant) for r in range(N)]
+                              on_result=False, ring_slots=max(10, 8 * B // S), max_wait_us=2000, max_inflight=args.depth, det_cap=256,
+                              jpeg_bytes_per_frame=enc_bytes)
+    # --annotate: every stream wants the annotated JPEG back (the /face_stream viewers of endpoints.rs:58-72): rectangles and
+    # labels at the router's 1280 x 720, q95 re-encode (inferer.rs:38-40)
+    hs = [sch.add_stream(1000 + r, args.variant, annotate=args.annotate) for r in range(NS)]
     where = [sch.stream_replica(h) for h in hs]
 
     def produce(r, steps):
@@ -302,7 +328,7 @@ def main_one_process(args):
                     time.sleep(0.0002)  # ring full: the router would drop (router.rs:65); the bench wants every frame run
 
     def run(steps):
-        th = [threading.Thread(target=produce, args=(r, steps)) for r in range(N)]
+        th = [threading.Thread(target=produce, args=(r, steps)) for r in range(NS)]
         for t in th:
             t.start()
         for t in th:
@@ -325,18 +351,20 @@ def main_one_process(args):
     after = sch.replica_stats(args.variant)
     frames = sum(a["frames"] - b_["frames"] for a, b_ in zip(after, before))
     dets = sum(a["detections"] - b_["detections"] for a, b_ in zip(after, before))
-    assert frames == N * B * K, (frames, N * B * K)
+    assert frames == NS * B * K, (frames, NS * B * K)
     hstats = [m.host_stats() for m in models]
     flops_frame = 798315520 if args.variant == 640 else 200837120
     out = {
-        "metric": "frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, Wd, Hd),
+        "metric": ("frames/sec end-to-end (decode->NMS), UltraFace-%d @ %dx%d" % (args.variant, Wd, Hd)) if not args.annotate else
+                  ("frames/sec decode->NMS->rectangles->JPEG q95 re-encode (N1 side workload), UltraFace-%d @ %dx%d" % (args.variant, Wd, Hd)),
         "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": Wm,
         "ms_per_step": round(el / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "UltraFace-%d, one %dx%d synthetic JPEG stream per GPU (q90 %s%s, %d distinct frames), batch=%d, seeded "
-                               "synthetic weights" % (args.variant, SW, SH, args.subsampling, ", no DHT segments (MJPG)" if args.no_dht else "",
-                                                      args.pool, B),
-                   "global_batch": N * B,
+        "config": {"workload": "UltraFace-%d, %d %dx%d synthetic JPEG stream(s) per GPU (q90 %s%s, %d distinct frames each), batches of up to %d "
+                               "formed by the scheduler across the streams, seeded synthetic weights%s" % (
+                                   args.variant, S, SW, SH, args.subsampling, ", no DHT segments (MJPG)" if args.no_dht else "", args.pool, B,
+                                   "; every stream gets its frames back annotated (rectangles + labels at 1280x720, JPEG q95)" if args.annotate else ""),
+                   "global_batch": N * B, "streams": NS,
                    "parallelism": "ONE process: ufd_create_replicas x%d (RCCL weight broadcast) + one ufd_sched over the replicas, "
                                   "stream i -> GPU i mod %d" % (N, N),
                    "timed_region": "host JPEG bytes pushed by one producer thread per stream -> detections delivered (ufd_sched_flush)",
@@ -528,8 +556,6 @@ def main():
         return out
 
     extras = {}
-    if args.annotate:
-        args.no_extras = True
     host_only = args.host_only
     if not args.no_extras:
         # ---- steady state: the same workload, >= 200 more steps behind the timed region (a 20-step sample holds one
@@ -565,7 +591,7 @@ def main():
         model.profile_sampling(1 << 30)
     if world == 1 and not args.no_extras and not host_only:
         # ---- the same workload over the other boundary
-        if device_entropy:
+        if device_entropy and not args.annotate:
             other = not primary_staged
             run_steps(args.warmup, other)
             torch.cuda.synchronize()
@@ -589,7 +615,7 @@ def main():
         model.profile_sampling(1 << 30)
         # ---- N1: the whole Inferer::run iteration, inferer.rs:35-46 -- decode -> infer -> rectangles -> JPEG q95
         # re-encode on the GPU, annotated streams back in (pinned) host memory; label size = the router's 1280 x 720
-        nab = min(nb, args.depth)
+        nab = 0 if args.annotate else min(nb, args.depth)  # (--annotate: that IS the timed workload)
         abs_ = [model.prep_annotate_batch(jpegs[i * B:(i + 1) * B], (1280, 720), out_bytes_per_frame=SW * SH) for i in range(nab)]
 
         def run_annotate(k):
@@ -604,25 +630,32 @@ def main():
                 out_bytes += sum(lens_)
             return out_bytes
 
-        run_annotate(max(args.warmup, nab))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ob = run_annotate(args.steps)
-        torch.cuda.synchronize()
-        el_a = time.perf_counter() - t1
-        extras["annotate"] = {"fps": round(B * args.steps / el_a, 1), "bytes_out_per_frame": round(ob / (B * args.steps)),
-                              "what": "ufd_submit_annotate_batch: host JPEG bytes -> detections + annotated q95 4:2:0 JPEG in host memory"}
+        if nab:
+            run_annotate(max(args.warmup, nab))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ob = run_annotate(args.steps)
+            torch.cuda.synchronize()
+            el_a = time.perf_counter() - t1
+            extras["annotate"] = {"fps": round(B * args.steps / el_a, 1), "bytes_out_per_frame": round(ob / (B * args.steps)),
+                                  "what": "ufd_submit_annotate_batch: host JPEG bytes -> detections + annotated q95 4:2:0 JPEG in host memory"}
         del abs_
         # ---- per-frame latency at batch 1, one frame in flight, host bytes -> host detections
         lat = []
+        lat_batches = [model.prep_annotate_batch([jpegs[i % len(jpegs)]], (1280, 720)) for i in range(8)] if args.annotate else None
         for i in range(60):
             j = jpegs[i % len(jpegs)]
             t1 = time.perf_counter()
-            model.infer_jpeg(j)
+            if args.annotate:  # (buffers prepared once, as a server's ring slots are: the clock sees submit + wait)
+                model.wait(model.submit_annotate_batch(lat_batches[i % 8]), collect=False)
+            else:
+                model.infer_jpeg(j)
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = sorted(lat[10:])
         extras["latency_ms_batch1"] = {"median": round(lat[len(lat) // 2], 3), "p90": round(lat[int(len(lat) * 0.9)], 3),
-                                       "what": "ufd_infer_jpeg, one %dx%d frame at a time, host bytes -> host detections" % (SW, SH)}
+                                       "what": ("ufd_annotate_jpeg_batch of one frame (host bytes -> detections + annotated JPEG in host memory)"
+                                                if args.annotate else "ufd_infer_jpeg, host bytes -> host detections") +
+                                               ", one %dx%d frame at a time" % (SW, SH)}
 
     verified = None
     if rank == 0 and not args.no_extras and not host_only:
@@ -632,6 +665,15 @@ def main():
         import oracle
 
         oracle.build()
+        annot_checked = None
+        if args.annotate:  # the annotated streams of a few frames, byte for byte against the oracle's (libjpeg-turbo-pinned) encoder
+            annot_checked = 0
+            for j in jpegs[:min(4, len(jpegs))]:
+                adets, stream = model.annotate_jpeg(j, (1280, 720))
+                frame = oracle.draw_labels(oracle.jpeg_decode_rgb(j), np.array([list(b_) + [c_] for b_, c_ in adets], np.float32).reshape(-1, 5), 1280, 720)
+                if stream != oracle.jpeg_encode_rgb(frame, 95):
+                    raise SystemExit("bench.py: annotated JPEG differs from the oracle's")
+                annot_checked += 1
         nver = min(2, nb)
         bts = get_batches(primary_staged)[:nver]
         tickets = [(model.submit_staged(b) if primary_staged else model.submit_jpeg_batch(b)) for b in bts]
@@ -657,6 +699,7 @@ def main():
             excused += len(c["left_got"]) + len(c["left_ref"]) - len(c["not_borderline"])
             unexplained += len(c["not_borderline"])
         verified = {"frames": len(got), "max_abs_err": max_err, "count_mismatch_frames": bad, "borderline_detections_excused": excused,
+                    "annotated_streams_byte_identical": annot_checked,
                     "unexplained_detections": unexplained,
                     "against": "CPU oracle (oracle/) on the same JPEG bytes, every detection of every frame; tolerance 1e-3 (north_star); "
                                "a count mismatch passes only when every unmatched detection sits within the tolerance of the "
@@ -816,7 +859,7 @@ def main():
                 json.dump({"steps": prof_steps, "batch": B, "stats": stats, "roof_steps": ROOF_STEPS,
                            "stats_loaded": extras.get("kernel_stats_loaded"), "stats_alone": extras.get("kernel_stats_alone")}, f, indent=1)
         if not args.no_cpu_baseline and world == 1 and not host_only:
-            out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H)
+            out["cpu_baseline"] = cpu_baseline(jpegs[:64], weights, priors, args.cpu_seconds, W, H, annotate=args.annotate)
         print(json.dumps(out), flush=True)
     if staged_batches:
         for b in staged_batches:
