@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   extern __shared__ float s_sh[];
   float* s_w = s_sh;                 // packed weights [1][9][64]
   float* s_lut = s_sh + 9 * 64;      // 3 x 256 normalisation table, then 256 zeros (the "table" of a padding row)
-  float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][2 column halves][16 groups][4 columns] of one input row
+  float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][16 groups][8 columns] of one input row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
@@ -1813,12 +1813,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   // (3 * 4c + 4r + 8) >> 4: only the two rounding terms differ from h2v2's 8 | 7.
   const bool c_v2 = dcv.v[0] == 2;
   const int bias_l = c_v2 ? 8 : 4, bias_r = c_v2 ? 7 : 8;
-  // Layout [channel][columns 0-3 | 4-7][group][4] (round 5): an MFMA lane's two 16-byte reads are then 16 bytes apart from its
-  // neighbours' -- with [channel][group][8] they were 32 apart, groups j, j + 4, j + 8, j + 12 on the same banks, and
-  // SQ_LDS_BANK_CONFLICT of this kernel stood at 106 % of its LDS-active cycles.
-  float* xb = s_x + wave * 512;                        // [4][2][16][4]
-  const float* xr = xb + q * 128 + j16 * 4;            // what this MFMA lane reads back: columns 0-3 here, 4-7 64 floats on
-  const int xl = max(q * 128 + 64 + j16 * 4 - 1, 0);   // the column left of them (group j16 - 1's last: its column 7)
+  // (Round 5 tried [channel][columns 0-3 | 4-7][group][4], which makes the MFMA lanes' 16-byte reads conflict-free: the
+  // kernel's SQ_LDS_BANK_CONFLICT share went from 106 % to 133 % of its LDS-active cycles and its time did not move, 60.4 ->
+  // 60.5 us -- the conflicts that count are the six table look-ups per lane and row below, whose addresses are the pixels.)
+  float* xb = s_x + wave * 512;                        // [4][16][8]
+  const float* xr = xb + q * 128 + j16 * 8;            // what this MFMA lane reads back
+  const int xl = max(q * 128 + j16 * 8 - 1, 0);        // the column left of them (group j16 - 1's last)
   const bool left_ok = j16 > 0 && ix0 > 0;             // else: zero padding at the row start (or a halo lane)
   *reinterpret_cast<float2*>(xb + 384 + 2 * lane) = make_float2(0.f, 0.f);  // channel 3: zeros, written once
   auto dpp_prev = [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); };
@@ -1855,12 +1855,12 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
     // (a padding row reads the table's row of zeros: two selects per row instead of a branch around the six reads)
     const float* l0 = s_lut + (ok ? 0 : 768);
     const int lstep = ok ? 256 : 0;
-    float* xw = xb + (cp >> 1) * 64 + cg * 4 + 2 * (cp & 1);
+    float* xw = xb + cg * 8 + 2 * cp;
     *reinterpret_cast<float2*>(xw) = make_float2(l0[r0], l0[r1]);
     *reinterpret_cast<float2*>(xw + 128) = make_float2(l0[lstep + g0], l0[lstep + g1]);
     *reinterpret_cast<float2*>(xw + 256) = make_float2(l0[2 * lstep + b0], l0[2 * lstep + b1]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's stores before the wave's loads (in-order LDS)
-    const float4 va = *reinterpret_cast<const float4*>(xr), vb = *reinterpret_cast<const float4*>(xr + 64);
+    const float4 va = *reinterpret_cast<const float4*>(xr), vb = *reinterpret_cast<const float4*>(xr + 4);
     const float left = xb[xl];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and these loads before the next row's stores
     v[0] = va.x, v[1] = va.y, v[2] = va.z, v[3] = va.w, v[4] = vb.x, v[5] = vb.y, v[6] = vb.z, v[7] = vb.w;

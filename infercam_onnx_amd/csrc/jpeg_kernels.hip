@@ -10,6 +10,11 @@ namespace {
 
 constexpr int kBlocksPerWG = 32;  // 32 DCT blocks (4 KiB of coefficients) per 256-thread workgroup
 constexpr int kWsStride = 65;     // padded LDS row so that pass-2 lanes (one block each) hit distinct banks
+// ... and the coefficient blocks in LDS 33 dwords apart, one lane per block in pass 1 too (round 5).  With blocks 64 int16 = 32
+// dwords apart and a wave covering 8 blocks x 8 columns, the eight blocks' copies of one coefficient sat in the same bank
+// (8-way conflict on each of the 8 reads of a thread) and the column results of blocks lb, columns c with equal lb + c in the
+// same bank of the padded workspace: SQ_LDS_BANK_CONFLICT was 276 % of the kernel's LDS-active cycles.
+constexpr int kInStride = 66;     // int16 per block in LDS
 
 #define FIX_0_298631336 2446
 #define FIX_0_390180644 3196
@@ -85,7 +90,7 @@ template <bool ZZ>
 __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ descs, const int16_t* __restrict__ coef,
                                               size_t coef_stride, uint8_t* __restrict__ planes, size_t plane_stride,
                                               const int16_t* __restrict__ dc, size_t dc_stride) {
-  __shared__ __attribute__((aligned(16))) int16_t s_in[kBlocksPerWG * 64];
+  __shared__ __attribute__((aligned(16))) int16_t s_in[kBlocksPerWG * kInStride];
   __shared__ int s_ws[kBlocksPerWG * kWsStride];
   const int frame = blockIdx.y;
   const JpegFrameDesc& d = descs[frame];
@@ -99,19 +104,20 @@ __global__ __launch_bounds__(256) void k_idct(const JpegFrameDesc* __restrict__ 
     uint4 v = *reinterpret_cast<const uint4*>(src + tid * 8);
     // the device entropy decoder keeps the DC terms in a compact side array (the thread that loads a block's head patches it in)
     if (dc && (tid & 7) == 0) v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)dc[(size_t)frame * dc_stride + g0 + (tid >> 3)];
-    *reinterpret_cast<uint4*>(&s_in[tid * 8]) = v;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_in[(tid >> 3) * kInStride + (tid & 7) * 8]);  // (4-byte aligned: the stride is odd in dwords)
+    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
   }
   __syncthreads();
-  // pass 1: columns.  thread -> (local block, column)
+  // pass 1: columns.  thread -> (column, local block): a wave covers 2 columns x 32 neighbouring blocks, like pass 2
   {
-    const int lb = tid >> 3, c = tid & 7;
+    const int lb = tid & 31, c = tid >> 5;
     if (lb < nblk) {
       const uint32_t g = g0 + lb;
       const int comp = (d.ncomp > 1 && g * 64 >= d.coef_off[1]) ? ((g * 64 >= d.coef_off[2]) ? 2 : 1) : 0;
       const uint16_t* q = d.qt[comp];
       int x[8], o[8];
 #pragma unroll
-      for (int r = 0; r < 8; r++) x[r] = (int)s_in[lb * 64 + (ZZ ? (int)c_nat_to_zig[r * 8 + c] : r * 8 + c)] * (int)q[r * 8 + c];
+      for (int r = 0; r < 8; r++) x[r] = (int)s_in[lb * kInStride + (ZZ ? (int)c_nat_to_zig[r * 8 + c] : r * 8 + c)] * (int)q[r * 8 + c];
       idct_1d(x, o, 11);  // CONST_BITS - PASS1_BITS
 #pragma unroll
       for (int r = 0; r < 8; r++) s_ws[lb * kWsStride + r * 8 + c] = o[r];
