@@ -7,6 +7,8 @@
 //   ufd_wait: a few hundred bytes of detections per frame come back (and the annotated streams).
 // Weights (1.1 MB) and priors stay resident in HBM for the life of the handle.  State and shared helpers: model_types.hpp.
 #include "model_types.hpp"
+#include "model_internal.hpp"
+#include "model_parts.hpp"
 
 namespace ufd {
 thread_local std::string g_create_error;
@@ -29,10 +31,12 @@ namespace {
 // event is waited for by a stream or by the host, copy + hipStreamSynchronize does not, and neither does copy + any kernel
 // + hipEventRecord).  So an empty kernel goes between a copy and the event that marks it.
 __global__ void k_copy_fence() {}
-hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream) {
+}  // namespace
+hipError_t ufd::record_behind_copy(hipEvent_t ev, hipStream_t stream) {
   hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, stream);
   return hipEventRecord(ev, stream);
 }
+namespace {
 
 // NO COPY STREAM (round 4).  The runtime gives a process four hardware queues; a fifth stream shares one of them and its
 // work is serialised with a context's kernels.  With a copy stream three compute contexts were the most that paid; without
@@ -64,58 +68,9 @@ __global__ __launch_bounds__(256) void k_results_out(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
-// packed streams of an annotate batch (16-byte aligned pieces, *total bytes in all) -> the caller's pinned buffer of `cap` bytes
-__global__ __launch_bounds__(256) void k_fetch_streams(const uint4* __restrict__ src, const uint32_t* __restrict__ total, uint4* __restrict__ dst,
-                                                       uint32_t cap16) {
-  const uint32_t n16 = min((*total + 15u) >> 4, cap16);
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
-}
-
 }  // namespace
 
-// ---------------------------------------------------------------- profiling
-namespace ufd {
-int prof_name_id(ufd_model* m, const std::string& name) {
-  for (size_t i = 0; i < m->prof_names.size(); i++)
-    if (m->prof_names[i] == name) return (int)i;
-  m->prof_names.push_back(name);
-  ufd_kernel_stat st;
-  std::memset(&st, 0, sizeof(st));
-  std::snprintf(st.name, sizeof(st.name), "%s", name.c_str());
-  m->prof_stats.push_back(st);
-  return (int)m->prof_names.size() - 1;
-}
-
-hipEvent_t prof_event(ufd_model* m) {
-  if (!m->prof_free.empty()) {
-    hipEvent_t e = m->prof_free.back();
-    m->prof_free.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
-  return e;
-}
-}  // namespace ufd
-
 namespace {
-
-void prof_flush(ufd_model* m) {
-  std::lock_guard<std::mutex> lk(m->shared_mu);
-  for (auto& pe : m->prof_pending) {
-    float ms = 0;
-    if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
-      auto& st = m->prof_stats[pe.name_id];
-      st.launches++;
-      st.total_ms += ms;
-      st.bytes += pe.bytes;
-      st.flops += pe.flops;
-    }
-    m->prof_free.push_back(pe.e0);
-    m->prof_free.push_back(pe.e1);
-  }
-  m->prof_pending.clear();
-}
 
 int alloc_slot(ufd_model* m, Slot& s) {
   if (s.h_descs) return UFD_OK;
@@ -221,39 +176,6 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 
 // ---------------------------------------------------------------- GPU stages
 // [count][3][H][W] in d_input (or the sample planes, fused stem) -> every conv output the heads need.
-// Host statistics: the batch's first kernel is about to be enqueued on the context's stream (its H2D, if any, is already
-// waited for on that stream) -- the time between the previous batch's end event and this one is time the stream had
-// nothing to run.
-void span_begin(Slot& s) {
-  Ctx& c = *tl_cur;
-  if (s.span_idx >= 0 || !c.ev_span[0][0]) return;
-  s.span_seq = c.span_issued++;
-  s.span_idx = (int)(s.span_seq % Ctx::kSpanRing);
-  (void)hipEventRecord(c.ev_span[s.span_idx][0], c.stream);
-}
-
-// ... and its last operation has been enqueued
-void span_end(Slot& s) {
-  if (s.span_idx >= 0) (void)hipEventRecord(tl_cur->ev_span[s.span_idx][1], tl_cur->stream);
-}
-
-// The slot's batch is complete: fold its span (and the gap in front of it) into the context's sums.
-void span_fold(ufd_model* m, Slot& s) {
-  if (s.span_idx < 0 || !s.ctx) return;
-  Ctx& c = *s.ctx;
-  float span = 0, gap = 0;
-  const int prev = (int)((s.span_seq + Ctx::kSpanRing - 1) % Ctx::kSpanRing);
-  const bool ok = hipEventElapsedTime(&span, c.ev_span[s.span_idx][0], c.ev_span[s.span_idx][1]) == hipSuccess;
-  std::lock_guard<std::mutex> lk(m->shared_mu);
-  // (a gap only between consecutive batches of the context, both since the last reset)
-  const bool have_prev = s.span_seq > 0 && c.span_last_done == s.span_seq &&
-                         hipEventElapsedTime(&gap, c.ev_span[prev][1], c.ev_span[s.span_idx][0]) == hipSuccess;
-  if (ok) c.gpu_batches++, c.gpu_span_ms += span;
-  if (ok && have_prev && c.gpu_batches > 1) c.gpu_gap_ms += std::max(gap, 0.0f);
-  c.span_last_done = s.span_seq + 1;
-  s.span_idx = -1;
-}
-
 void enqueue_forward(ufd_model* m, uint32_t count) {
   for (int i = 0; i < kNumConv; i++) enqueue_layer(m, i, count);
   tl_cur->last_forward_count = count;
@@ -305,48 +227,6 @@ int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   HIPC(m, hipEventRecord(s.done, tl_cur->stream));
   s.ctx = tl_cur;
   return UFD_OK;
-}
-
-// N1: the finished streams of the slot's batch -> the caller's buffer: which frames hand theirs out, and where they lie.
-// The bytes are there already when the buffer is pinned (k_fetch_streams at the end of the batch's chain); otherwise
-// this is the second half of a two-step copy, one D2H of everything that fits.
-int fetch_streams(ufd_model* m, Slot& s) {
-  const ufd_annotate& a = s.annot_args;
-  for (uint32_t i = 0; i < s.count; i++) a.jpeg_off[i] = 0, a.jpeg_len[i] = 0;
-  if (!s.annot_ran) return UFD_OK;  // nothing decoded
-  const uint32_t* len = s.h_enc_meta;
-  const uint32_t* off = s.h_enc_meta + m->B;
-  size_t fit = 0;  // bytes of the packed output that hold whole streams and fit the caller's buffer
-  int rc = UFD_OK;
-  for (uint32_t i = 0; i < s.count; i++) {
-    // (the frame's final status as finish_slot merged it -- host parse, device entropy decoder, truncation -- whether or
-    // not the caller passed a status array: a frame the device decoder flagged never hands out its stream)
-    const bool failed = s.st[i] != UFD_OK && s.st[i] != UFD_E_TRUNCATED;
-    if (failed || !len[i]) continue;
-    if ((size_t)off[i] + len[i] > a.jpeg_cap) {
-      if (s.st[i] == UFD_OK) s.st[i] = UFD_E_TRUNCATED;
-      if (s.status && s.status[i] == UFD_OK) s.status[i] = UFD_E_TRUNCATED;
-      if (!s.status && rc == UFD_OK) rc = UFD_E_TRUNCATED;
-      continue;
-    }
-    a.jpeg_off[i] = off[i], a.jpeg_len[i] = len[i];
-    fit = std::max(fit, (size_t)off[i] + len[i]);
-  }
-  if (fit && !s.annot_fetched) {
-    // (the caller's buffer is not pinned host memory: a copy on the batch's own stream, behind whatever that context has
-    // queued since -- the price of pageable output)
-    HIPC(m, hipMemcpyAsync(a.jpeg_out, s.d_enc_out, fit, hipMemcpyDeviceToHost, s.ctx->stream));
-    HIPC(m, record_behind_copy(s.enc_copied, s.ctx->stream));
-    HIPC(m, hipEventSynchronize(s.enc_copied));
-  } else if (fit > (a.jpeg_cap & ~(size_t)15)) {
-    // k_fetch_streams writes whole 16-byte pieces only: a buffer whose size is no multiple of 16 and whose last stream ends in
-    // the ragged tail gets those 1..15 bytes (the EOI marker or the multipart trailer) by a copy of their own.
-    const size_t done = a.jpeg_cap & ~(size_t)15;
-    HIPC(m, hipMemcpyAsync(a.jpeg_out + done, s.d_enc_out + done, fit - done, hipMemcpyDeviceToHost, s.ctx->stream));
-    HIPC(m, record_behind_copy(s.enc_copied, s.ctx->stream));
-    HIPC(m, hipEventSynchronize(s.enc_copied));
-  }
-  return rc;
 }
 
 // Releases the slot on every exit path of finish_slot (an early HIP error return must not leak it for the life of the
@@ -767,156 +647,6 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
     hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, c.stream);
   }
   span_begin(s);
-  return UFD_OK;
-}
-
-// ---------------------------------------------------------------- N1: rectangles + JPEG re-encode (inferer.rs:38-40)
-size_t enc_frame_bound(uint32_t w, uint32_t h) {
-  const size_t mcus = (size_t)((w + 15) / 16) * ((h + 15) / 16);
-  return 2 * enc_stream_bound(mcus) + 1024;  // every entropy-coded byte stuffed + header, EOI, framing
-}
-
-// Encoder scratch of a context for frames of up to mw x mh (grown on demand: a camera stream has one frame size, so
-// this happens on its first annotate batch) and the set-up of the requested (quality, framing).
-int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart, uint32_t mw, uint32_t mh) {
-  if (quality < 1 || quality > 100) return m->fail(UFD_E_ARG, "quality must be in 1..100");
-  EncBuffers& e = c.enc;
-  if (!c.enc_ready) {  // fixed-size pieces, once
-    HIPC(m, hipMalloc(&e.total_bits, sizeof(uint32_t) * m->B));
-    HIPC(m, hipMalloc(&c.d_enc_tables, sizeof(uint32_t) * 2 * 272));
-    HIPC(m, hipMalloc(&c.d_enc_descs, sizeof(JpegFrameDesc) * m->B));
-    HIPC(m, hipMalloc(&c.d_label_ops, label_ops_bytes(m->B, (uint32_t)m->K)));
-    {
-      const int* g;
-      const float* cov;
-      size_t ng, nc;
-      label_atlas(&g, &ng, &cov, &nc);
-      HIPC(m, hipMalloc(&c.d_glyphs, ng * sizeof(int)));
-      HIPC(m, hipMalloc(&c.d_coverage, nc * sizeof(float)));
-      HIPC(m, hipMemcpy(c.d_glyphs, g, ng * sizeof(int), hipMemcpyHostToDevice));
-      HIPC(m, hipMemcpy(c.d_coverage, cov, nc * sizeof(float), hipMemcpyHostToDevice));
-    }
-    uint32_t tabs[2 * 272];
-    enc_make_code_tables(tabs);
-    HIPC(m, hipMemcpy(c.d_enc_tables, tabs, sizeof(tabs), hipMemcpyHostToDevice));
-    e.tables = c.d_enc_tables;
-    c.enc_ready = true;
-  }
-  const size_t mcus = (size_t)((mw + 15) / 16) * ((mh + 15) / 16);
-  if (mcus > c.enc_mcus) {
-    // earlier encodes of this context may still use the old scratch: drain, free, allocate the larger set.  A failed
-    // allocation leaves enc_mcus = 0 and null pointers behind (nothing leaks, the next batch tries again).
-    HIPC(m, hipStreamSynchronize(c.stream));
-    (void)hipFree(e.planes), (void)hipFree(e.coef), (void)hipFree(e.bits), (void)hipFree(e.words), (void)hipFree(e.chunk_ff);
-    e.planes = nullptr, e.coef = nullptr, e.bits = nullptr, e.words = nullptr, e.chunk_ff = nullptr;
-    c.enc_mcus = 0;
-    const size_t sb = enc_stream_bound(mcus);
-    e.coef_stride = mcus * 6 * 64;
-    e.blk_stride = mcus * 6;
-    e.word_stride = (((sb + 3) / 4 + 3) & ~(size_t)3) + 8;  // whole 16-byte groups + the padding the scan zeroes
-    e.chunk_stride = (sb + 4095) / 4096 + 1;
-    e.plane_stride = mcus * 384;  // 256 luma + 2 x 64 chroma samples per MCU
-    HIPC(m, hipMalloc(&e.planes, e.plane_stride * m->B));
-    HIPC(m, hipMalloc(&e.coef, sizeof(int16_t) * e.coef_stride * m->B));
-    HIPC(m, hipMalloc(&e.bits, sizeof(uint32_t) * e.blk_stride * m->B));
-    HIPC(m, hipMalloc(&e.words, sizeof(uint32_t) * e.word_stride * m->B));
-    HIPC(m, hipMalloc(&e.chunk_ff, sizeof(uint32_t) * e.chunk_stride * m->B));
-    c.enc_mcus = mcus;
-  }
-  // the (quality, framing) set-up: a cached one, a free entry (its fresh device header has no reader yet: no drain), or
-  // the least recently used entry, rewritten behind the stream's earlier encodes
-  int pick = -1, lru = 0;
-  for (int i = 0; i < Ctx::kEncSetups; i++) {
-    const Ctx::EncSetup& q = c.enc_setups[i];
-    if (q.quality == (int)quality && q.multipart == (int)multipart) pick = i;
-    if (q.last_use < c.enc_setups[lru].last_use) lru = i;
-  }
-  if (pick < 0) {
-    pick = lru;
-    Ctx::EncSetup& q = c.enc_setups[pick];
-    uint8_t ql[64], qc[64], hdr[1024];
-    enc_quant_tables((int)quality, ql, qc);
-    q.ifast = quality < 96;  // turbojpeg.c setCompDefaults: JDCT_ISLOW from quality 96 on, JDCT_FASTEST below
-    enc_make_quant(ql, qc, q.ifast, &q.q);
-    const size_t n = enc_make_header(ql, qc, multipart, hdr, &q.pre_len, &q.hdr_len, &q.dim_off, &q.post_len);
-    if (q.d_header) HIPC(m, hipStreamSynchronize(c.stream));  // an evicted set-up: earlier encodes still read its header
-    else HIPC(m, hipMalloc(&q.d_header, 1024));
-    q.quality = -1;
-    HIPC(m, hipMemcpy(q.d_header, hdr, n, hipMemcpyHostToDevice));
-    q.quality = (int)quality, q.multipart = (int)multipart;
-  }
-  Ctx::EncSetup& q = c.enc_setups[pick];
-  q.last_use = ++c.enc_seq;
-  c.enc_cur = pick;
-  e.header = q.d_header;
-  e.pre_len = q.pre_len, e.hdr_len = q.hdr_len, e.dim_off = q.dim_off, e.post_len = q.post_len;
-  return UFD_OK;
-}
-
-// Output of a slot's batch for frames of up to mw x mh (grown on demand; the slot is ours and its previous batch has
-// been waited for, so nothing on the GPU still refers to the old buffer).
-int ensure_slot_encoder(ufd_model* m, Slot& s, uint32_t mw, uint32_t mh) {
-  if (!s.d_enc_meta) {
-    HIPC(m, hipMalloc(&s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1)));
-    HIPC(m, hipHostMalloc(&s.h_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipHostMallocDefault));
-    HIPC(m, hipEventCreateWithFlags(&s.enc_copied, hipEventDisableTiming));
-  }
-  const size_t need = enc_frame_bound(mw, mh) * m->B;
-  if (need > s.enc_out_cap) {
-    (void)hipFree(s.d_enc_out);
-    s.d_enc_out = nullptr, s.enc_out_cap = 0;
-    HIPC(m, hipMalloc(&s.d_enc_out, need));
-    s.enc_out_cap = need;
-  }
-  return UFD_OK;
-}
-
-// Rectangles of the slot's detections into the context's RGB frames, then the encoder; lengths / offsets of the
-// finished streams follow the detections to the host.  On the context's stream, behind the NMS.
-int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count) {
-  Ctx& c = *tl_cur;
-  int rc = ensure_encoder(m, c, s.annot_args.quality, (s.annot_args.flags & UFD_ANNOT_MULTIPART) != 0, mw, mh);
-  if (rc) return rc;
-  rc = ensure_slot_encoder(m, s, mw, mh);
-  if (rc) return rc;
-  {
-    ProfScope ps(m, "draw_labels", 0, 0);
-    launch_draw_labels(d_descs, s.d_dets, (uint32_t)m->K, c.d_ndet, (uint32_t)m->K, c.d_label_ops, c.d_glyphs, c.d_coverage,
-                       !(s.annot_args.flags & UFD_ANNOT_NO_TEXT), c.d_rgb, m->rgb_stride, mw, mh, s.annot_args.label_width,
-                       s.annot_args.label_height, count, c.stream);
-  }
-  EncBuffers e = c.enc;
-  e.out = s.d_enc_out;
-  e.out_len = s.d_enc_meta, e.out_off = s.d_enc_meta + m->B, e.out_total = s.d_enc_meta + 2 * m->B;
-  {
-    std::unique_ptr<ProfScope> scope;
-    const double bytes = (double)count * mw * mh * 3.0;
-    const EncStageHook hook = [&](const char* stage, bool begin) {
-      if (begin) scope.reset(new ProfScope(m, stage, bytes, 0));
-      else scope.reset();
-    };
-    launch_jpeg_encode(d_descs, c.d_rgb, m->rgb_stride, mw, mh, count, c.enc_setups[c.enc_cur].q, c.enc_setups[c.enc_cur].ifast, e, c.stream,
-                       &hook);
-  }
-  HIPC(m, hipMemcpyAsync(s.h_enc_meta, s.d_enc_meta, sizeof(uint32_t) * (2 * m->B + 1), hipMemcpyDeviceToHost, c.stream));
-  s.annot_ran = true;
-  s.annot_fetched = false;
-  if (s.annot_args.jpeg_out && s.annot_args.jpeg_cap >= 16) {
-    hipPointerAttribute_t at;
-    std::memset(&at, 0, sizeof(at));
-    // (pinned host memory this handle's GPU can write: allocated portable -- ufd_host_alloc, ufd_model_host_alloc -- or on this device)
-    if (hipPointerGetAttributes(&at, s.annot_args.jpeg_out) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer &&
-        (reinterpret_cast<uintptr_t>(at.devicePointer) & 15) == 0 &&
-        ((at.allocationFlags & hipHostMallocPortable) || at.device == m->cfg.device_id)) {
-      const uint32_t cap16 = (uint32_t)std::min<size_t>(s.annot_args.jpeg_cap >> 4, 0xFFFFFFFFu);
-      ProfScope ps(m, "d2h_streams", 0, 0);
-      hipLaunchKernelGGL(k_fetch_streams, dim3(256), dim3(256), 0, c.stream, reinterpret_cast<const uint4*>(s.d_enc_out),
-                         s.d_enc_meta + 2 * m->B, static_cast<uint4*>(at.devicePointer), cap16);
-      s.annot_fetched = true;
-    } else {
-      (void)hipGetLastError();  // (pageable memory: hipPointerGetAttributes reports an error the next call must not see)
-    }
-  }
   return UFD_OK;
 }
 
@@ -1522,23 +1252,6 @@ int create(const ufd_config* cfg, ufd_model** out) {
   return UFD_OK;
 }
 
-template <typename F>
-int guarded(ufd_model* m, F&& f) {
-  if (!m) return UFD_E_ARG;
-  std::lock_guard<std::mutex> lk(m->mu);
-  try {
-    if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
-    tl_cur = &m->ctx[0];  // synchronous calls and taps run on context 0 from the calling thread
-    tl_pool = m->pool.get();
-    tl_prof = true;
-    return f();
-  } catch (const std::exception& e) {
-    return m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
-  } catch (...) {
-    return m->fail(UFD_E_DEVICE, "unknown exception");
-  }
-}
-
 }  // namespace
 
 // =================================================================== C ABI
@@ -1583,10 +1296,6 @@ int ufd_model_placement(const ufd_model* m, int32_t* device_id, int32_t* numa_no
   if (pci_bdf && pci_cap) std::snprintf(pci_bdf, pci_cap, "%s", m->pci_bdf.c_str());
   if (cpu_list && cpu_cap) std::snprintf(cpu_list, cpu_cap, "%s", m->cpu_list.c_str());
   return UFD_OK;
-}
-
-int ufd_annotate_parity(uint32_t annot_flags) {
-  return (annot_flags & UFD_ANNOT_NO_TEXT) ? UFD_PARITY_EXACT : UFD_PARITY_LABELS_UNPINNED;
 }
 
 int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height) {
@@ -1694,7 +1403,6 @@ int ufd_annotate_jpeg_batch(ufd_model* m, const uint8_t* const* jpegs, const siz
   return ufd_wait(m, ticket);
 }
 
-size_t ufd_encode_bound(uint32_t w, uint32_t h) { return enc_frame_bound(w, h) + 64; }
 
 void* ufd_host_alloc(size_t bytes) {
   void* p = nullptr;
@@ -2071,71 +1779,6 @@ int ufd_debug_load_onnx(const char* path, uint32_t variant, float* weights, size
   } catch (...) {
     return UFD_E_DEVICE;
   }
-}
-
-int ufd_host_stats_reset(ufd_model* m) {
-  if (!m) return UFD_E_ARG;
-  std::lock_guard<std::mutex> lk(m->shared_mu);
-  for (int c = 0; c < m->num_ctx; c++) {
-    Worker& w = m->workers[c];
-    w.ns_busy = 0, w.ns_plan = 0, w.ns_copy = 0, w.batches = 0, w.launches = 0;
-    m->ctx[c].gpu_batches = 0, m->ctx[c].gpu_span_ms = 0, m->ctx[c].gpu_gap_ms = 0;
-  }
-  m->ns_wait = 0, m->waits = 0;
-  m->stats_t0 = now_ns();
-  return UFD_OK;
-}
-
-int ufd_host_stats_read(ufd_model* m, ufd_host_stats* out) {
-  if (!m || !out || out->struct_size != sizeof(ufd_host_stats)) return UFD_E_ARG;
-  std::memset(out, 0, sizeof(*out));
-  out->struct_size = sizeof(*out);
-  std::lock_guard<std::mutex> lk(m->shared_mu);
-  out->num_ctx = (uint32_t)m->num_ctx;
-  out->wall_ms = (double)(now_ns() - m->stats_t0) * 1e-6;
-  uint64_t busy = 0, plan = 0, copy = 0;
-  for (int c = 0; c < m->num_ctx; c++) {
-    const Worker& w = m->workers[c];
-    busy += w.ns_busy, plan += w.ns_plan, copy += w.ns_copy;
-    out->batches += w.batches, out->launches += w.launches;
-    out->worker_busy_ms[c] = (double)w.ns_busy * 1e-6;
-    out->gpu_batches[c] = m->ctx[c].gpu_batches;
-    out->gpu_span_ms[c] = m->ctx[c].gpu_span_ms;
-    out->gpu_gap_ms[c] = m->ctx[c].gpu_gap_ms;
-  }
-  out->plan_ms = (double)plan * 1e-6, out->copy_ms = (double)copy * 1e-6;
-  out->issue_ms = (double)(busy - std::min(busy, plan + copy)) * 1e-6;
-  out->waits = m->waits, out->wait_ms = (double)m->ns_wait * 1e-6;
-  return UFD_OK;
-}
-
-int ufd_profile_reset(ufd_model* m) {
-  return guarded(m, [&]() -> int {
-    HIPC(m, hipStreamSynchronize(tl_cur->stream));
-    prof_flush(m);
-    for (auto& st : m->prof_stats) st.launches = 0, st.total_ms = 0, st.bytes = 0, st.flops = 0;
-    return UFD_OK;
-  });
-}
-
-int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
-  return guarded(m, [&]() -> int {
-    if (!every_n) return m->fail(UFD_E_ARG, "every_n must be >= 1");
-    m->prof_every = every_n;
-    m->prof_batch = 0;
-    return UFD_OK;
-  });
-}
-
-int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n) {
-  return guarded(m, [&]() -> int {
-    if (!n) return m->fail(UFD_E_ARG, "null argument");
-    HIPC(m, hipStreamSynchronize(tl_cur->stream));
-    prof_flush(m);
-    *n = (uint32_t)m->prof_stats.size();
-    for (uint32_t i = 0; i < std::min<uint32_t>(cap, *n); i++) stats[i] = m->prof_stats[i];
-    return UFD_OK;
-  });
 }
 
 }  // extern "C"

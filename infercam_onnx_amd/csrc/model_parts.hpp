@@ -1,0 +1,38 @@
+// model_parts.hpp -- what model.cpp, stats.cpp and annotate.cpp need from one another (library-internal, not part of the C
+// ABI; include behind model_types.hpp, whose types the declarations use).
+#pragma once
+#include "model_types.hpp"
+
+namespace ufd {
+// stats.cpp: kernel profiling (events on the library's streams), device-time spans per context, host statistics
+void prof_flush(ufd_model* m);
+void span_begin(Slot& s);
+void span_end(Slot& s);
+void span_fold(ufd_model* m, Slot& s);
+// annotate.cpp: N1 (inferer.rs:38-46) -- encoder scratch, rectangles + labels + re-encode of a decoded batch, the streams' way out
+size_t enc_frame_bound(uint32_t w, uint32_t h);
+int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart, uint32_t mw, uint32_t mh);
+int ensure_slot_encoder(ufd_model* m, Slot& s, uint32_t mw, uint32_t mh);
+int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count);
+int fetch_streams(ufd_model* m, Slot& s);
+// model.cpp: an event that marks a copy (an empty kernel between the two: ROCm 7.2 keeps ~2 KB per event recorded directly behind a copy)
+hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream);
+
+// Synchronous entry points and stage taps: handle lock, device selection, context 0, no exception across the ABI.
+template <typename F>
+int guarded(ufd_model* m, F&& f) {
+  if (!m) return UFD_E_ARG;
+  std::lock_guard<std::mutex> lk(m->mu);
+  try {
+    if (hipSetDevice(m->cfg.device_id) != hipSuccess) return m->fail(UFD_E_DEVICE, "hipSetDevice failed");
+    tl_cur = &m->ctx[0];  // synchronous calls and taps run on context 0 from the calling thread
+    tl_pool = m->pool.get();
+    tl_prof = true;
+    return f();
+  } catch (const std::exception& e) {
+    return m->fail(UFD_E_DEVICE, std::string("exception: ") + e.what());
+  } catch (...) {
+    return m->fail(UFD_E_DEVICE, "unknown exception");
+  }
+}
+}  // namespace ufd
