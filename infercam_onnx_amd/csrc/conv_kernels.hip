@@ -824,16 +824,6 @@ __device__ __forceinline__ void dw_taps(const float4 (&m3)[3], const float* wq, 
   // (ReLU as the integer maximum with 0: behind inline asm fmaxf() would cost a canonicalising v_max_f32 of its own first)
   t[0] = relu_acc(t[0]), t[1] = relu_acc(t[1]), t[2] = relu_acc(t[2]), t[3] = relu_acc(t[3]);
 }
-// Edge-tap table of a packed depthwise table w2 [cin][12]: [4 variants][cin][8] = (w00 w10 w20 0 | w02 w12 w22 0); variants 0 ..
-// 2 as dw_variant (tap row 0 / 2 zeroed for a window over the top / bottom border), variant 3 all zero.
-__device__ __forceinline__ void fill_edge_taps(float* s_e, const float* __restrict__ w2, int cin) {
-  for (int i = threadIdx.x; i < 4 * cin * 8; i += 256) {
-    const int v = i / (cin * 8), c = (i >> 3) % cin, j = i & 7, k = j & 3;
-    const bool zero = v == 3 || k == 3 || (v == 1 && k == 0) || (v == 2 && k == 2);
-    s_e[i] = zero ? 0.f : w2[c * 12 + 3 * k + (j >> 2) * 2];
-  }
-}
-
 template <int C1, int CT2, bool RING>  // channels of the first block's input (16 / 32), 32-cout tiles of the second block (1 / 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dwpw2_mfma(ConvArgs3 p3) {
   const ConvArgs& a1 = p3.a[0];
@@ -864,13 +854,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = threadIdx.x; i < n4; i += 256) d4[i] = s4[i];
     };
     fill_dw_variants(s_dw1, a1.w2, C1);
-    fill_edge_taps(s_e1, a1.w2, C1);
+    copy4(s_e1, a1.w2 + C1 * 12, 4 * C1 * 2);                    // edge taps, packed on the host (pack_depthwise_weights)
     copy4(s_w1, a1.w, KS1 * 16);
-    for (int i = threadIdx.x; i < 2 * 16 * 32; i += 256) {
-      const int v = i >> 9, c = 2 * ((i >> 5) & 15) + (i & 1), k = (i >> 3) & 3, e = (i >> 1) & 3;
-      const float* w = a2.w2 + c * 12;
-      s_f2[i] = k < 3 ? (e == 0 ? (v ? 0.f : w[3 * k]) : w[3 * k + e - 1]) : (e == 0 ? w[9] : 0.f);
-    }
+    copy4(s_f2, a2.w2 + 32 * 12 + 4 * 32 * 8, 2 * 16 * 8);     // fold records of the second block's 32 channels, likewise
     copy4(s_w2, a2.w, CT2 * KS2 * 16);
     if (threadIdx.x < 32 * (1 + CT2)) {  // accumulator row r of half h holds channel (r & 3) + 8 * (r >> 2) + 4 * h of its tile
       const int t = threadIdx.x, r = t & 15, co = (t >> 5) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
@@ -1934,7 +1920,13 @@ void pack_pointwise_weights(const float* w, int cin, int cout, float* packed) {
       }
 }
 
-size_t depthwise_packed_floats(int c) { return (size_t)c * 12; }
+// [c][12] records (9 taps ky-major, bias, 2 pad), then the two derived tables of the chained kernel (k_dwpw2_mfma copies them
+// to LDS as they are: built per block from the records they cost every block ~1500 dependent scalar loads in its prologue):
+//   edge taps [4][c][8] = (w00 w10 w20 0 | w02 w12 w22 0), copies 0 .. 2 as dw_variant (tap row 0 / 2 zeroed for a window over
+//   the top / bottom border), copy 3 all zero;
+//   fold records [2][c / 2][32]: per channel pair (i, i + 1) and tap row k eight floats (wk0' wk0' | wk0 wk0 | wk1 wk1 | wk2 wk2),
+//   then (bias bias 0 ...); wk0' = wk0 in copy 0, 0 in copy 1 (lanes at the left image border).
+size_t depthwise_packed_floats(int c) { return (size_t)c * (12 + 32 + 32); }
 
 void pack_depthwise_weights(const float* w, const float* bias, int c, float* packed) {
   for (int i = 0; i < c; i++) {
@@ -1942,6 +1934,24 @@ void pack_depthwise_weights(const float* w, const float* bias, int c, float* pac
     packed[i * 12 + 9] = bias[i];
     packed[i * 12 + 10] = packed[i * 12 + 11] = 0.0f;
   }
+  float* e = packed + (size_t)c * 12;
+  for (int v = 0; v < 4; v++)
+    for (int i = 0; i < c; i++)
+      for (int j = 0; j < 8; j++) {
+        const int k = j & 3;
+        const bool zero = v == 3 || k == 3 || (v == 1 && k == 0) || (v == 2 && k == 2);
+        e[((size_t)v * c + i) * 8 + j] = zero ? 0.0f : w[i * 9 + 3 * k + (j >> 2) * 2];
+      }
+  float* f = e + (size_t)4 * c * 8;
+  for (int v = 0; v < 2; v++)
+    for (int pr = 0; pr < c / 2; pr++)
+      for (int idx = 0; idx < 32; idx++) {
+        const int i = 2 * pr + (idx & 1), k = idx >> 3, el = (idx >> 1) & 3;
+        float x;
+        if (k < 3) x = el == 0 ? (v ? 0.0f : w[i * 9 + 3 * k]) : w[i * 9 + 3 * k + el - 1];
+        else x = el == 0 ? bias[i] : 0.0f;
+        f[((size_t)v * (c / 2) + pr) * 32 + idx] = x;
+      }
 }
 
 size_t conv3x3_packed_floats(int cin) { return (size_t)cin * 3 * 64; }
