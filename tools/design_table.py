@@ -18,6 +18,7 @@ for ln in open(os.path.join(d, "kernel_times_alone.txt")):
 batches = alone.get("k_stem_planes_mfma", (34, 0))[0]
 sq = json.load(open(os.path.join(d, "sq_counters.json"))).get("instances", {}) if os.path.exists(os.path.join(d, "sq_counters.json")) else {}
 pmc = json.load(open(os.path.join(d, "pmc_traffic.json"))).get("instances", {})
+isa = json.load(open(os.path.join(d, "isa_mix.json"))).get("instances", {}) if os.path.exists(os.path.join(d, "isa_mix.json")) else {}
 bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
 loaded = bench.get("kernels_ms_per_step", {})
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,9 +36,9 @@ def print(*a):  # noqa: A001  (collect what is printed: --update writes it into 
     _print(*a)
 
 
-print("Source: `%s/` (kernel_times_alone.txt, bench.json, sq_counters.json, pmc_traffic.json); regenerate with `python tools/design_table.py %s --update`.\n" % (d.rstrip("/"), d.rstrip("/")))
-print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | traffic MB / launch (fetch + write) |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("Source: `%s/` (kernel_times_alone.txt, bench.json, sq_counters.json, pmc_traffic.json, isa_mix.json); regenerate with `python tools/design_table.py %s --update`.\n" % (d.rstrip("/"), d.rstrip("/")))
+print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | LDS conflicts | traffic MB / launch (fetch + write) | hot loop: vector instr. / MFMA (not fp32 arithmetic) |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 tot = 0.0
 pct = lambda x: "%.0f %%" % (100 * x) if x is not None else "–"
 for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
@@ -49,9 +50,14 @@ for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1])
     p = pmc.get(k, {})
     tr = "%.0f + %.0f" % (p["fetch_bytes_per_launch"] / 1e6, p["write_bytes_per_launch"] / 1e6) if p else "–"
     ld = loaded_by_dev.get(k)
-    print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s |" % (
+    h = isa.get(k, {}).get("hot_loop")
+    mix = "–"
+    if h and h.get("MFMA"):
+        valu = sum(h.get(c, 0) for c in ("FMA", "mov", "cndmask", "maxmin", "cmp", "int", "cvt"))
+        mix = "%.1f (%.1f)" % (valu / h["MFMA"], (valu - h.get("FMA", 0)) / h["MFMA"])
+    print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         k, per, us, "%.0f" % ld if ld else "–", pct(s.get("mfma_busy")), pct(s.get("valu_busy")),
-        "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), tr))
+        "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), pct(s.get("lds_conflict_share")), tr, mix))
 print("\nkernels alone per batch: %.0f µs; delivered: %.3f ms per batch (steady state %.0f frames/s)" % (
     tot, bench["host"]["ms_per_batch"] if "host" in bench else bench["ms_per_step"], bench.get("steady_state_fps", 0)))
 
