@@ -1,4 +1,5 @@
 #!/bin/bash
+# (UFD_DWPW2_LDS_PAD existed only for this measurement: docs/EXPERIMENTS.md round 5, "Room beside the chained kernel?")
 # one block of the chained kernel per CU (its LDS request padded beyond half a CU's LDS): does the room it leaves pay?
 # pad 0: as shipped (m1->m2: 80 KB, two blocks per CU; m3->m4: 25 KB); 8192: m1->m2 one block per CU, m3->m4 unchanged in effect;
 # 90000: both one block per CU

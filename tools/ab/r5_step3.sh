@@ -1,4 +1,5 @@
 #!/bin/bash
+# (UFD_DWPW_DEPTH and the ab/tail3.so build existed only for this measurement: docs/EXPERIMENTS.md round 5, "not kept")
 # round 5, third kernel step: k_rfb_tail at three waves per SIMD; k_dwpw_mfma with four k-steps of windows in flight
 set -u
 cd $GRAFT_REPO_ROOT

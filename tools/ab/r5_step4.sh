@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the dw -> pw family diet this A/B measured was not kept: docs/EXPERIMENTS.md round 5)
 # round 5, fourth kernel step: the stride-1 dw -> pw family on dw_taps_cm; then the SQ counters of every kernel (alt build)
 set -u
 cd $GRAFT_REPO_ROOT
