@@ -3,8 +3,9 @@ through ufd_infer_jpeg_batch and, every other round, ufd_annotate_jpeg_batch (re
 whatever the damaged frame decodes to) in mixed batches.  Every frame must end as OK / UFD_E_TRUNCATED / UFD_E_DECODE /
 UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE, every annotated stream must be a framed JPEG, and a clean batch must still decode
 bit-exactly afterwards.
-Usage: python tools/fuzz_gpu.py [rounds] [big]   (exits non-zero on any violation; "big": 640x480-class frames through
-UltraFace-640 instead of thumbnail-sized ones through UltraFace-320)"""
+Usage: python tools/fuzz_gpu.py [rounds] [big|model]   (exits non-zero on any violation; "big": 640x480-class frames through
+UltraFace-640 instead of thumbnail-sized ones through UltraFace-320; "model": every frame exactly 640x480, so that the 4:2:0 and
+4:2:2 ones take the fused stem -- sample planes straight into the first convolution -- in mixed, damaged batches)"""
 import sys
 import numpy as np
 
@@ -39,7 +40,8 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(11)
     w = synth.synthetic_weights()
-    big = len(sys.argv) > 2 and sys.argv[2] == "big"
+    model_size = len(sys.argv) > 2 and sys.argv[2] == "model"
+    big = model_size or (len(sys.argv) > 2 and sys.argv[2] == "big")
     if big:
         m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=w, priors=synth.gen_priors(640, 480), max_batch=8,
                               max_src=(704, 544), det_cap=17640)
@@ -47,7 +49,8 @@ def main():
         m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=8,
                               max_src=(640, 480), det_cap=4420)
     w0, h0 = (640, 480) if big else (96, 64)
-    base = [synth.encode_jpeg(synth.synth_frame(5, i, w0 + 8 * i, h0 + 8 * i), **kw) for i, kw in enumerate((
+    step = 0 if model_size else 8
+    base = [synth.encode_jpeg(synth.synth_frame(5, i, w0 + step * i, h0 + step * i), **kw) for i, kw in enumerate((
         {}, {"restart_rows": 1}, {"subsampling": "4:2:2"}, {"progressive": True}, {"optimize": True, "quality": 30},
         {"subsampling": "4:4:4", "restart_rows": 2}, {"quality": 100}, {"subsampling": "4:2:2", "restart_rows": 1}))]
     ref, st = m.infer_jpeg_batch(base)
