@@ -1,6 +1,8 @@
 """Host-side logic of the product library that needs no GPU: the C-ABI surface, the host Huffman
 stage, the ONNX loader, the Python mirror of nn.rs, and loud failure without a device."""
 import os
+import subprocess
+import sys
 import re
 
 import numpy as np
@@ -299,3 +301,52 @@ def test_planner_never_lets_two_live_tensors_share_arena_bytes(variant, flags):
                 assert li in gone, (li, gone)
         if flags == 2048:
             assert launches == (19 if variant == 640 else 26) and not any(L["rfb_tail"] for L in layers)
+
+
+def test_detection_list_comparison_rule():
+    """oracle/compare.py (round 5): the one rule by which the tests AND bench.py's `verified` block compare a frame's detections
+    with the oracle's -- equal within the tolerance in order; else matched as sets, and a detection without a partner is excused
+    only when its decision provably sat on the confidence threshold (strict `>`, nn.rs:121-128) or on max_iou (strict `>`,
+    nn.rs:209-214).  bench.py fails on any other leftover (it used to tolerate one mismatching frame in 64)."""
+    from oracle.compare import match_detections
+
+    a = np.array([[0.1, 0.1, 0.3, 0.3, 0.9], [0.5, 0.5, 0.7, 0.7, 0.8]], np.float32)
+    r = match_detections(a, a + 5e-5)
+    assert r["equal"] and not r["left_got"] and not r["not_borderline"]
+    # two detections whose confidences differ by less than the tolerance swap places: equal as sets
+    b = np.array([[0.5, 0.5, 0.7, 0.7, 0.80004], [0.1, 0.1, 0.3, 0.3, 0.80001]], np.float32)
+    r = match_detections(b, b[::-1].copy())
+    assert not r["equal"] and not r["left_got"] and not r["left_ref"] and r["max_err"] <= 1e-4
+    # an extra detection whose confidence sits on the threshold: unmatched but borderline
+    c = np.vstack([a, [[0.8, 0.8, 0.9, 0.9, 0.50003]]]).astype(np.float32)
+    r = match_detections(c, a)
+    assert len(r["left_got"]) == 1 and not r["not_borderline"]
+    # an extra detection well above the threshold and overlapping nothing: a real disagreement
+    d = np.vstack([a, [[0.8, 0.8, 0.9, 0.9, 0.7]]]).astype(np.float32)
+    r = match_detections(d, a)
+    assert len(r["left_got"]) == 1 and len(r["not_borderline"]) == 1
+    # ... unless its IoU with a kept detection of the other list is within 1e-3 of max_iou (the NMS decision flipped)
+    e = np.vstack([a, [[0.1, 0.1, 0.3, 0.5, 0.7]]]).astype(np.float32)  # IoU with a[0]: 0.04 / 0.08 = 0.5
+    r = match_detections(e, a, max_iou=0.5)
+    assert len(r["left_got"]) == 1 and not r["not_borderline"]
+    assert match_detections(np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32))["equal"]
+
+
+def test_isa_mix_reads_the_built_code_objects(tmp_path):
+    """tools/isa_mix.py (round 5's instruction ledger) on the library's own object files: every MFMA kernel instance is found
+    with its hot loop, the chained kernel's k-loop carries its DPP multiply-adds and no select, and the JSON beside the table
+    is what tools/design_table.py reads."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "isa_mix.txt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    inst = json.load(open(str(tmp_path / "isa_mix.json")))["instances"]
+    for k in ("k_dwpw2_mfma<16, 1, true>", "k_dwpw2_mfma<32, 2, false>", "k_dwpw_mfma<1, 1, 2, 1>", "k_dwpw_coop<1, 4>", "k_rfb_tail",
+              "k_stem_planes_mfma", "k_pw_mfma<1, 4, 1>", "k_conv3x3_rows_mfma<1, 1>"):
+        assert k in inst and inst[k]["kernel"]["MFMA"] > 0, k
+        # (k_rfb_tail's channel loops are fully unrolled since round 5: no loop of it holds an MFMA)
+        assert k == "k_rfb_tail" or inst[k]["hot_loop"].get("MFMA", 0) > 0, k
+    h = inst["k_dwpw2_mfma<16, 1, true>"]["hot_loop"]
+    assert h["MFMA"] == 64 and h["DPP"] >= 100 and h.get("cndmask", 0) <= 16, h  # (round 4's build: 135 selects in this loop)
