@@ -151,14 +151,55 @@ __device__ __forceinline__ int xcd_contiguous(int bx, int grid_x) { return (bx &
 // remedy: hipcc then keeps the 64 accumulators in vector registers through the prologue -- 204 VGPRs for 98, one wave
 // per SIMD instead of three.)
 constexpr int kBiasLds = 32;  // floats per cout tile
+// (in two steps, so that the load can sit in front of the block's table copies and the store behind them: one memory round
+// trip for everything a block stages, see copy_tables16)
 template <int NT>
-__device__ __forceinline__ void fill_bias_lds(const ConvArgs& a, float* s_bias, int tile0) {
-  const int t = threadIdx.x;
-  if (t < 32 * NT) {
-    const int r = t & 15;
-    const int co = (tile0 + (t >> 5)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
-    s_bias[t] = co < a.cout ? a.bias[co] : 0.0f;
-  }
+__device__ __forceinline__ float bias_for_lds(const ConvArgs& a, int tile0) {
+  const int t = threadIdx.x & (32 * NT - 1), r = t & 15;  // (NT is a power of two; threads past 32 * NT repeat a load)
+  const int co = (tile0 + (t >> 5)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
+  const float b = a.bias[min(co, a.cout - 1)];
+  return co < a.cout ? b : 0.0f;
+}
+template <int NT>
+__device__ __forceinline__ void put_bias_lds(float* s_bias, float b) {
+  if (threadIdx.x < 32 * NT) s_bias[threadIdx.x] = b;
+}
+
+// Tables global -> LDS in 16-byte pieces, ALL of a thread's loads in flight before its first store: up to U pieces per
+// thread and trip, from two concatenated sources (piece i < nA: srcA[i] -> putA(i, v); else srcB[i - nA] -> putB(i - nA, v)).
+// Written as `for (i = tid; i < n; i += 256) dst[i] = src[i]` hipcc emits load - s_waitcnt vmcnt(0) - store per trip, and
+// a conditional source (`i < nA ? a[i] : b[i - nA]`) a branch with a wait of its own per piece: the prologue of every block
+// was 5-11 dependent memory round trips (~1 us each under load) on waves that live 17-30 us.  Loads past the end repeat
+// the last piece (no branch around a load: behind one the wait counters are not statically known and every wait is for all).
+template <int U, typename PutA, typename PutB>
+__device__ __forceinline__ void copy_tables16(const float* __restrict__ srcA, int nA, PutA&& putA, const float* __restrict__ srcB, int nB, PutB&& putB) {
+  const float4* a4 = reinterpret_cast<const float4*>(srcA);
+  const float4* b4 = reinterpret_cast<const float4*>(srcB);
+  const int n = nA + nB;
+  auto trip = [&](int i0) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = min(i0 + 256 * u, n - 1);
+      v[u] = *(i < nA ? a4 + i : b4 + (i - nA));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + 256 * u;
+      if (i < nA) putA(i, v[u]);
+      else if (i < n) putB(i - nA, v[u]);
+    }
+  };
+  // (the first trip -- the only one for most tables -- outside the loop: in front of a loop hipcc waits for every load in
+  // flight, the caller's prefetched input windows included, before the loop's own loads are even requested)
+  trip((int)threadIdx.x);
+  for (int i0 = threadIdx.x + 256 * U; i0 < n + (int)threadIdx.x; i0 += 256 * U) trip(i0);  // (block-uniform trip count)
+}
+template <int U>
+__device__ __forceinline__ void copy_table16(float* dst, const float* __restrict__ src, int n4) {
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  auto put = [&](int i, float4 v) { d4[i] = v; };
+  copy_tables16<U>(src, n4, put, src, 0, put);
 }
 template <int CT>
 __device__ __forceinline__ void init_acc(const float* s_bias, floatx16 (&acc)[CT][4], int half) {
@@ -230,13 +271,10 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   float* s_w = s_mem + CT * kBiasLds;
   float* s_red = s_w + CT * ksteps * 64;
   {
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
-    float4* wdst = reinterpret_cast<float4*>(s_w);
-    const int w4 = CT * ksteps * 16;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < w4; i += 256) wdst[i] = wsrc[i];
+    const float bv = bias_for_lds<CT>(a, ct0);
+    copy_table16<8>(s_w, a.w + (size_t)ct0 * ksteps * 64, CT * ksteps * 16);
+    put_bias_lds<CT>(s_bias, bv);
   }
-  fill_bias_lds<CT>(a, s_bias, ct0);
   __syncthreads();
   const int hw = a.oh * a.ow, gpf = hw >> 2;  // pixel groups per frame
   // (32-bit index arithmetic: a tensor below 4 GiB has fewer than 2^28 pixel groups; the 64-bit division this used to be
@@ -332,13 +370,6 @@ __device__ __forceinline__ void put_dw_variants(float4* dst, int n4, int i, floa
   if (q == 1) bot.z = bot.w = 0.f;
   if (q == 2) bot.x = 0.f;
   dst[i] = v, dst[n4 + i] = top, dst[2 * n4 + i] = bot;
-}
-__device__ __forceinline__ void fill_dw_variants(float* s_dw, const float* __restrict__ w2, int cin) {
-  const float4* src = reinterpret_cast<const float4*>(w2);
-  float4* dst = reinterpret_cast<float4*>(s_dw);
-  const int n4 = cin * 3;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < n4; i += 256) put_dw_variants(dst, n4, i, src[i]);
 }
 __device__ __forceinline__ int dw_variant(bool row0ok, bool row2ok) { return !row0ok ? 1 : (!row2ok ? 2 : 0); }
 
@@ -437,21 +468,15 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
 #pragma unroll
   for (int d = 0; d < D; d++) load_window(min(kbeg + d, kend - 1), ring[d]);
   // the first windows are in flight while the weights go to LDS
-  {  // straight 16-byte copies in ONE loop, so that loads of both tables are in flight together
-    // (a.w2 is pre-packed [cin][12], a.w [cout tile][k-step][64])
-    const float4* dsrc = reinterpret_cast<const float4*>(a.w2);
-    const float4* wsrc = reinterpret_cast<const float4*>(a.w + (size_t)ct0 * ksteps * 64);
+  {  // (a.w2 is pre-packed [cin][12], a.w [cout tile][k-step][64]; both tables and the bias in one memory round trip)
     float4* ddst = reinterpret_cast<float4*>(s_dw);
     float4* wdst = reinterpret_cast<float4*>(s_w);
-    const int n4 = a.cin * 3, w4 = CT * ksteps * 16;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4 + w4; i += 256) {
-      const float4 v = i < n4 ? dsrc[i] : wsrc[i - n4];
-      if (i < n4) put_dw_variants(ddst, n4, i, v);
-      else wdst[i - n4] = v;
-    }
+    const int n4 = a.cin * 3;
+    const float bv = bias_for_lds<CT>(a, ct0);
+    copy_tables16<3>(a.w2, n4, [&](int i, float4 v) { put_dw_variants(ddst, n4, i, v); },
+                     a.w + (size_t)ct0 * ksteps * 64, CT * ksteps * 16, [&](int i, float4 v) { wdst[i] = v; });
+    put_bias_lds<CT>(s_bias, bv);
   }
-  fill_bias_lds<CT>(a, s_bias, ct0);
   __syncthreads();
   floatx16 acc[CT][4];
   init_acc<CT>(s_bias, acc, half);
@@ -538,7 +563,7 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   if (tgrp >= a.tiles) return;  // whole block, before any barrier
   const int half = lane >> 5, j32 = lane & 31, ksteps = a.cin >> 1;
   float* s_bias = s_mem;                                            // [CTW][2][16]
-  float* s_dw = s_mem + CTW * kBiasLds;                             // [3][cin][12] (fill_dw_variants)
+  float* s_dw = s_mem + CTW * kBiasLds;                             // [3][cin][12] (put_dw_variants)
   float4* s_t = reinterpret_cast<float4*>(s_dw + 3 * a.cin * 12);   // [PT][3][CH][64]
   const int ohw = a.oh * a.ow, gpf = ohw >> 2, gpr = a.ow >> 2;
   const int total = a.B * gpf;
@@ -552,12 +577,7 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   const int ihw = a.ih * a.iw;
   const int ct = cgrp * CTW + cw;
 
-  // (a barrier of its own for the bias, at the very start where the block's waves are in step anyway: initialising the
-  // accumulators behind the prologue's barrier instead makes hipcc keep two copies of them, 162 + 128 registers)
-  fill_bias_lds<CTW>(a, s_bias, cgrp * CTW);
-  __syncthreads();
-  floatx16 acc[1][4];
-  init_acc<1>(s_bias + cw * kBiasLds, acc, half);
+  floatx16 acc[1][4];  // (initialised behind the prologue's barrier, below)
 
   // (addressing and border handling as in k_dwpw_mfma: byte offsets from a wave-uniform channel
   // base, tap rows over the image border zeroed in the lane's copy of the LDS table)
@@ -648,12 +668,24 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
   // publication of chunk c+2 and land during the MFMA phase of chunk c and the barrier.  A whole iteration more of run-ahead
   // cost 48 (stride 1) / 96 (stride 2: 3 rows x 8 floats per window) registers and bought nothing: k_dwpw_coop<1, 4> 29.7 ->
   // 29.0 us, the stride-2 dual launches 41.7 -> 37.5 us alone at three waves per SIMD instead of two.
+  // Prologue: everything the block needs first -- the windows and the weights of chunk 0, the depthwise table, the bias --
+  // is requested in ONE go in front of the first barrier (it used to be bias, barrier, windows + table in a load - wait -
+  // store loop, barrier, ...: five to six memory round trips one after the other on waves that live ~29 us; a second set of
+  // windows up front as well costs 28-60 registers, a wave per SIMD on the stride-2 instances).
   float wA[CH], wB[CH];
   DwWindow<S> win[NS];
   load_windows(0, win);
   load_weights(0, wA);
-  fill_dw_variants(s_dw, a.w2, a.cin);  // (the first windows are in flight while the table goes to LDS)
+  {
+    const float bv = bias_for_lds<CTW>(a, cgrp * CTW);
+    float4* ddst = reinterpret_cast<float4*>(s_dw);
+    const int n4 = a.cin * 3;
+    auto put = [&](int i, float4 v) { put_dw_variants(ddst, n4, i, v); };
+    copy_tables16<2>(a.w2, n4, put, a.w2, 0, put);
+    put_bias_lds<CTW>(s_bias, bv);
+  }
   __syncthreads();
+  init_acc<1>(s_bias + cw * kBiasLds, acc, half);
   publish(0, win);
   load_windows(1, win);
   publish(1, win);
@@ -830,7 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const ConvArgs& a2 = p3.a[1];
   constexpr int KS1 = C1 / 2, KS2 = 16;
   extern __shared__ float s_mem[];
-  float* s_dw1 = s_mem;                 // [3][C1][12] (fill_dw_variants)
+  float* s_dw1 = s_mem;                 // [3][C1][12] (put_dw_variants)
   float* s_e1 = s_dw1 + 3 * C1 * 12;    // [4][C1][8] (fill_edge_taps)
   float* s_w1 = s_e1 + 4 * C1 * 8;      // [KS1][64]
   float* s_f2 = s_w1 + KS1 * 64;        // [2][16 channel pairs (c, c + 1)][32] second depthwise conv: per tap row k eight floats (wk0' wk0'
@@ -848,21 +880,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (tile >= a2.tiles) return;  // whole block, before the barrier
   {
-    auto copy4 = [&](float* dst, const float* src, int n4) {
-      const float4* s4 = reinterpret_cast<const float4*>(src);
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      for (int i = threadIdx.x; i < n4; i += 256) d4[i] = s4[i];
-    };
-    fill_dw_variants(s_dw1, a1.w2, C1);
-    copy4(s_e1, a1.w2 + C1 * 12, 4 * C1 * 2);                    // edge taps, packed on the host (pack_depthwise_weights)
-    copy4(s_w1, a1.w, KS1 * 16);
-    copy4(s_f2, a2.w2 + 32 * 12 + 4 * 32 * 8, 2 * 16 * 8);     // fold records of the second block's 32 channels, likewise
-    copy4(s_w2, a2.w, CT2 * KS2 * 16);
-    if (threadIdx.x < 32 * (1 + CT2)) {  // accumulator row r of half h holds channel (r & 3) + 8 * (r >> 2) + 4 * h of its tile
-      const int t = threadIdx.x, r = t & 15, co = (t >> 5) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((t >> 4) & 1);
-      if (t < 32) s_b1[t] = a1.bias[co];
-      else s_b2[t - 32] = co - 32 < a2.cout ? a2.bias[co - 32] : 0.0f;
+    // The five tables and the two biases in ONE memory round trip: every thread requests its 16-byte pieces of the
+    // concatenation (depthwise records | edge taps | first 1x1 | fold records | second 1x1 -- sizes are compile-time) and its
+    // bias value, then stores them.  (As five copy loops one after the other, each `load - wait - store` per trip, a block's
+    // prologue was a dozen dependent round trips.)  Edge taps and fold records come packed by pack_depthwise_weights.
+    constexpr int nD = C1 * 3, nE = 4 * C1 * 2, nW1 = KS1 * 16, nF = 2 * 16 * 8, nW2 = CT2 * KS2 * 16;
+    constexpr int o1 = nD, o2 = o1 + nE, o3 = o2 + nW1, o4 = o3 + nF, nAll = o4 + nW2, U = (nAll + 255) / 256;
+    const float4* gD = reinterpret_cast<const float4*>(a1.w2);
+    const float4* gE = reinterpret_cast<const float4*>(a1.w2 + C1 * 12);
+    const float4* gW1 = reinterpret_cast<const float4*>(a1.w);
+    const float4* gF = reinterpret_cast<const float4*>(a2.w2 + 32 * 12 + 4 * 32 * 8);
+    const float4* gW2 = reinterpret_cast<const float4*>(a2.w);
+    const int t = threadIdx.x;
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = min(t + 256 * u, nAll - 1);
+      v[u] = *(i < o1 ? gD + i : i < o2 ? gE + (i - o1) : i < o3 ? gW1 + (i - o2) : i < o4 ? gF + (i - o3) : gW2 + (i - o4));
     }
+    // accumulator row r of half h holds channel (r & 3) + 8 * (r >> 2) + 4 * h of its tile
+    const int tb = t & (32 * (1 + CT2) - 1 < 64 ? 63 : 127), r = tb & 15, co = (tb >> 5) * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((tb >> 4) & 1);
+    const float bias1 = a1.bias[co & 31];
+    const float bias2 = a2.bias[min(max(co - 32, 0), a2.cout - 1)];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = t + 256 * u;
+      if (i < o1) put_dw_variants(reinterpret_cast<float4*>(s_dw1), nD, i, v[u]);
+      else if (i < o2) reinterpret_cast<float4*>(s_e1)[i - o1] = v[u];
+      else if (i < o3) reinterpret_cast<float4*>(s_w1)[i - o2] = v[u];
+      else if (i < o4) reinterpret_cast<float4*>(s_f2)[i - o3] = v[u];
+      else if (i < nAll) reinterpret_cast<float4*>(s_w2)[i - o4] = v[u];
+    }
+    if (t < 32) s_b1[t] = bias1;
+    else if (t < 32 * (1 + CT2)) s_b2[t - 32] = co - 32 < a2.cout ? bias2 : 0.0f;
   }
   __syncthreads();
   const int half = lane >> 5, j32 = lane & 31;
@@ -1269,11 +1319,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   const int cin4 = (a.cin + 3) >> 2;
   const bool w_in_lds = a.dbg != 0;
   if (w_in_lds) {
-    const float4* src = reinterpret_cast<const float4*>(a.w);
-    float4* dst = reinterpret_cast<float4*>(s_w);
-    const int n4 = cin4 * 9 * 16;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    copy_table16<4>(s_w, a.w, cin4 * 9 * 16);
     __syncthreads();
   }
   // (The k-loop of these convs is two to four channel chunks long: what surrounds it counts as much.  32-bit index
@@ -1577,12 +1623,7 @@ __global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
   const int ohw = fin.oh * fin.ow, gpf = ohw >> 2, gpr = fin.ow >> 2;
   const int total = fin.B * gpf;
   if ((long)bx * 4 * kTailNG - kTailHL >= (long)total) return;  // whole block, before the barrier
-  {
-    const float4* src = reinterpret_cast<const float4*>(fin.w);
-    float4* dst = reinterpret_cast<float4*>(s_wf);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < kTailChunks * 4 * 16; i += 256) dst[i] = src[i];
-  }
+  copy_table16<(kTailChunks * 4 * 16 + 255) / 256>(s_wf, fin.w, kTailChunks * 4 * 16);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
@@ -1751,10 +1792,8 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   float* s_x = s_lut + 1024;         // per wave: exchange buffer [4 channels][16 groups][8 columns] of one input row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
-  for (int i = threadIdx.x; i < 9 * 64; i += 256) s_w[i] = a.w[i];
-  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = sa.lut[i];
-  s_lut[768 + threadIdx.x] = 0.0f;
-  __syncthreads();
+  // (the tables are copied to LDS further down, BEHIND the wave's descriptor reads and its first two rows' sample loads: three
+  // dependent memory round trips in a row -- tables, barrier, descriptor, samples -- were a quarter of a wave's life)
   // Row rolling: a wave owns a band of a.band output rows of its 14 column groups.  Output row oy reads input rows
   // 2oy-1 .. 2oy+1, so consecutive output rows share one input row: its 8 upsampled, colour-converted, normalised
   // pixels stay in registers (2 * band + 1 input rows converted per band instead of 3 * band), and the tables above
@@ -1783,13 +1822,21 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const int c_oy0 = __shfl(oy0, cg);
   const int c_ix = __shfl(ix0, cg) + 2 * cp;  // the lane's two input columns: c_ix, c_ix + 1
   const int cc = c_ix >> 1;                    // ... and its chroma column
+  // (every descriptor field the lane needs is loaded UNCONDITIONALLY into a local first -- c_frame is a valid index for every
+  // lane -- and selected afterwards: written as `ok && d.width == ...` / `ok ? d.wblk[0] : 0` each field was a load, a wait
+  // and a branch of its own, eleven dependent memory round trips in every wave's prologue)
   const JpegFrameDesc& dcv = sa.descs[c_frame];
-  const bool c_frame_ok = c_inrange && dcv.width == a.iw && dcv.height == a.ih;  // failed frames: zero input
+  const int d_width = dcv.width, d_height = dcv.height, d_v0 = dcv.v[0], d_wblk0 = dcv.wblk[0], d_wblk1 = dcv.wblk[1];
+  const int c_dw = dcv.dw[1], c_dh = dcv.dh[1];
+  const uint32_t d_off0 = dcv.plane_off[0], d_off1 = dcv.plane_off[1], d_off2 = dcv.plane_off[2];
+  const bool c_frame_ok = c_inrange & (d_width == a.iw) & (d_height == a.ih);  // failed frames: zero input
   const uint8_t* cfp = sa.planes + (size_t)c_frame * sa.plane_stride;
-  const int c_ypitch = dcv.wblk[0] * 8, c_cpitch = dcv.wblk[1] * 8, c_dw = dcv.dw[1], c_dh = dcv.dh[1];
-  const uint8_t* c_y = cfp + dcv.plane_off[0] + c_ix;
-  const uint8_t* c_cb = cfp + dcv.plane_off[1] + cc;
-  const uint8_t* c_cr = cfp + dcv.plane_off[2] + cc;
+  // (a failed frame's lanes load the first bytes of the plane buffer -- its descriptor may hold anything -- and convert_row
+  // turns whatever they read into zeros: the loads themselves stay unconditional, see load_samples)
+  const int c_ypitch = c_frame_ok ? d_wblk0 * 8 : 0, c_cpitch = c_frame_ok ? d_wblk1 * 8 : 0;
+  const uint8_t* c_y = c_frame_ok ? cfp + d_off0 + c_ix : sa.planes;
+  const uint8_t* c_cb = c_frame_ok ? cfp + d_off1 + cc : sa.planes;
+  const uint8_t* c_cr = c_frame_ok ? cfp + d_off2 + cc : sa.planes;
   // neighbour chroma columns come from the adjacent lanes; at the image's edges jdsample.c repeats the column itself.
   // (Lane 0's left and lane 63's right neighbour lie outside the wave: they only enter pixels of the two halo groups
   // that nobody reads -- group 0 provides its LAST column, group 15 nothing.)
@@ -1797,7 +1844,7 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   // h2v1 (4:2:2: chroma at full height) through the h2v2 arithmetic: near row = far row = the pixel's own chroma row makes
   // the column sums 4c, and jdsample.c's h2v1 outputs (3c + l + 1) >> 2 | (3c + r + 2) >> 2 are (3 * 4c + 4l + 4) >> 4 |
   // (3 * 4c + 4r + 8) >> 4: only the two rounding terms differ from h2v2's 8 | 7.
-  const bool c_v2 = dcv.v[0] == 2;
+  const bool c_v2 = d_v0 == 2;
   const int bias_l = c_v2 ? 8 : 4, bias_r = c_v2 ? 7 : 8;
   // (Round 5 tried [channel][columns 0-3 | 4-7][group][4], which makes the MFMA lanes' 16-byte reads conflict-free: the
   // kernel's SQ_LDS_BANK_CONFLICT share went from 106 % to 133 % of its LDS-active cycles and its time did not move, 60.4 ->
@@ -1816,18 +1863,26 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
 
   // input row 2 * oy0 + k of the wave's groups: v[0..7] = columns ix0 .. ix0+7 of the lane's channel, v[8] = column ix0 - 1
   // (0 at the row start); a row outside the image is zero padding
-  auto convert_row = [&](int k, float (&v)[9]) {
-    const int iy = 2 * c_oy0 + k;
-    const bool ok = c_frame_ok && iy >= 0 && iy < a.ih;
-    const int yc = min(max(iy, 0), a.ih - 1);
+  // (the five sample loads of a row are issued ONE ROW AHEAD of their conversion -- load_samples / convert_row -- into a
+  // register ping-pong: issued where they are used, every row of a wave's band waited a memory round trip, ~1.5 us x 9 rows of
+  // a 17 us wave for 3.3 us of issue work)
+  struct Samples {
+    uint32_t yy, cbn, cbf, crn, crf;
+  };
+  auto load_samples = [&](int k, Samples& sm) {
+    const int yc = min(max(2 * c_oy0 + k, 0), a.ih - 1);
     const int cy = c_v2 ? yc >> 1 : yc;  // h2v2 fancy upsampling: near / far row; h2v1: both the pixel's own
     const int ny = c_v2 ? max(0, min(c_dh - 1, (yc & 1) ? cy + 1 : cy - 1)) : cy;
-    uint32_t yy = 0, cbn = 0, cbf = 0, crn = 0, crf = 0;
-    if (c_frame_ok) {
-      const uint32_t ro = (uint32_t)__mul24(cy, c_cpitch), fo = (uint32_t)__mul24(ny, c_cpitch);
-      yy = *reinterpret_cast<const uint16_t*>(c_y + (uint32_t)__mul24(yc, c_ypitch));
-      cbn = c_cb[ro], cbf = c_cb[fo], crn = c_cr[ro], crf = c_cr[fo];
-    }
+    // (no branch around the loads: behind one the compiler cannot count what is in flight and waits for ALL of it -- the
+    // row just requested included -- in front of the previous row's conversion)
+    const uint32_t ro = (uint32_t)__mul24(cy, c_cpitch), fo = (uint32_t)__mul24(ny, c_cpitch);
+    sm.yy = *reinterpret_cast<const uint16_t*>(c_y + (uint32_t)__mul24(yc, c_ypitch));
+    sm.cbn = c_cb[ro], sm.cbf = c_cb[fo], sm.crn = c_cr[ro], sm.crf = c_cr[fo];
+  };
+  auto convert_row = [&](int k, const Samples& sm, float (&v)[9]) {
+    const int iy = 2 * c_oy0 + k;
+    const bool ok = c_frame_ok && iy >= 0 && iy < a.ih;
+    const uint32_t yy = sm.yy, cbn = sm.cbn, cbf = sm.cbf, crn = sm.crn, crf = sm.crf;
     const int scb = mad24(3, (int)cbn, (int)cbf), scr = mad24(3, (int)crn, (int)crf);  // column sums 3 * near + far
     const int pcb = dpp_prev(scb), ncb = dpp_next(scb), pcr = dpp_prev(scr), ncr = dpp_next(scr);
     const int lcb = has_prev ? pcb : scb, rcb = has_next ? ncb : scb, lcr = has_prev ? pcr : scr, rcr = has_next ? ncr : scr;
@@ -1865,7 +1920,10 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   };
   float bias[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) bias[r] = 4 * q + r < a.cout ? a.bias[4 * q + r] : 0.0f;
+  for (int r = 0; r < 4; r++) {  // (unconditional loads from a clamped index: no branch, no wait per element)
+    const float b = a.bias[min(4 * q + r, a.cout - 1)];
+    bias[r] = 4 * q + r < a.cout ? b : 0.0f;
+  }
 
   // stores: 32-bit byte offset of (frame, channel 4q, row oy0, column ox) from the tensor base, a channel step per store;
   // ReLU as the integer maximum with 0 (relu_acc), or with INT_MIN = the identity
@@ -1876,7 +1934,21 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
   const int lowest = a.relu ? 0 : (int)0x80000000;
 
   float top[9], mid[9], bot[9];
-  convert_row(-1, top);
+  Samples even, odd;  // the samples of the next even / odd input row of the band
+  load_samples(-1, odd);
+  load_samples(0, even);
+  {  // 144 + 192 16-byte pieces, at most one of each per thread, both loads in flight together (as `for (i = tid; ...) s[i] =
+    // g[i]` loops these were six load - wait - store round trips one after the other)
+    const int tid = threadIdx.x;
+    const float4 wv = reinterpret_cast<const float4*>(a.w)[min(tid, 143)];
+    const float4 lv = reinterpret_cast<const float4*>(sa.lut)[min(tid, 191)];
+    if (tid < 144) reinterpret_cast<float4*>(s_w)[tid] = wv;
+    if (tid < 192) reinterpret_cast<float4*>(s_lut)[tid] = lv;
+    s_lut[768 + tid] = 0.0f;
+  }
+  __syncthreads();
+  convert_row(-1, odd, top);
+  load_samples(1, odd);
 #pragma unroll 1
   for (int i = 0; i < R; i++) {
 #pragma unroll
@@ -1884,9 +1956,13 @@ __global__ __launch_bounds__(256) void k_stem_planes_mfma(StemArgs sa) {
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[j][r] = bias[r];
     mac_row(0, top);
-    convert_row(2 * i, mid);
+    convert_row(2 * i, even, mid);
+    load_samples(2 * i + 2, even);  // (past the band's last row: a clamped, valid address, never converted)
+    __builtin_amdgcn_sched_barrier(0);  // (the odd row's samples are not touched before here: hoisted, their first use waits)
     mac_row(1, mid);
-    convert_row(2 * i + 1, bot);
+    convert_row(2 * i + 1, odd, bot);
+    load_samples(2 * i + 3, odd);
+    __builtin_amdgcn_sched_barrier(0);
     mac_row(2, bot);
     if (live) {
       uint32_t o = out_off + 4u * (uint32_t)(i * a.ow);
@@ -1986,7 +2062,8 @@ bool conv3x3_rows_supported(const ConvArgs& a) {
 
 bool stem_planes_supported(const ConvArgs& a) {
   return a.k == 3 && a.stride == 2 && a.dil == 1 && a.pad == 1 && a.cin == 3 && a.cout <= 16 && !a.depthwise && !a.res &&
-         a.iw == 2 * a.ow && a.ih == 2 * a.oh && (a.ow & 3) == 0 && (a.iw & 7) == 0;
+         a.iw == 2 * a.ow && a.ih == 2 * a.oh && (a.ow & 3) == 0 && (a.iw & 7) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;  // (the kernel copies the packed weights in 16-byte pieces)
 }
 
 void launch_stem_planes_mfma(const StemArgs& sa0, hipStream_t s) {
