@@ -336,7 +336,8 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
 }
 template <int CT, int D, int SK>
 __global__ __launch_bounds__(256) void k_pw_mfma(ConvArgs3 p3) {
-  pw_mfma_body<CT, D, SK>(p3.a[blockIdx.y], (int)blockIdx.x);
+  const ConvArgs a = p3.a[blockIdx.y];  // (a copy: see k_dwpw_mfma)
+  pw_mfma_body<CT, D, SK>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,7 +527,8 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
 }
 template <int CT, int S, int D, int SK>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
-  dwpw_mfma_body<CT, S, D, SK>(p3.a[blockIdx.y], (int)blockIdx.x);
+  const ConvArgs a = p3.a[blockIdx.y];  // (a copy: every field the body reads is requested in one go at the top)
+  dwpw_mfma_body<CT, S, D, SK>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,7 +713,8 @@ __device__ __forceinline__ void dwpw_coop_body(const ConvArgs& a, int bx) {
 }
 template <int S, int CTW>
 __global__ __launch_bounds__(256) void k_dwpw_coop(ConvArgs3 p3) {
-  dwpw_coop_body<S, CTW>(p3.a[blockIdx.y], (int)blockIdx.x);
+  const ConvArgs a = p3.a[blockIdx.y];  // (a copy: see k_dwpw_mfma)
+  dwpw_coop_body<S, CTW>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,9 +733,11 @@ __global__ __launch_bounds__(256) void k_dual_dwpw_coop(DualArgs q) {  // A: k_d
   const int bid = (int)blockIdx.x, na = q.ax * q.ay;
   if (bid < na) {
     const int y = bid / q.ax;
-    dwpw_mfma_body<1, SA, 2, SKA>(q.a.a[y], bid - y * q.ax);
+    const ConvArgs a = q.a.a[y];  // (copies: see k_dwpw_mfma)
+    dwpw_mfma_body<1, SA, 2, SKA>(a, bid - y * q.ax);
   } else {
-    dwpw_coop_body<SB, 4>(q.b.a[0], bid - na);
+    const ConvArgs b = q.b.a[0];
+    dwpw_coop_body<SB, 4>(b, bid - na);
   }
 }
 template <int SA, int SKA, int SKB>
@@ -740,9 +745,11 @@ __global__ __launch_bounds__(256) void k_dual_dwpw_pw(DualArgs q) {  // A as abo
   const int bid = (int)blockIdx.x, na = q.ax * q.ay;
   if (bid < na) {
     const int y = bid / q.ax;
-    dwpw_mfma_body<1, SA, 2, SKA>(q.a.a[y], bid - y * q.ax);
+    const ConvArgs a = q.a.a[y];  // (copies: see k_dwpw_mfma)
+    dwpw_mfma_body<1, SA, 2, SKA>(a, bid - y * q.ax);
   } else {
-    pw_mfma_body<1, 4, SKB>(q.b.a[0], bid - na);
+    const ConvArgs b = q.b.a[0];
+    pw_mfma_body<1, 4, SKB>(b, bid - na);
   }
 }
 
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // a.w: packed [cin][3][64] (lane l of slot s: W[l&15][ci][4s + (l>>4)], 0 for taps >= 9 / cout pad).
 template <int PG, int U, int SK = 1>
 __global__ __launch_bounds__(256) void k_conv3x3_mfma(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];
+  const ConvArgs a = p3.a[blockIdx.y];  // (a copy: see k_dwpw_mfma)
   __shared__ float s_red[SK > 1 ? 3 * 4 * PG * 64 : 1];  // split-K: partial tiles of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, quad = lane >> 4;
@@ -1318,10 +1325,6 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   const int q = lane >> 4, j16 = lane & 15;
   const int cin4 = (a.cin + 3) >> 2;
   const bool w_in_lds = a.dbg != 0;
-  if (w_in_lds) {
-    copy_table16<4>(s_w, a.w, cin4 * 9 * 16);
-    __syncthreads();
-  }
   // (The k-loop of these convs is two to four channel chunks long: what surrounds it counts as much.  32-bit index
   // arithmetic -- a tensor below 4 GiB has fewer than 2^28 pixel groups, and the 64-bit division this used to be is a
   // ~100-instruction routine of quarter-rate multiplies; the lane's four bias values as one 16-byte load; the store
@@ -1339,13 +1342,16 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
 
   floatx4 acc[4];
   {
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (unconditional loads from clamped indices, zeroed by select: a load in a lane-dependent branch is a wait of its own)
+    float4 b4;
     if ((cout & 3) == 0) {  // (wave-uniform) the lane's channels 4q .. 4q+3 exist together or not at all
-      if (4 * q < cout) b4 = *reinterpret_cast<const float4*>(a.bias + 4 * q);
+      b4 = *reinterpret_cast<const float4*>(a.bias + min(4 * q, cout - 4));
+      if (4 * q >= cout) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       const float* bias = a.bias;
-      b4.x = 4 * q + 0 < cout ? bias[4 * q + 0] : 0.0f, b4.y = 4 * q + 1 < cout ? bias[4 * q + 1] : 0.0f;
-      b4.z = 4 * q + 2 < cout ? bias[4 * q + 2] : 0.0f, b4.w = 4 * q + 3 < cout ? bias[4 * q + 3] : 0.0f;
+      const float b0 = bias[min(4 * q + 0, cout - 1)], b1 = bias[min(4 * q + 1, cout - 1)], b2 = bias[min(4 * q + 2, cout - 1)], b3 = bias[min(4 * q + 3, cout - 1)];
+      b4.x = 4 * q + 0 < cout ? b0 : 0.0f, b4.y = 4 * q + 1 < cout ? b1 : 0.0f;
+      b4.z = 4 * q + 2 < cout ? b2 : 0.0f, b4.w = 4 * q + 3 < cout ? b3 : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[j][0] = b4.x, acc[j][1] = b4.y, acc[j][2] = b4.z, acc[j][3] = b4.w;
@@ -1415,9 +1421,16 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   // other half of a register ping-pong -- the loop runs two chunks per iteration so that no copy is needed, and the
   // sched_barrier keeps the requests where they are written (round 5: with `cur = nxt` copies at the loop's end hipcc sank the
   // loads down to the copies and waited for them there, one exposed memory round trip per 36 MFMAs).
+  // The first chunk's rows are requested in front of the weight table's copy and its barrier (the block's tables, bias and
+  // first rows in one memory round trip instead of three).
+  Rows rows[2];
+  load_rows(0, rows[0]);
+  if (w_in_lds) {
+    copy_table16<4>(s_w, a.w, cin4 * 9 * 16);
+    __syncthreads();
+  }
   auto run = [&](auto in_lds) {
     constexpr bool kLds = decltype(in_lds)::value;
-    Rows rows[2];
     float wts[2][9];
     auto load_wts = [&](int kc, float (&w)[9]) {
       if (kLds) return;
@@ -1455,7 +1468,6 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
         }
       }
     };
-    load_rows(0, rows[0]);
     load_wts(0, wts[0]);
     for (int kc = 0; kc < cin4; kc += 2) {
       if (kc + 1 < cin4) load_rows(kc + 1, rows[1]), load_wts(kc + 1, wts[1]);
@@ -1493,7 +1505,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
 // a register pick or one shuffle per tap, where the run-time form pays three selects and an LDS-pipe permute per tap).
 template <int S, int DIL>
 __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
-  const ConvArgs& a = p3.a[blockIdx.y];
+  const ConvArgs a = p3.a[blockIdx.y];  // (a copy: see k_dwpw_mfma)
   if (DIL != 0) {
     conv3x3_rows_body<S, DIL>(a);
     return;
@@ -1612,8 +1624,9 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 }
 
 // (capped at 168 registers for three waves per SIMD, round 5: 150 registers, no spill, 69.9 -> 68.9 us alone, frame rate
-// unchanged -- left to the compiler)
-__global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
+// unchanged.  Two waves per SIMD -- 256 registers -- stated: the 1x1's table is held in registers across the first dilated
+// conv, and left to itself hipcc aimed at three waves and spilled 32 dwords for it.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rfb_tail(RfbTailArgs t) {
   const ConvArgs& fin = t.fin;
   extern __shared__ float s_tail[];
   // (LDS holds the 1x1's weights only, 28 KB: with the dilated convs' 27 KB beside them a CU took two blocks, not the three
@@ -1623,8 +1636,18 @@ __global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
   const int ohw = fin.oh * fin.ow, gpf = ohw >> 2, gpr = fin.ow >> 2;
   const int total = fin.B * gpf;
   if ((long)bx * 4 * kTailNG - kTailHL >= (long)total) return;  // whole block, before the barrier
-  copy_table16<(kTailChunks * 4 * 16 + 255) / 256>(s_wf, fin.w, kTailChunks * 4 * 16);
-  __syncthreads();
+  // The 1x1's weight table is REQUESTED here and stored to LDS behind the first dilated conv, in front of the barrier its
+  // first reader (fold_branch) needs: the table's round trip runs beside that conv's loads and MFMAs instead of in front of
+  // everything (28 registers held meanwhile; the kernel has two waves per SIMD either way).
+  constexpr int kTab4 = kTailChunks * 4 * 16, kTabU = (kTab4 + 255) / 256;
+  static_assert(kTabU <= 8, "the table's registers");
+  typedef float floatx32 __attribute__((ext_vector_type(32)));  // (a vector, not an array: an array of float4 went to scratch)
+  floatx32 tab;
+#pragma unroll
+  for (int u = 0; u < kTabU; u++) {
+    const float4 v = reinterpret_cast<const float4*>(fin.w)[min((int)threadIdx.x + 256 * u, kTab4 - 1)];
+    tab[4 * u] = v.x, tab[4 * u + 1] = v.y, tab[4 * u + 2] = v.z, tab[4 * u + 3] = v.w;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
   const int g = (bx * 4 + wave) * kTailNG + j16 - kTailHL;
@@ -1660,6 +1683,11 @@ __global__ __launch_bounds__(256) void k_rfb_tail(RfbTailArgs t) {
   {
     floatx4 br[4];
     rfb_dilated<2>(t.a3.a[0], t.a3.a[0].w, lane, frame32, oy, ox, br);
+#pragma unroll
+    for (int u = 0; u < kTabU; u++)
+      if ((int)threadIdx.x + 256 * u < kTab4)
+        reinterpret_cast<float4*>(s_wf)[threadIdx.x + 256 * u] = make_float4(tab[4 * u], tab[4 * u + 1], tab[4 * u + 2], tab[4 * u + 3]);
+    __syncthreads();
     fold_branch(0, br);
   }
   {
