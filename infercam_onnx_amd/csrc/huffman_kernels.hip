@@ -245,14 +245,21 @@ __device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, 
 }
 
 // exclusive scan of one int per thread over the 1024-thread block; returns the block total in *total
+// inclusive scan over the wave on the vector ALU: four row shifts (a DPP row is 16 lanes; lanes without a source add 0), then
+// lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 -- six instructions with the shift folded into the add
+// (as __shfl_up steps: six ds_bpermute round trips through the LDS pipe plus a compare and a select each)
+__device__ __forceinline__ int wave_inscan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
+}
 __device__ __forceinline__ int block_exscan(int v, int* s_wave /*16*/, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += u;
-  }
+  const int inc = wave_inscan(v);
   __syncthreads();  // s_wave reuse
   if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
@@ -265,6 +272,29 @@ __device__ __forceinline__ int block_exscan(int v, int* s_wave /*16*/, int* tota
   }
   *total = tot;
   return base + inc - v;
+}
+
+// three scans at once (k_dc_prefix: one per component): one pair of barriers instead of three
+__device__ __forceinline__ void block_exscan3(const int (&v)[3], int (*s_wave)[kSyncThreads / 64] /*[3][16]*/, int (&pre)[3], int (&total)[3]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) inc[c] = wave_inscan(v[c]);
+  __syncthreads();  // s_wave reuse
+  if (lane == 63) s_wave[0][wave] = inc[0], s_wave[1][wave] = inc[1], s_wave[2][wave] = inc[2];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSyncThreads / 64; w++) {
+      const int x = s_wave[c][w];
+      if (w < wave) base += x;
+      tot += x;
+    }
+    total[c] = tot;
+    pre[c] = base + inc[c] - v[c];
+  }
 }
 
 constexpr int kSyncLaneThreads = 256;  // seed / extend / write: one lane per (subsequence, hypothesis)
@@ -868,7 +898,7 @@ __global__ __launch_bounds__(kSyncLaneThreads) void k_huff_write(const HuffScan*
 __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __restrict__ scans,
                                                             const JpegFrameDesc* __restrict__ descs,
                                                             int16_t* __restrict__ dc, size_t dc_stride) {
-  __shared__ int s_wave[kSyncThreads / 64];
+  __shared__ int s_wave[3][kSyncThreads / 64];
   __shared__ int s_pre[3][kSyncThreads];  // exclusive prefix of this pass (without the carry)
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (scans[frame].nseg == 0) return;
@@ -878,22 +908,47 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
   const int ri = d.restart_interval > 0 ? d.restart_interval : total;
   int carry[3] = {0, 0, 0};      // sum over all MCUs in front of this pass
   int seg_carry[3] = {0, 0, 0};  // ... in front of the restart interval that is open at the start of the pass
+  // Sampling factors <= 2 (4:4:4, 4:2:2, 4:2:0, 4:4:0 -- all the GPU path's upsamplers cover): the up to 3 x 2 x 2 blocks of
+  // the thread's MCU are requested TOGETHER, from clamped addresses with a predicate per block, and kept in registers for the
+  // second phase.  (As loops over run-time h x v every block was a load, a wait and a branch of its own, twice: a dozen
+  // dependent memory round trips per pass, 13.6 us for a kernel that moves 14 KB per frame.)
+  int hh[3], vv[3], wb[3], co[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const bool have = c < d.ncomp;
+    hh[c] = have ? d.h[c] : 0, vv[c] = have ? d.v[c] : 0, wb[c] = d.wblk[c], co[c] = (int)(d.coef_off[c] >> 6);
+  }
+  const bool small = max(max(hh[0], hh[1]), hh[2]) <= 2 && max(max(vv[0], vv[1]), vv[2]) <= 2;
   for (int base = 0; base < total; base += kSyncThreads) {
     const int mcu = base + tid;
     const bool valid = mcu < total;
     const int my = mcu / d.mcux, mx = mcu - my * d.mcux;
     int sums[3] = {0, 0, 0};
-    if (valid)
+    int dcv[3][2][2];
+    if (small) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int by = 0; by < 2; by++)
+#pragma unroll
+          for (int bx = 0; bx < 2; bx++) {
+            const bool have = valid && by < vv[c] && bx < hh[c];
+            const int idx = have ? co[c] + (my * vv[c] + by) * wb[c] + mx * hh[c] + bx : 0;
+            const int v = fdc[idx];
+            dcv[c][by][bx] = have ? v : 0;
+          }
+#pragma unroll
+      for (int c = 0; c < 3; c++) sums[c] = dcv[c][0][0] + dcv[c][0][1] + dcv[c][1][0] + dcv[c][1][1];
+    } else if (valid) {
       for (int c = 0; c < d.ncomp; c++)
         for (int by = 0; by < d.v[c]; by++)
           for (int bx = 0; bx < d.h[c]; bx++)
             sums[c] += fdc[(d.coef_off[c] >> 6) + (size_t)(my * d.v[c] + by) * d.wblk[c] + mx * d.h[c] + bx];
-    int pre[3], tot[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      pre[c] = block_exscan(sums[c], s_wave, &tot[c]);
-      s_pre[c][tid] = pre[c];
     }
+    int pre[3], tot[3];
+    block_exscan3(sums, s_wave, pre, tot);
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_pre[c][tid] = pre[c];
     __syncthreads();
     // predictor = (sum in front of this MCU) - (sum in front of its restart interval)
     const int seg_start = (mcu / ri) * ri;
@@ -903,7 +958,17 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
       const int before_seg = seg_start >= base ? carry[c] + s_pre[c][seg_start - base] : seg_carry[c];
       pred[c] = carry[c] + pre[c] - before_seg;
     }
-    if (valid)
+    if (small) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int by = 0; by < 2; by++)
+#pragma unroll
+          for (int bx = 0; bx < 2; bx++) {
+            pred[c] += dcv[c][by][bx];  // (0 for a block that does not exist)
+            if (valid && by < vv[c] && bx < hh[c]) fdc[co[c] + (my * vv[c] + by) * wb[c] + mx * hh[c] + bx] = (int16_t)pred[c];
+          }
+    } else if (valid) {
       for (int c = 0; c < d.ncomp; c++)
         for (int by = 0; by < d.v[c]; by++)
           for (int bx = 0; bx < d.h[c]; bx++) {
@@ -911,6 +976,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_dc_prefix(const HuffScan* __re
             pred[c] += *p;
             *p = (int16_t)pred[c];
           }
+    }
     // the interval open at the start of the next pass
     const int nbase = base + kSyncThreads;
     const int nstart = (nbase / ri) * ri;
