@@ -1623,9 +1623,9 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
   }
 }
 
-// (capped at 168 registers for three waves per SIMD, round 5: 150 registers, no spill, 69.9 -> 68.9 us alone, frame rate
-// unchanged.  Two waves per SIMD -- 256 registers -- stated: the 1x1's table is held in registers across the first dilated
-// conv, and left to itself hipcc aimed at three waves and spilled 32 dwords for it.)
+// (Register budget: with `amdgpu_waves_per_eu(2, 2)` -- "plan for two waves per SIMD, up to 256 registers" -- hipcc comes out
+// at 159 unified registers, which the hardware still runs three waves of; left to itself it splits them 96 + 84 accumulation
+// registers = 180, two waves.  Capped at 168 in the earlier form of the kernel: 69.9 -> 68.9 us alone.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rfb_tail(RfbTailArgs t) {
   const ConvArgs& fin = t.fin;
   extern __shared__ float s_tail[];
