@@ -305,19 +305,24 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
   const float* __restrict__ in2 = a.in2;
   const uint32_t in2_off = in2 ? (frame32 * (uint32_t)a.in2_ctotal + (uint32_t)half) * (uint32_t)hw + (uint32_t)pix : 0u;
   const int ksplit = in2 ? a.ksplit : 0x7FFFFFFF;
+  // (ONE load from a selected address: as two loads in the arms of a branch every wait of the k-loop was for all loads in
+  // flight -- vmcnt(0) per k-step, the D-deep queue waited for its newest entry)
   auto load_b = [&](int ks) -> float4 {
-    if (ks >= ksplit) return *reinterpret_cast<const float4*>(in2 + (in2_off + (uint32_t)(ks - ksplit) * in_step));
-    return *reinterpret_cast<const float4*>(in + (in_off + (uint32_t)ks * in_step));
+    const float* p = ks >= ksplit ? in2 + (in2_off + (uint32_t)(ks - ksplit) * in_step) : in + (in_off + (uint32_t)ks * in_step);
+    return *reinterpret_cast<const float4*>(p);
   };
   float4 bq[D];
 #pragma unroll
-  for (int d = 0; d < D; d++) bq[d] = load_b(min(kbeg + d, kend - 1));
+  for (int d = 0; d < D; d++) {
+    bq[d] = load_b(min(kbeg + d, kend - 1));
+    // (in THIS order: hipcc requested them last slot first, so entering the loop its first wait was for the newest load --
+    // and a loop's waits are those of its worst entry: vmcnt(0) at the top of every iteration)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int ks = kbeg; ks < kend; ks += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const float4 b = bq[d];
-      const int kn = min(ks + D + d, kend - 1);  // refill the slot (tail: harmless re-read)
-      bq[d] = load_b(kn);
 #pragma unroll
       for (int ct = 0; ct < CT; ct++) {
         const float w = s_w[(ct * ksteps + ks + d) * 64 + lane];
@@ -326,6 +331,13 @@ __device__ __forceinline__ void pw_mfma_body(const ConvArgs& a, int bx) {
         acc[ct][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.z, acc[ct][2], 0, 0, 0);
         acc[ct][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b.w, acc[ct][3], 0, 0, 0);
       }
+      // Refill the slot BEHIND the MFMAs that read it (the load lands in the same registers: requested in front of them it
+      // needed other registers and a copy back at the loop's end, which waited for the newest load), and pinned: to save
+      // registers hipcc kept the D ADDRESSES ahead instead and issued every load one k-step before its use -- vmcnt(0)
+      // per k-step, a queue of depth one.
+      const int kn = min(ks + D + d, kend - 1);  // (tail: harmless re-read)
+      bq[d] = load_b(kn);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (SK > 1) {
@@ -1147,6 +1159,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (ks + 2 < KS1) load_ring(y1, ks + 2);
         else if (!last) load_ring(y1 + 1, ks + 2 - KS1);
       }
+      // (memory instructions stay on their side of this line, everything else may cross: in the unrolled loop hipcc sank
+      // the requests of an even k-step down to those of the odd one behind it -- six loads in a burst, the first three
+      // waited for at once: a queue of depth zero for every other k-step)
+      __builtin_amdgcn_sched_barrier(0);
       const float w = s_w1[ks * 64 + lane];
       float tnext[4];
       if (ks + 1 < KS1) taps_of(ks + 1, wl, el, er, tnext);
@@ -1416,7 +1432,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
   // (4 selects; the neighbours' halo values come out of their own zeroed segments -- same output row, same tap row --
   // or are masked by the column tests) instead of each of the 12 operands made from it, and the column tests are compiled
   // in only where they can fail: left of pixel j < DIL, right of pixel j > 3 - DIL.  54 selects per chunk became 18.
-  auto zero_if = [](bool keep, const float4& m) { return keep ? m : make_float4(0.f, 0.f, 0.f, 0.f); };
+  // (as an integer AND with an all-ones / all-zero mask: `keep ? m : 0` became a BRANCH around four moves, with a wait for
+  // the row's load inside it -- and behind a conditionally executed wait every later wait is for everything in flight, the
+  // next chunk's rows included)
+  auto zero_if = [](bool keep, const float4& m) {
+    const int k = keep ? -1 : 0;
+    return make_float4(__int_as_float(__float_as_int(m.x) & k), __int_as_float(__float_as_int(m.y) & k), __int_as_float(__float_as_int(m.z) & k),
+                       __int_as_float(__float_as_int(m.w) & k));
+  };
   // Rows (and, when they come from memory, the nine weights) of chunk kc + 1 are requested before chunk kc's MFMAs, into the
   // other half of a register ping-pong -- the loop runs two chunks per iteration so that no copy is needed, and the
   // sched_barrier keeps the requests where they are written (round 5: with `cur = nxt` copies at the loop's end hipcc sank the
@@ -1469,12 +1492,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs& a) {
       }
     };
     load_wts(0, wts[0]);
+    // (the requests are unconditional -- past the last chunk a harmless re-read of it: behind a branch around a load the
+    // wait counters are not statically known either)
     for (int kc = 0; kc < cin4; kc += 2) {
-      if (kc + 1 < cin4) load_rows(kc + 1, rows[1]), load_wts(kc + 1, wts[1]);
+      load_rows(min(kc + 1, cin4 - 1), rows[1]), load_wts(min(kc + 1, cin4 - 1), wts[1]);
       __builtin_amdgcn_sched_barrier(0);
       chunk(kc, rows[0], wts[0]);
       if (kc + 1 >= cin4) break;
-      if (kc + 2 < cin4) load_rows(kc + 2, rows[0]), load_wts(kc + 2, wts[0]);
+      load_rows(min(kc + 2, cin4 - 1), rows[0]), load_wts(min(kc + 2, cin4 - 1), wts[0]);
       __builtin_amdgcn_sched_barrier(0);
       chunk(kc + 1, rows[1], wts[1]);
     }
