@@ -1720,32 +1720,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     rfb_dilated<3>(t.a3.a[1], t.a3.a[1].w, lane, frame32, oy, ox, br);
     fold_branch(1, br);
   }
-  {
-    floatx4 br[4];
-    rfb_dilated<5>(t.a3.a[2], t.a3.a[2].w, lane, frame32, oy, ox, br);
-    fold_branch(2, br);
-  }
-  // x's row segments: channel 4 kc + q of the lane's 4 pixels, eight chunks in flight.  (Measured alone, 640 model at batch
-  // 32: requested here 76 us; requested before the convs with two chunks of rows in flight, 184 registers = two waves per
-  // SIMD, 79 us; capped at 128 registers for four waves, 18 dwords spilled, 78 us; with the convs' weights in LDS too,
-  // 55 KB = two blocks per CU, 80 us.  The two launches it replaces take 37 + 34 us: the 1x1 here also multiplies the four
-  // halo columns of every 16, which the 32x32x2 kernel does not have.)
+  // x's row segments: channel 4 kc + q of the lane's 4 pixels, sixteen chunks.  The first eight are requested in front of the
+  // third branch's fold, the other eight behind it, and PINNED there: left to itself hipcc keeps the sixteen addresses instead
+  // and requests every chunk one chunk -- 16 MFMAs, a third of a memory round trip -- before its use.
+  // (Measured alone in round 3, 640 model at batch 32: requested behind the convs 76 us; before the convs with two chunks of rows
+  // in flight, 184 registers = two waves per SIMD, 79 us; capped at 128 registers for four waves, 18 dwords spilled, 78 us;
+  // with the convs' weights in LDS too, 55 KB = two blocks per CU, 80 us.  The two launches it replaces take 37 + 34 us: the
+  // 1x1 here also multiplies the four halo columns of every 16, which the 32x32x2 kernel does not have.)
   const uint32_t x_off = (frame32 * (uint32_t)fin.in2_ctotal + (uint32_t)q) * (uint32_t)ohw + (uint32_t)(oy * fin.ow + ox);
   const uint32_t x_step = 4u * (uint32_t)ohw;
   const float* __restrict__ xin = fin.in2;
-  float4 xa[8];
+  float4 xa[8], xb[8];
+  {
+    floatx4 br[4];
+    rfb_dilated<5>(t.a3.a[2], t.a3.a[2].w, lane, frame32, oy, ox, br);
 #pragma unroll
-  for (int kc = 0; kc < 8; kc++) xa[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)kc * x_step));
+    for (int kc = 0; kc < 8; kc++) xa[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)kc * x_step));
+    __builtin_amdgcn_sched_barrier(0);
+    fold_branch(2, br);
+  }
+#pragma unroll
+  for (int kc = 0; kc < 8; kc++) xb[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)(8 + kc) * x_step));
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int half = 0; half < 2; half++) {
-    float4 xb[8];
-    if (half == 0) {
-#pragma unroll
-      for (int kc = 0; kc < 8; kc++) xb[kc] = *reinterpret_cast<const float4*>(xin + (x_off + (uint32_t)(8 + kc) * x_step));
-    }
 #pragma unroll
     for (int kc = 0; kc < 8; kc++) {
-      const float4 xv = xa[kc];
+      const float4 xv = half == 0 ? xa[kc] : xb[kc];
       const float xp[4] = {xv.x, xv.y, xv.z, xv.w};
       const int chunk = 12 + half * 8 + kc;
 #pragma unroll
@@ -1754,10 +1755,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int p = 0; p < 4; p++) out[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xp[p], out[m][p], 0, 0, 0);
       }
-    }
-    if (half == 0) {
-#pragma unroll
-      for (int kc = 0; kc < 8; kc++) xa[kc] = xb[kc];
     }
   }
   if (!live) return;
