@@ -67,7 +67,7 @@ while time.time() - t0 < secs:
             continue
     inflight.append(submit(batches[k]))
     n += 1
-    if time.time() - last > min(10, secs / 4):
+    if time.time() - last > min(10, secs / 16):
         last = time.time()
         rec = (n, rss_mb(), gpu_used_mb())
         first = first or rec
@@ -81,12 +81,17 @@ hs = m.host_stats()
 print("host:", hs["per_batch_us"], hs["gpu_span_share"])
 m.close()
 # A leak grows with the batch count to the end of the run; one-off growth (late first touches of pinned pages, allocator arenas
-# of threads that start late, the runtime enlarging a pool once: +190 MB between the first two samples of one run, flat
-# afterwards) does not.  So the slope is taken over the SECOND HALF of the run (round 4's runtime leak was 2.1 KB per batch:
-# 45 MB in 12 s); the bar is per batch OR small in total.
-mid = samples[len(samples) // 2] if len(samples) >= 3 else first
-per_batch = (end[1] - mid[1]) * 1048576.0 / max(n - mid[0], 1)
-print("host memory per batch over the second half (from batch %d on): %.0f bytes" % (mid[0], per_batch))
-ok = (per_batch < 300 or end[1] - mid[1] < 12) and abs(end[2] - first[2]) < 64
+# of threads that start late, the runtime enlarging a pool once: +190 MB in ONE sampling interval -- between the first two
+# samples of one run, between the last two of another -- flat before and after) does not.  So the slope is taken over the
+# SECOND HALF of the run with the largest single step between two samples taken out (round 4's runtime leak was 2.1 KB per
+# batch, in every interval: 45 MB in 12 s); the bar is per batch OR small in total.
+samples.append(end)
+half = samples[len(samples) // 2:] if len(samples) >= 4 else [first, end]
+steps = [b[1] - a[1] for a, b in zip(half, half[1:])]
+growth = sum(steps) - (max(steps) if len(steps) >= 3 else 0.0)
+per_batch = growth * 1048576.0 / max(half[-1][0] - half[0][0], 1)
+print("host memory per batch over the second half (from batch %d on, largest step of %d left out: %+.1f MB): %.0f bytes"
+      % (half[0][0], len(steps), max(steps), per_batch))
+ok = (per_batch < 300 or growth < 12) and abs(end[2] - first[2]) < 64
 print("ok" if ok else "GROWTH")
 sys.exit(0 if ok else 1)
