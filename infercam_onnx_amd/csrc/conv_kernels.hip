@@ -2392,7 +2392,9 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     return;
   }
   if (stride == 1) {
-    // (four k-steps of windows in flight instead of two, round 5: 31.1 -> 30.6 us alone, frame rate unchanged -- not kept)
+    // (four k-steps of windows in flight instead of two, round 5: 31.1 -> 30.6 us alone, frame rate unchanged; again with the
+    // requests pinned -- twelve loads in flight in the ISA, where hipcc had left six --: 29.6 -> 29.1 us, the dual launches
+    // that share the body 35.1 -> 36.4: these layers do not wait for their windows.  Not kept.)
     if (c.deep) launch(k_dwpw_mfma<1, 1, 2, 1>);
     else launch(k_dwpw_mfma<1, 1, 1, 1>);
   } else {
