@@ -1153,11 +1153,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // the queue slots of step ks are consumed (into tcur): refill them with step ks + PD / ks + 2 -- of the next X1 row
       // once this one runs out
       if (RING) ring_at(y1 + 1, ks) = win[ks % PD][0];  // this step's bottom row: the middle / top row of the next two X1 rows
+      // (the next X1 row's first windows are requested on the band's last row too -- ro_next is that row's own address then,
+      // a harmless re-read: behind `if (!last)` the requests sat in a conditionally executed block and every wait of the
+      // row's last PD - 1 k-steps was computed as if they had not been issued -- vmcnt(2) (1) (0) where (3) (3) (3) was meant)
       if (ks + PD < KS1) load_window(ro, ks + PD);
-      else if (!last) load_window(ro_next, ks + PD - KS1);
+      else load_window(ro_next, ks + PD - KS1);
       if (RING) {
         if (ks + 2 < KS1) load_ring(y1, ks + 2);
-        else if (!last) load_ring(y1 + 1, ks + 2 - KS1);
+        else load_ring(y1 + 1, ks + 2 - KS1);
       }
       // (memory instructions stay on their side of this line, everything else may cross: in the unrolled loop hipcc sank
       // the requests of an even k-step down to those of the odd one behind it -- six loads in a burst, the first three
