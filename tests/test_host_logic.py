@@ -332,6 +332,30 @@ def test_detection_list_comparison_rule():
     assert match_detections(np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32))["equal"]
 
 
+def test_prefetch_queues_are_in_the_isa():
+    """tools/ab/r5_queue_audit.py on the built objects: the software prefetch of the kernels round 5 repaired is still one in
+    the code hipcc emits -- no `vmcnt(0)` (a wait for the load that was just requested) in the k-loops of the 1x1 kernel and
+    of the chained dw->pw kernels, and the queue depths the source asks for (rules 6 and 7).  A compiler or
+    source change that lets the loads sink again shows here before it shows as 10-25 % on those kernels."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", "r5_queue_audit.py"), "k_pw_mfma<1, 4, 1>", "k_dwpw2_mfma<32, 2, false>",
+                        "k_dwpw2_mfma<16, 1, true>", "k_conv3x3_rows_mfma<1, 1>"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    loops = {}
+    lines = r.stdout.splitlines()
+    for head, body in zip(lines[0::2], lines[1::2]):
+        loops[head.split(" (hot loop")[0]] = body.strip()
+    waits = lambda k: [int(x) for x in re.findall(r"\((\d+)\)", loops[k])]
+    assert set(waits("k_pw_mfma<1, 4, 1>")) == {3}, loops["k_pw_mfma<1, 4, 1>"]              # four k-steps of activations in flight
+    w = waits("k_dwpw2_mfma<32, 2, false>")
+    assert min(w[2:]) >= 6 and len(w) > 40, loops["k_dwpw2_mfma<32, 2, false>"]             # behind the row's first step: two windows (6 rows) stay in flight
+    w = waits("k_dwpw2_mfma<16, 1, true>")
+    assert w[1:] == [4, 4, 4, 4], loops["k_dwpw2_mfma<16, 1, true>"]                           # k-steps 4..7 of an X1 row: four requests behind the one consumed
+    assert waits("k_conv3x3_rows_mfma<1, 1>")[:3] == [5, 4, 3], loops["k_conv3x3_rows_mfma<1, 1>"]  # the next chunk's rows stay in flight
+
+
 def test_isa_mix_reads_the_built_code_objects(tmp_path):
     """tools/isa_mix.py (round 5's instruction ledger) on the library's own object files: every MFMA kernel instance is found
     with its hot loop, the chained kernel's k-loop carries its DPP multiply-adds and no select, and the JSON beside the table
