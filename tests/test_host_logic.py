@@ -332,6 +332,18 @@ def test_detection_list_comparison_rule():
     assert match_detections(np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32))["equal"]
 
 
+def _built_kernel_objects():
+    """The library's object files (csrc/build/*_kernels.o: hipcc cross-compiles them without a GPU); built here if a fresh
+    check-out has none yet."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = os.path.join(root, "infercam_onnx_amd", "csrc", "build", "*_kernels.o")
+    if not glob.glob(pat):
+        subprocess.run(["make", "-C", os.path.join(root, "infercam_onnx_amd", "csrc"), "-j8"], check=True, capture_output=True, timeout=1500)
+    assert glob.glob(pat)
+
+
 def test_prefetch_queues_are_in_the_isa():
     """tools/ab/r5_queue_audit.py on the built objects: the software prefetch of the kernels round 5 repaired is still one in
     the code hipcc emits -- no `vmcnt(0)` (a wait for the load that was just requested) in the k-loops of the 1x1 kernel and
@@ -339,6 +351,7 @@ def test_prefetch_queues_are_in_the_isa():
     source change that lets the loads sink again shows here before it shows as 10-25 % on those kernels."""
     import re
 
+    _built_kernel_objects()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab", "r5_queue_audit.py"), "k_pw_mfma<1, 4, 1>", "k_dwpw2_mfma<32, 2, false>",
                         "k_dwpw2_mfma<16, 1, true>", "k_conv3x3_rows_mfma<1, 1>"], capture_output=True, text=True, timeout=600)
@@ -362,6 +375,7 @@ def test_isa_mix_reads_the_built_code_objects(tmp_path):
     is what tools/design_table.py reads."""
     import json
 
+    _built_kernel_objects()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "isa_mix.txt")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), "--out", out], capture_output=True, text=True, timeout=600)
