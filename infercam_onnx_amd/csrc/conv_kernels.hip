@@ -1561,7 +1561,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
 // rounding apart from the two-launch form (which itself differs from the oracle's order by the same kind of rounding).
 // a3.a[b]: conv b as for launch_conv3x3_rows_mfma (w = row packing); fin: the summed 1x1 (in2 = x with in2_ctotal, w = tail
 // packing [28 chunks][4 cout tiles][64], bias = both biases summed, out).
-constexpr int kTailHL = 2, kTailNG = 16 - 2 * kTailHL;
+#ifndef UFD_TAIL_HALO_LANES
+#define UFD_TAIL_HALO_LANES 0
+#endif
+constexpr int kTailHL = UFD_TAIL_HALO_LANES ? 2 : 0, kTailNG = 16 - 2 * kTailHL;
 constexpr int kTailChunks = 12 + 16;  // 48 branch channels + 64 channels of x, 4 per MFMA
 struct RfbTailArgs {
   ConvArgs3 a3;
@@ -1610,6 +1613,35 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) m[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c));
   };
+  // No halo lanes (kTailHL = 0): all 16 lanes of a quad own outputs, and the two pixel groups left / right of the tile come
+  // from memory -- ONE more row segment per lane and row: lanes 0, 1 read groups g - 2 (the tile's left neighbours), lanes
+  // 14, 15 groups g + 2, the others their own again (a cache hit).  A neighbour value is then dpp(own row) | dpp(edge row):
+  // the row shifts deliver 0 to lanes without a source, the edge rows are masked to 0 outside their two lanes.
+  const int j16 = lane & 15;
+  const int e_shift = kTailHL ? 0 : (j16 < 2 ? -8 : (j16 >= 14 ? 8 : 0));
+  const uint32_t e_last = (uint32_t)a.B * (uint32_t)a.in_ctotal * (uint32_t)ihw - 4u;
+  const int e_mask_l = j16 < 2 ? -1 : 0, e_mask_r = j16 >= 14 ? -1 : 0;
+  auto load_edge = [&](int kc, int r) -> float4 {
+    const uint32_t c = (uint32_t)min(4 * kc + q, a.cin - 1) * (uint32_t)ihw;
+    const int off = (int)(rowoff[r] + c) + e_shift;
+    return *reinterpret_cast<const float4*>(in + (uint32_t)min(max(off, 0), (int)e_last));
+  };
+  auto pick = [](const float4& m, int k) { return k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w)); };
+  auto masked = [](float v, int mask) { return __int_as_float(__float_as_int(v) & mask); };
+  auto either = [](float a0, float b0) { return __int_as_float(__float_as_int(a0) | __float_as_int(b0)); };
+  // as col(), with the tile's outer neighbours from the edge row e
+  auto col_e = [&](const float4& m, const float4& e, int c) -> float {
+    const int o = (c >= 0) ? (c >> 2) : -((3 - c) >> 2);
+    const int k = c - 4 * o;
+    const float v = pick(m, k);
+    switch (o) {
+      case 0: return v;
+      case -1: return either(row_shift<0x111>(v), row_shift<0x101>(masked(pick(e, k), e_mask_l)));  // lane 0 <- lane 1's left edge
+      case -2: return either(row_shift<0x112>(v), masked(pick(e, k), e_mask_l));
+      case 1: return either(row_shift<0x101>(v), row_shift<0x111>(masked(pick(e, k), e_mask_r)));   // lane 15 <- lane 14's right edge
+      default: return either(row_shift<0x102>(v), masked(pick(e, k), e_mask_r));
+    }
+  };
   // Rows AND weights of chunk kc + 1 are requested before chunk kc's MFMAs and held in the other half of a register ping-pong
   // (the loop is fully unrolled: cin = 16, rfb_tail_supported); the sched_barrier keeps the requests where they are written.
   // Round 5: with `cur = nxt` copies at the loop's end hipcc sank the next rows' loads down to the copies and waited for them
@@ -1620,9 +1652,14 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
     for (int t = 0; t < 9; t++) w[t] = wsrc[(kc * 9 + t) * 64 + lane];
   };
   constexpr int kChunks = 4;
-  float4 rows[2][3];
+  float4 rows[2][3], edges[3];  // (the edge rows in ONE set of registers: row r of the next chunk is requested as soon as row r
+                                 // of this one has been read -- a chunk's MFMAs ahead of its use, 12 registers instead of 24)
   float wts[2][9];
   load_rows(0, rows[0]);
+  if (!kTailHL) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) edges[r] = load_edge(0, r);
+  }
   load_wts(0, wts[0]);
   (void)cin4;
 #pragma unroll
@@ -1633,14 +1670,16 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const float4 m = rowok[r] ? cur[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 e = (kTailHL || !rowok[r]) ? make_float4(0.f, 0.f, 0.f, 0.f) : edges[r];
       float x[3][4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float vl = col(m, j - DIL), vc = col(m, j), vr = col(m, j + DIL);
+        const float vl = kTailHL ? col(m, j - DIL) : col_e(m, e, j - DIL), vc = col(m, j), vr = kTailHL ? col(m, j + DIL) : col_e(m, e, j + DIL);
         x[0][j] = j >= DIL ? vl : (lok[j] ? vl : 0.0f);
         x[1][j] = vc;
         x[2][j] = j + DIL <= 3 ? vr : (rok[j] ? vr : 0.0f);
       }
+      if (!kTailHL && kc + 1 < kChunks) edges[r] = load_edge(kc + 1, r);
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const float w = wts[kc & 1][r * 3 + kx];
