@@ -1552,7 +1552,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
 // activation) and relu(ConvLinear(cat48) + shortcut(x)) -- SURVEY 8.1 rows 15, 18, 22, 23, 24.  The 48-channel concat
 // tensor (29.5 MB per 32-frame batch of the 640 model, written by one launch and read by the next) never exists: a wave
 // computes the three convs for its tile exactly as k_conv3x3_rows_mfma does (same lane layout, same MFMA sequence, one
-// conv after the other with the halo of the widest dilation, HL = 2) and keeps the results in their accumulators; the D
+// conv after the other; since round 5 WITHOUT halo lanes -- rfb_dilated: the tile's outer neighbours come from memory, all 16
+// lanes of a quad own outputs; -DUFD_TAIL_HALO_LANES=1 builds the form with the halo of the widest dilation, HL = 2, 12
+// outputs per quad) and keeps the results in their accumulators; the D
 // layout of v_mfma_f32_16x16x4_f32 -- register r of lane (q, j) = channel 4q + r of pixel group j -- IS a B operand of the
 // same instruction for the k-chunk of channels {r, 4 + r, 8 + r, 12 + r}, so the 1x1 conv multiplies them straight out of
 // the registers (weights packed in that channel order: pack_rfb_tail_weights), then runs over the 64 channels of x from
@@ -1768,7 +1770,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (Measured alone in round 3, 640 model at batch 32: requested behind the convs 76 us; before the convs with two chunks of rows
   // in flight, 184 registers = two waves per SIMD, 79 us; capped at 128 registers for four waves, 18 dwords spilled, 78 us;
   // with the convs' weights in LDS too, 55 KB = two blocks per CU, 80 us.  The two launches it replaces take 37 + 34 us: the
-  // 1x1 here also multiplies the four halo columns of every 16, which the 32x32x2 kernel does not have.)
+  // 1x1 here also multiplied the four halo columns of every 16 then, which the 32x32x2 kernel does not have.)
   const uint32_t x_off = (frame32 * (uint32_t)fin.in2_ctotal + (uint32_t)q) * (uint32_t)ohw + (uint32_t)(oy * fin.ow + ox);
   const uint32_t x_step = 4u * (uint32_t)ohw;
   const float* __restrict__ xin = fin.in2;
