@@ -686,25 +686,30 @@ def main():
             refs = list(ex.map(lambda j: oracle.infer_jpeg(j, W, H, weights, priors, 0.5, 0.5), jpegs[:nver * B]))
         from oracle.compare import match_detections
 
-        max_err, bad, excused, unexplained = 0.0, 0, 0, 0
+        max_err, bad, excused, unexplained, over_cap = 0.0, 0, 0, 0, 0
         for (g, n), r in zip(got, refs):
             if n > model.det_cap:  # (more detections than the bench's output rows hold: compare what was returned)
                 r = r[:len(g)]
             # matched as sets (detections whose confidences differ by less than fp32 rounding may swap places); a detection
             # without a partner is excused only when its decision provably sat on a threshold at fp32 resolution -- the
             # rule of tests/helpers.py:assert_dets_match (oracle/compare.py)
-            c = match_detections(g, r, 0.5, 0.5, atol=1e-3)
+            c = match_detections(g, r, 0.5, 0.5, atol=1e-4)  # (the tests' tolerance; north_star's 1e-3 is the bar on max_err below)
             max_err = max(max_err, c["max_err"])
             bad += len(g) != len(r)
-            excused += len(c["left_got"]) + len(c["left_ref"]) - len(c["not_borderline"])
+            n_left = len(c["left_got"]) + len(c["left_ref"])
+            excused += n_left - len(c["not_borderline"])
             unexplained += len(c["not_borderline"])
+            # the cap of tests/helpers.py:assert_dets_match: borderline leftovers stay below 1 % of a frame's list (or 2)
+            over_cap += n_left > max(2, 0.01 * max(len(g), len(r)))
         verified = {"frames": len(got), "max_abs_err": max_err, "count_mismatch_frames": bad, "borderline_detections_excused": excused,
                     "annotated_streams_byte_identical": annot_checked,
                     "unexplained_detections": unexplained,
                     "against": "CPU oracle (oracle/) on the same JPEG bytes, every detection of every frame; tolerance 1e-3 (north_star); "
-                               "a count mismatch passes only when every unmatched detection sits within the tolerance of the "
-                               "confidence or IoU threshold"}
-        if max_err > 1e-3 or unexplained:
+                               "a count mismatch passes only when every unmatched detection sits within 1e-4 of the "
+                               "confidence threshold or 1e-3 of the IoU threshold, such detections stay below max(2, 1 %) of the frame's list "
+                               "and such frames below max(1, 2 %) of the sample"}
+        verified["frames_over_the_excuse_cap"] = over_cap
+        if max_err > 1e-3 or unexplained or over_cap or bad > max(1, len(got) // 50):
             raise SystemExit("bench.py: detections differ from the CPU oracle: %s" % verified)
 
     if rank == 0:

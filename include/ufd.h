@@ -86,6 +86,9 @@ typedef struct ufd_config {
 #define UFD_FLAG_NO_STEM_FUSE 128u /* upsample/colour/normalise kernel + stem conv instead of the stem reading the sample planes */
 #define UFD_FLAG_NO_DUAL 512u      /* head pairs and the backbone block beside them as separate launches instead of one grid */
 #define UFD_FLAG_NO_RFB_TAIL 2048u /* the RFB's dilated convs and its summed 1x1 as two launches (concat tensor in memory) instead of k_rfb_tail */
+#define UFD_FLAG_SUBSEQ_32 4096u   /* device entropy decoder: 32-byte subsequences whatever the batch holds (the host plan picks 32 for a */
+#define UFD_FLAG_SUBSEQ_64 8192u   /* frame or a few, 64 otherwise; same coefficients either way) ... or 64-byte ones */
+#define UFD_FLAG_TEST_DUPLICATE_DEVICES 16384u /* ufd_create_replicas only: let one device be listed twice (a one-GPU box rehearsing n = 2) */
 /* Host placement: by default the handle's issue workers and pool threads are pinned to the CPUs of the NUMA node the GPU
  * hangs off (/sys/bus/pci/devices/<bdf>/numa_node), inside the process's affinity mask -- eight handles on a two-socket
  * box then stage their JPEG bytes and issue their launches from the socket next to their GPU (ufd_model_placement

@@ -823,13 +823,18 @@ typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 //   t1 += w0 * m.x + w1 * m.y + w2 * m.z                   t3 += w0 * m.z + w1 * m.w + wr * [lane + 1].m.x
 // (each sum in this order: taps left to right).  wl / wr: w0 / w2, or 0 in the lane at the left / right image border.
 // FIRST: t = bias + ... (the first tap row of a channel).  Written as the 13 instructions it is: the compiler does not fold
-// a DPP move into the multiply-add that uses it.  s_nop 1: a DPP source must not have been written by the vector ALU in the two
-// cycles before (the pixels come from loads, but the register allocator may move them; the assembler does not check inline asm).
+// a DPP move into the multiply-add that uses it.  s_nop 4: a DPP source must not have been written by the vector ALU in the two
+// cycles before, and a vector-ALU write of EXEC (v_cmpx) needs FIVE wait states in front of a DPP op -- the pixels come from
+// loads and the kernels branch on scalar conditions, but the compiler's hazard recogniser does not look inside inline asm, so
+// the asm carries the worst case itself (3 cycles more per 12-13 vector instructions).  wave_shr / wave_shl are GFX9 DPP modes.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "dw_row / wave_inscan use GFX9-only DPP modes (wave_shr, wave_shl, row_bcast): this library is built for gfx950 only"
+#endif
 template <bool FIRST>
 __device__ __forceinline__ void dw_row(float (&t)[4], const float4 m, float w0, float w1, float w2, float wl, float wr, float bias) {
   if (FIRST) {
     float tmp;
-    asm("s_nop 1\n\t"
+    asm("s_nop 4\n\t"
         "v_mov_b32_dpp %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fma_f32 %0, %12, %4, %14\n\t"
         "v_fma_f32 %1, %9, %5, %14\n\t"
@@ -846,7 +851,7 @@ __device__ __forceinline__ void dw_row(float (&t)[4], const float4 m, float w0, 
         : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(tmp)
         : "v"(m.x), "v"(m.y), "v"(m.z), "v"(m.w), "v"(w0), "v"(w1), "v"(w2), "v"(wl), "v"(wr), "v"(bias));
   } else {
-    asm("s_nop 1\n\t"
+    asm("s_nop 4\n\t"
         "v_fmac_f32_dpp %0, %7, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32 %1, %8, %4\n\t"
         "v_fmac_f32 %2, %8, %5\n\t"
@@ -1553,8 +1558,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
 // tensor (29.5 MB per 32-frame batch of the 640 model, written by one launch and read by the next) never exists: a wave
 // computes the three convs for its tile exactly as k_conv3x3_rows_mfma does (same lane layout, same MFMA sequence, one
 // conv after the other; since round 5 WITHOUT halo lanes -- rfb_dilated: the tile's outer neighbours come from memory, all 16
-// lanes of a quad own outputs; -DUFD_TAIL_HALO_LANES=1 builds the form with the halo of the widest dilation, HL = 2, 12
-// outputs per quad) and keeps the results in their accumulators; the D
+// lanes of a quad own outputs; the form with the halo of the widest dilation, 12 outputs per quad, was 66.6 us for 58.0 and
+// is gone) and keeps the results in their accumulators; the D
 // layout of v_mfma_f32_16x16x4_f32 -- register r of lane (q, j) = channel 4q + r of pixel group j -- IS a B operand of the
 // same instruction for the k-chunk of channels {r, 4 + r, 8 + r, 12 + r}, so the 1x1 conv multiplies them straight out of
 // the registers (weights packed in that channel order: pack_rfb_tail_weights), then runs over the 64 channels of x from
@@ -1563,10 +1568,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_rows_mfma(ConvArgs3 p3) {
 // rounding apart from the two-launch form (which itself differs from the oracle's order by the same kind of rounding).
 // a3.a[b]: conv b as for launch_conv3x3_rows_mfma (w = row packing); fin: the summed 1x1 (in2 = x with in2_ctotal, w = tail
 // packing [28 chunks][4 cout tiles][64], bias = both biases summed, out).
-#ifndef UFD_TAIL_HALO_LANES
-#define UFD_TAIL_HALO_LANES 0
-#endif
-constexpr int kTailHL = UFD_TAIL_HALO_LANES ? 2 : 0, kTailNG = 16 - 2 * kTailHL;
+constexpr int kTailNG = 16;           // pixel groups (4 pixels each) per wave: every lane of a quad owns one
 constexpr int kTailChunks = 12 + 16;  // 48 branch channels + 64 channels of x, 4 per MFMA
 struct RfbTailArgs {
   ConvArgs3 a3;
@@ -1615,12 +1617,12 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) m[r] = *reinterpret_cast<const float4*>(in + (rowoff[r] + c));
   };
-  // No halo lanes (kTailHL = 0): all 16 lanes of a quad own outputs, and the two pixel groups left / right of the tile come
+  // No halo lanes: all 16 lanes of a quad own outputs, and the two pixel groups left / right of the tile come
   // from memory -- ONE more row segment per lane and row: lanes 0, 1 read groups g - 2 (the tile's left neighbours), lanes
   // 14, 15 groups g + 2, the others their own again (a cache hit).  A neighbour value is then dpp(own row) | dpp(edge row):
   // the row shifts deliver 0 to lanes without a source, the edge rows are masked to 0 outside their two lanes.
   const int j16 = lane & 15;
-  const int e_shift = kTailHL ? 0 : (j16 < 2 ? -8 : (j16 >= 14 ? 8 : 0));
+  const int e_shift = j16 < 2 ? -8 : (j16 >= 14 ? 8 : 0);
   const uint32_t e_last = (uint32_t)a.B * (uint32_t)a.in_ctotal * (uint32_t)ihw - 4u;
   const int e_mask_l = j16 < 2 ? -1 : 0, e_mask_r = j16 >= 14 ? -1 : 0;
   auto load_edge = [&](int kc, int r) -> float4 {
@@ -1658,10 +1660,8 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
                                  // of this one has been read -- a chunk's MFMAs ahead of its use, 12 registers instead of 24)
   float wts[2][9];
   load_rows(0, rows[0]);
-  if (!kTailHL) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) edges[r] = load_edge(0, r);
-  }
+  for (int r = 0; r < 3; r++) edges[r] = load_edge(0, r);
   load_wts(0, wts[0]);
   (void)cin4;
 #pragma unroll
@@ -1672,16 +1672,16 @@ __device__ __forceinline__ void rfb_dilated(const ConvArgs& a, const float* __re
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const float4 m = rowok[r] ? cur[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 e = (kTailHL || !rowok[r]) ? make_float4(0.f, 0.f, 0.f, 0.f) : edges[r];
+      const float4 e = rowok[r] ? edges[r] : make_float4(0.f, 0.f, 0.f, 0.f);
       float x[3][4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float vl = kTailHL ? col(m, j - DIL) : col_e(m, e, j - DIL), vc = col(m, j), vr = kTailHL ? col(m, j + DIL) : col_e(m, e, j + DIL);
+        const float vl = col_e(m, e, j - DIL), vc = col(m, j), vr = col_e(m, e, j + DIL);
         x[0][j] = j >= DIL ? vl : (lok[j] ? vl : 0.0f);
         x[1][j] = vc;
         x[2][j] = j + DIL <= 3 ? vr : (rok[j] ? vr : 0.0f);
       }
-      if (!kTailHL && kc + 1 < kChunks) edges[r] = load_edge(kc + 1, r);
+      if (kc + 1 < kChunks) edges[r] = load_edge(kc + 1, r);
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         const float w = wts[kc & 1][r * 3 + kx];
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int bx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
   const int ohw = fin.oh * fin.ow, gpf = ohw >> 2, gpr = fin.ow >> 2;
   const int total = fin.B * gpf;
-  if ((long)bx * 4 * kTailNG - kTailHL >= (long)total) return;  // whole block, before the barrier
+  if ((long)bx * 4 * kTailNG >= (long)total) return;  // whole block, before the barrier
   // The 1x1's weight table is REQUESTED here and stored to LDS behind the first dilated conv, in front of the barrier its
   // first reader (fold_branch) needs: the table's round trip runs beside that conv's loads and MFMAs instead of in front of
   // everything (28 registers held meanwhile; the kernel has two waves per SIMD either way).
@@ -1719,9 +1719,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j16 = lane & 15;
-  const int g = (bx * 4 + wave) * kTailNG + j16 - kTailHL;
-  const bool inrange = g >= 0 && g < total;
-  const bool live = inrange && j16 >= kTailHL && j16 < 16 - kTailHL;
+  const int g = (bx * 4 + wave) * kTailNG + j16;
+  const bool inrange = g < total;
+  const bool live = inrange;
   const uint32_t frame32 = inrange ? (uint32_t)g / (uint32_t)gpf : 0u;
   const int rem = inrange ? g - (int)frame32 * gpf : 0;
   const int oy = rem / gpr, ox = (rem - oy * gpr) * 4;
@@ -2246,7 +2246,9 @@ bool rfb_tail_supported(const ConvArgs* dil3, const ConvArgs& fin) {
     if (a.k != 3 || a.stride != 1 || a.dil != kDil[b] || a.pad != a.dil || a.cin != 16 || a.cout != 16 || a.depthwise || a.res || a.relu) return false;
     if (a.ih != fin.oh || a.iw != fin.ow || a.oh != fin.oh || a.ow != fin.ow) return false;
   }
-  return fin.k == 1 && fin.cout == 64 && fin.cin == 48 + 64 && fin.in2_ctotal >= 64 && (fin.ow & 3) == 0 && !fin.res;  // (shapes only: also asked at plan time)
+  // ow % 8: lanes 0 / 1 and 14 / 15 of a quad fetch each other's outer neighbours (rfb_dilated, load_edge), so a pair of pixel
+  // groups must never straddle a row or a frame: an even number of groups per row (20 for the 640 model, 10 for the 320 one)
+  return fin.k == 1 && fin.cout == 64 && fin.cin == 48 + 64 && fin.in2_ctotal >= 64 && (fin.ow & 7) == 0 && !fin.res;  // (shapes only: also asked at plan time)
 }
 
 void launch_rfb_tail(const ConvArgs* dil3, const ConvArgs& fin, hipStream_t s) {
@@ -2459,7 +2461,7 @@ struct DualChoice {
   size_t lds = 0;
 };
 bool choose_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b, int b_stride, DualChoice* out) {
-  if (std::getenv("UFD_NO_DUAL")) return false;
+  if (experiment_env("UFD_NO_DUAL")) return false;
   if (na < 1 || na > 3 || a_stride != 1 || dwpw_uses_coop(a, na)) return false;
   const DwpwConfig ca = dwpw_config(a, na);
   if (!ca.deep) return false;
@@ -2551,7 +2553,7 @@ bool dwpw2_supported(const ConvArgs& first, const ConvArgs& second) {
 static int dwpw2_band(const ConvArgs& second) {
   const long waves1 = (2L * second.B * (second.oh * second.ow / 4) + kDwGroups - 1) / kDwGroups;
   const double rounds = (double)waves1 / 2048.0;
-  if (const char* e = std::getenv("UFD_BAND_SMALL"))  // (experiment knob)
+  if (const char* e = experiment_env("UFD_BAND_SMALL"))  // (experiment knob)
     if (rounds < 3.0 && std::atoi(e) > 0 && second.oh % std::atoi(e) == 0) return std::atoi(e);
   if (rounds < 3.0) return 1;
   int best = 1;

@@ -1074,7 +1074,7 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
   const dim3 gext2((nsub * kHypSlots + kExtendThreads - 1) / kExtendThreads, frames);     // k_huff_extend: 64
   const dim3 ext_threads(kExtendThreads);
   // speculation rounds (UFD_EXTEND_ROUNDS while measuring; 2 is what ships: docs/EXPERIMENTS.md rounds 4 and 5)
-  static const int rounds = std::getenv("UFD_EXTEND_ROUNDS") ? std::max(0, std::min(4, std::atoi(std::getenv("UFD_EXTEND_ROUNDS")))) : 2;
+  static const int rounds = experiment_env("UFD_EXTEND_ROUNDS") ? std::max(0, std::min(4, std::atoi(experiment_env("UFD_EXTEND_ROUNDS")))) : 2;
   uint8_t *cnt_in = cnt_a, *cnt_out = cnt_b;
   for (int r = 0; r < rounds; r++) {
     stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_in, cnt_out); });

@@ -283,8 +283,8 @@ struct Decoder {
     d->mcuy = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
     uint32_t coff = 0, poff = 0, blocks = 0;
     for (int i = 0; i < d->ncomp; i++) {
-      // the GPU upsamplers cover expansion factors 1 and 2 (4:4:4, 4:2:2, 4:2:0, 4:4:0)
-      if (d->hmax % d->h[i] || d->vmax % d->v[i] || d->hmax / d->h[i] > 2 || d->vmax / d->v[i] > 2) return kJpegUnsupported;
+      // integral expansion factors only, as jdsample.c (JERR_FRACT_SAMPLE_NOTIMPL otherwise): 1..4 each way
+      if (d->hmax % d->h[i] || d->vmax % d->v[i]) return kJpegUnsupported;
       d->wblk[i] = d->mcux * d->h[i];
       d->hblk[i] = d->mcuy * d->v[i];
       d->dw[i] = (d->width * d->h[i] + d->hmax - 1) / d->hmax;
@@ -452,6 +452,11 @@ struct Decoder {
       nx = (d->dw[sc.comp[0]] + 7) / 8;
       ny = (d->dh[sc.comp[0]] + 7) / 8;
     }
+    if (inter) {  // jdinput.c per_scan_setup: more than D_MAX_BLOCKS_IN_MCU = 10 blocks is JERR_BAD_MCU_SIZE
+      int blocks = 0;
+      for (int i = 0; i < sc.ns; i++) blocks += d->h[sc.comp[i]] * d->v[sc.comp[i]];
+      if (blocks > 10) return kJpegCorrupt;
+    }
     for (int i = 0; i < sc.ns; i++) {
       bool need_dc = !d->progressive || (sc.ss == 0 && sc.ah == 0);
       bool need_ac = !d->progressive || sc.ss > 0;
@@ -531,7 +536,7 @@ struct Decoder {
       if (ds < 0 || as < 0) return kJpegNotEligible;
       for (int by = 0; by < d->v[c]; by++)
         for (int bx = 0; bx < d->h[c]; bx++) {
-          if (nb >= 10) return kJpegNotEligible;
+          if (nb >= 10) return kJpegCorrupt;  // (as decode_scan: libjpeg refuses the scan)
           plan->scan.blk_comp[nb] = (uint8_t)c, plan->scan.blk_bx[nb] = (uint8_t)bx, plan->scan.blk_by[nb] = (uint8_t)by;
           plan->scan.blk_dc[nb] = (uint8_t)ds, plan->scan.blk_ac[nb] = (uint8_t)as;
           nb++;

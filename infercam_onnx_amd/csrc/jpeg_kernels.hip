@@ -201,7 +201,7 @@ __device__ __forceinline__ void upsample4(const JpegFrameDesc& d, const uint8_t*
     }
     return;
   }
-  {  // hx == 1, vx == 2 (4:4:0): h1v2 fancy
+  if (hx == 1 && vx == 2) {  // 4:4:0: h1v2 fancy (no width condition in jdsample.c)
     const int iy = y >> 1;
     const int ny = max(0, min(dh - 1, (y & 1) ? iy + 1 : iy - 1));
     const uint8_t* r0 = pl + (size_t)iy * pitch;
@@ -212,6 +212,12 @@ __device__ __forceinline__ void upsample4(const JpegFrameDesc& d, const uint8_t*
       const int i = min(x0 + j, pitch - 1);
       out[j] = (r0[i] * 3 + r1[i] + bias) >> 2;
     }
+    return;
+  }
+  {  // every other integral expansion (4:1:1, 4:1:0, 4:4:1, 3x, ...): jdsample.c int_upsample, plain replication
+    const uint8_t* row = pl + (size_t)(y / vx) * pitch;
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = row[min((x0 + j) / hx, pitch - 1)];
   }
 }
 

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <functional>
 
+#include "experiments.hpp"
 #include "jpeg_host.hpp"
 
 namespace ufd {

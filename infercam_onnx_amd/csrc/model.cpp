@@ -479,8 +479,9 @@ DevicePlan plan_device_entropy(ufd_model* m, Slot& s, const uint8_t* const* jpeg
   // the MCU: 32 frames of 640x480 are 100 k lanes), 32 for a frame or a few at a time -- the launches of the chain last as
   // long as their slowest lane walks, and half the symbols per lane is 167 -> 129 us for ONE 640x480 frame (24 bytes gain
   // nothing more, 16 leave the true chain unspeculated in most frames: k_huff_resolve then decodes on the spot, 1 ms).
-  static const size_t small_bytes = std::getenv("UFD_SUB_SMALL_BYTES") ? (size_t)std::atol(std::getenv("UFD_SUB_SMALL_BYTES")) : 200u * 1024;
-  const uint32_t sub_floor = batch_bytes <= small_bytes ? 32u : 64u;
+  static const size_t small_bytes = experiment_env("UFD_SUB_SMALL_BYTES") ? (size_t)std::atol(experiment_env("UFD_SUB_SMALL_BYTES")) : 200u * 1024;
+  // (UFD_FLAG_SUBSEQ_32 / _64: the parity test that shows the floor does not change a pixel forces either)
+  const uint32_t sub_floor = m->force_sub_floor ? m->force_sub_floor : (batch_bytes <= small_bytes ? 32u : 64u);
   for (uint32_t i = 0; i < count; i++) {
     std::memset(&s.h_scans[i], 0, sizeof(HuffScan));  // nseg = 0: the frame's workgroups exit at once
     if (s.st[i] != kJpegOk) continue;
@@ -565,7 +566,7 @@ int enqueue_device_entropy(ufd_model* m, Ctx& c, const DevicePlan& p, uint32_t c
                         c.sync, c.d_status, c.stream, &hook, p.used_coef);
     // Timing experiments only (UFD_REPEAT_ENTROPY=n: the decoder chain n more times, same results): what the stage costs the
     // LOADED pipeline is the frame rate it takes away when it runs twice (docs/EXPERIMENTS.md, round 5).
-    static const int repeat = std::getenv("UFD_REPEAT_ENTROPY") ? std::atoi(std::getenv("UFD_REPEAT_ENTROPY")) : 0;
+    static const int repeat = experiment_env("UFD_REPEAT_ENTROPY") ? std::atoi(experiment_env("UFD_REPEAT_ENTROPY")) : 0;
     for (int r = 0; r < repeat; r++)
       launch_huffman_sync(d_blob, d_scans, d_ivs, count, p.max_nsub, p.max_bpm, m->d_sync_luts, d_descs, d_coef, m->coef_stride,
                           c.sync, c.d_status, c.stream, nullptr, p.used_coef);
@@ -1054,6 +1055,10 @@ int create(const ufd_config* cfg, ufd_model** out) {
     g_create_error = "ufd_create: max_batch must be in 1..1024";
     return UFD_E_ARG;
   }
+  if (const char* knob = stray_experiment_knob()) {  // (before the device check: a CPU test covers it)
+    g_create_error = std::string(knob) + " is set, but this build of libufacehip has no experiment hooks (make EXPERIMENTS=1 builds the one that has)";
+    return UFD_E_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_create_error = "no HIP device: libufacehip needs a gfx950 GPU (there is no CPU fallback)";
@@ -1078,7 +1083,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->max_w = std::max<uint32_t>(m->max_w, m->W);
   m->max_h = std::max<uint32_t>(m->max_h, m->H);
   m->profile = (cfg->flags & UFD_FLAG_PROFILE) != 0;
-  if (const char* e = std::getenv("UFD_PLAN_PARALLEL")) m->plan_parallel = std::atoi(e) != 0;
+  if (const char* e = experiment_env("UFD_PLAN_PARALLEL")) m->plan_parallel = std::atoi(e) != 0;
+  m->force_sub_floor = (cfg->flags & UFD_FLAG_SUBSEQ_32) ? 32u : ((cfg->flags & UFD_FLAG_SUBSEQ_64) ? 64u : 0u);
   unsigned threads = cfg->host_threads ? cfg->host_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   m->host_threads = threads;
 #define HIPB(expr)                                                                      \
@@ -1168,8 +1174,8 @@ int create(const ufd_config* cfg, ufd_model** out) {
   // ---- buffers
   const size_t B = m->B;
   {
-    // worst-case slab: every component at full resolution, padded to 16-pixel MCUs
-    const size_t pw = (m->max_w + 15) / 16 * 16, ph = (m->max_h + 15) / 16 * 16;
+    // worst-case slab: every component at full resolution, padded to the largest MCU there is (sampling factor 4 = 32 pixels)
+    const size_t pw = (m->max_w + 31) / 32 * 32, ph = (m->max_h + 31) / 32 * 32;
     m->coef_stride = pw * ph * 3;
     m->plane_stride = pw * ph * 3;
     m->rgb_stride = ((size_t)m->max_w * m->max_h * 3 + 15) & ~(size_t)15;

@@ -315,7 +315,8 @@ struct ufd_model {
   uint32_t iv_cap = 0;      // restart intervals per batch
   bool stem_fusable = false;          // layer 0 can run as k_stem_planes_mfma
   bool rfb_tail = false;              // the three dilated RFB convs + the summed 1x1 run as ONE launch (k_rfb_tail)
-  bool plan_parallel = false;         // UFD_PLAN_PARALLEL=1 at ufd_create: header scan + staging copy on the pool (A/B knob)
+  bool plan_parallel = false;         // UFD_PLAN_PARALLEL=1 at ufd_create: header scan + staging copy on the pool (A/B knob, experiments build)
+  uint32_t force_sub_floor = 0;       // UFD_FLAG_SUBSEQ_32 / _64: the entropy decoder's subsequence size forced (0 = the host plan's choice)
   bool gpu_entropy_enabled = true;   // device entropy kernels for baseline single-scan streams
   std::vector<float*> tap_buf;        // UFD_FLAG_TAP_LAYERS: per tensor, a copy taken right after its producing launch
 

@@ -572,7 +572,7 @@ void tap_outputs(ufd_model* m, int i, uint32_t count, hipStream_t st) {
 static bool ablated(int i) {
   static const std::vector<int> skip = [] {
     std::vector<int> v;
-    if (const char* e = std::getenv("UFD_ABLATE_LAYERS"))
+    if (const char* e = experiment_env("UFD_ABLATE_LAYERS"))
       for (const char* p = e; *p;) {
         v.push_back(std::atoi(p));
         while (*p && *p != ',') p++;

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/ufd.h"
+#include "experiments.hpp"
 #include "model_internal.hpp"
 
 namespace {
@@ -98,9 +99,13 @@ int replicas(const ufd_config* cfg, const int32_t* device_ids, uint32_t n, ufd_m
     set_create_error("ufd_create_replicas: variant must be 640 or 320");
     return UFD_E_ARG;
   }
-  // (UFD_TEST_DUPLICATE_DEVICES: tests/cpp/replicas_test.cpp lists the one GPU of its box twice so that the n = 2 group of
+  if (const char* knob = stray_experiment_knob()) {
+    set_create_error(std::string(knob) + " is set, but this build of libufacehip has no experiment hooks (make EXPERIMENTS=1 builds the one that has)");
+    return UFD_E_ARG;
+  }
+  // (UFD_FLAG_TEST_DUPLICATE_DEVICES: tests/cpp/replicas_test.cpp lists the one GPU of its box twice so that the n = 2 group of
   // ncclBroadcasts below executes at all without a second GPU -- if RCCL forms a communicator with two ranks on one device)
-  const bool allow_dup = std::getenv("UFD_TEST_DUPLICATE_DEVICES") != nullptr;
+  const bool allow_dup = (cfg->flags & UFD_FLAG_TEST_DUPLICATE_DEVICES) != 0;
   for (uint32_t i = 0; i < n && !allow_dup; i++)
     for (uint32_t j = 0; j < i; j++)
       if (device_ids[i] == device_ids[j]) {

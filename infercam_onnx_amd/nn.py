@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libufacehip.so")
+# (UFD_LIBRARY: the measurement build `make EXPERIMENTS=1` leaves beside it, for tools/ab -- never a CPU stand-in)
+LIB_PATH = os.environ.get("UFD_LIBRARY") or os.path.join(_HERE, "libufacehip.so")
 
 UFD_OK = 0
 UFD_E_ARG, UFD_E_DECODE, UFD_E_UNSUPPORTED, UFD_E_TRUNCATED = -1, -2, -3, -4
@@ -24,6 +25,7 @@ UFD_FLAG_NO_NUMA_PIN = 256
 UFD_FLAG_SPIN_WAIT = 1024
 UFD_FLAG_NO_RFB_TAIL = 2048
 UFD_FLAG_NO_DUAL = 512
+UFD_FLAG_SUBSEQ_32, UFD_FLAG_SUBSEQ_64, UFD_FLAG_TEST_DUPLICATE_DEVICES = 4096, 8192, 16384
 UFD_MAX_REPLICAS = 64
 UFD_SCHED_NO_WAIT = 0xFFFFFFFF
 UFD_PARITY_EXACT, UFD_PARITY_LABELS_UNPINNED = 0, 1

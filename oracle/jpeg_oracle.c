@@ -12,9 +12,11 @@
  *
  * Supported: 8-bit baseline/extended-sequential Huffman (SOF0/SOF1) and progressive Huffman
  * (SOF2; the reference's own test pictures, tests/integration_tests.rs:20-31), 1 or 3
- * components, any sampling factors that libjpeg's fancy/box upsamplers handle for
- * h in {1,2}, v in {1,2} relative to the max factor, restart intervals, Annex-K default
- * tables for DHT-less MJPEG.
+ * components, every sampling layout jdsample.c takes (integral expansion factors 1..4: fancy
+ * h2v1 / h2v2 / h1v2, plain replication for everything else, e.g. 4:1:1 and 4:1:0; at most 10
+ * blocks per interleaved MCU, jdinput.c per_scan_setup), YCbCr / RGB / grey colour spaces by
+ * libjpeg's marker rules, restart intervals, Annex-K default tables for DHT-less MJPEG.
+ * Pinned on all of these by streams libjpeg-turbo wrote and decoded: tests/golden/jpeg_layouts.npz.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -330,6 +332,11 @@ static int decode_scan(dec_t* d, const scan_t* sc, const uint8_t* p, const uint8
     comp_t* c = &d->comp[sc->ci[0]];
     nx = (c->dw + 7) / 8;
     ny = (c->dh + 7) / 8;
+  }
+  if (interleaved) { /* jdinput.c per_scan_setup: JERR_BAD_MCU_SIZE above D_MAX_BLOCKS_IN_MCU = 10 */
+    int blocks = 0;
+    for (int i = 0; i < sc->ns; i++) blocks += d->comp[sc->ci[i]].h * d->comp[sc->ci[i]].v;
+    if (blocks > 10) return UFO_E_DECODE;
   }
   for (int i = 0; i < sc->ns; i++) {
     if (!d->progressive || sc->ss == 0) {

@@ -52,9 +52,9 @@ int main(int argc, char** argv) {
   cfg.weights_floats = wbytes.size() / 4;
   if (argc > 4 && std::string(argv[4]) == "dup") {
     // The n = 2 form of the broadcast on a ONE-GPU box: device 0 listed twice (the library lets that through only under
-    // UFD_TEST_DUPLICATE_DEVICES).  RCCL may refuse two ranks on one device: then the outcome is printed, not failed --
+    // UFD_FLAG_TEST_DUPLICATE_DEVICES).  RCCL may refuse two ranks on one device: then the outcome is printed, not failed --
     // the point is to execute ncclCommInitAll + the group of two ncclBroadcasts if the runtime allows it at all.
-    setenv("UFD_TEST_DUPLICATE_DEVICES", "1", 1);
+    cfg.flags |= UFD_FLAG_TEST_DUPLICATE_DEVICES;
     int32_t ids[2] = {0, 0};
     ufd_model* h2[2] = {nullptr, nullptr};
     const int rc2 = ufd_create_replicas(&cfg, ids, 2, h2);

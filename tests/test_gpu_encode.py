@@ -294,3 +294,20 @@ def test_annotate_mixed_frame_sizes_and_flavours_in_one_batch(weights):
             assert status == [0] * len(frames)
             for j, d, s in zip(frames, dets, streams):
                 assert s == _expected_stream(j, d, label)
+
+
+def test_annotate_frames_of_the_other_libjpeg_layouts(weights):
+    """Round 6: 4:1:1, 4:1:0, 4:4:0 and RGB-colourspace camera frames (libjpeg-turbo-written fixtures) through the whole
+    `Inferer::run` iteration -- decode (generic upsampler), detect, draw, re-encode: streams equal the oracle's."""
+    from test_oracle_jpeg import layout_fixtures
+
+    fx = layout_fixtures()
+    frames = [fx["411_640x480"][0]["base"], fx["410_640x480"][0]["prog"], fx["440_640x480"][0]["dri_row"],
+              fx["rgb_adobe0_320x240"][0]["base"], fx["411_321x243"][0]["base"], fx["y11c22_150x100"][0]["base"]]
+    priors = synth.gen_priors(320, 240)
+    with _model(320, weights, max_batch=8, max_src=(640, 480), det_cap=4420) as m:
+        dets, status, streams = m.annotate_jpeg_batch(frames, (1280, 720))
+        assert status == [0] * len(frames)
+        for j, d, s in zip(frames, dets, streams):
+            assert_dets_match(dets_array(d), oracle.infer_jpeg(j, 320, 240, weights, priors), what="annotate layouts")
+            assert s == _expected_stream(j, d, (1280, 720))

@@ -355,7 +355,7 @@ sys.path.insert(0, %r)
 from infercam_onnx_amd import nn, synth
 w = synth.synthetic_weights()
 m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=w, priors=synth.gen_priors(320, 240), max_batch=2,
-                      max_src=(1280, 960), device_entropy=True)
+                      max_src=(1280, 960), device_entropy=True, extra_flags=int(sys.argv[1]))
 h = hashlib.sha256()
 for i, (wd, ht, kw) in enumerate([(640, 480, {}), (640, 480, {"quality": 30}), (641, 479, {"quality": 100}), (320, 240, {"optimize": True}),
                                   (17, 9, {}), (1280, 720, {"quality": 60})]):
@@ -370,16 +370,17 @@ print("floor-hash", h.hexdigest())
 def test_sync_decoder_subsequence_floor_does_not_change_a_pixel():
     """The self-synchronising decoder cuts a frame's stream into subsequences of >= 64 bytes when the batch fills the GPU
     with lanes anyway, >= 32 bytes for a frame or a few at a time (model.cpp, sub_floor: 167 -> 129 us of entropy chain for
-    ONE 640x480 frame).  The same frames decoded one at a time under both floors (UFD_SUB_SMALL_BYTES forces either), each in a
+    ONE 640x480 frame).  The same frames decoded one at a time under both floors (UFD_FLAG_SUBSEQ_32 / _64 force either), each in a
     process of its own: identical pixels (against the oracle: the single-frame tests above run under the 32-byte floor, the
     batch tests and bench.py's `verified` under the 64-byte one)."""
     import subprocess
     import sys
 
     hashes = []
-    for thr in ("0", "100000000"):
-        env = dict(os.environ, UFD_SUB_SMALL_BYTES=thr)
-        r = subprocess.run([sys.executable, "-c", _FLOOR_SCRIPT % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    from infercam_onnx_amd import nn
+
+    for flag in (nn.UFD_FLAG_SUBSEQ_64, nn.UFD_FLAG_SUBSEQ_32):
+        r = subprocess.run([sys.executable, "-c", _FLOOR_SCRIPT % ROOT, str(flag)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "floor-hash" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
         hashes.append(r.stdout.split("floor-hash")[1].split()[0])
     assert hashes[0] == hashes[1], hashes
@@ -929,3 +930,72 @@ def test_table_set_and_tap_caches_evict(weights, oracle_lib):
         assert any(n.startswith("huff_write") for n in names), names  # the device entropy path stayed in use
     finally:
         model.close()
+
+
+# ---------------------------------------------------------------- A1: every layout libjpeg-turbo decodes (round 6)
+def _layout_fixtures():
+    from test_oracle_jpeg import layout_fixtures
+
+    return layout_fixtures()
+
+
+def _check_layout_stream(m, oracle_lib, name, kind, jpeg, rgb, sha):
+    from test_oracle_jpeg import check_pixels
+
+    got = m.debug_decode_jpeg(jpeg)
+    ref = oracle_lib.jpeg_decode_rgb(jpeg)
+    assert got.shape == ref.shape and np.array_equal(got, ref), "%s/%s: %d samples differ from the oracle" % (name, kind, (got != ref).sum())
+    check_pixels(name, kind, got, rgb, sha)  # ... and from what libjpeg-turbo itself decoded
+
+
+@pytest.mark.parametrize("path", ["host_entropy", "device_entropy", "default"])
+def test_every_libjpeg_layout_on_the_gpu(model320, model320_dev, model320_auto, oracle_lib, path):
+    """`turbojpeg::decompress_image` (inferer.rs:35) is libjpeg-turbo: it takes any integral sampling layout.  The 237
+    libjpeg-turbo-written streams of tests/golden/jpeg_layouts.npz (4:4:0, 4:1:1, 4:1:0, 4:4:1, 3x1 ..., luma coarser
+    than chroma, a rate per chroma plane, RGB colour space by marker rules, grey with a 2x2 SOF; baseline / two restart
+    layouts / progressive / optimised tables) decode on the GPU to the oracle's and to libjpeg-turbo's pixels, with the
+    entropy stage on the host workers, on the device, and wherever the product's default routing sends it."""
+    m = {"host_entropy": model320, "device_entropy": model320_dev, "default": model320_auto}[path]
+    n = 0
+    for name, (streams, rgb, sha) in sorted(_layout_fixtures().items()):
+        for kind, jpeg in streams.items():
+            _check_layout_stream(m, oracle_lib, name, kind, jpeg, rgb, sha)
+            n += 1
+    assert n == 237
+
+
+def test_layouts_take_the_device_entropy_decoder(weights, oracle_lib):
+    """Baseline 4:1:1 / 4:1:0 (10 blocks per MCU) / 4:4:0 / RGB-colourspace frames are decoded by the self-synchronising
+    DEVICE decoder, not by the host fallback (the profile shows huff_write and no coefficient upload), mixed in one batch
+    with a 4:2:0 frame; detections equal the oracle's."""
+    from infercam_onnx_amd import synth
+
+    fx = _layout_fixtures()
+    m = make_model(640, weights, max_batch=8, profile=True)
+    try:
+        jpegs = [fx["411_640x480"][0]["base"], fx["410_640x480"][0]["dri_row"], fx["440_640x480"][0]["base"],
+                 synth.encode_jpeg(synth.synth_frame(21, 1120, 640, 480)), fx["rgb_adobe0_320x240"][0]["base"],
+                 fx["rgb_420_320x240"][0]["dri_row"], fx["y11c22_150x100"][0]["base"], fx["gray_sof22_67x45"][0]["base"]]
+        res, st = m.infer_jpeg_batch(jpegs)
+        names = {p["name"] for p in m.profile_read() if p["launches"] > 0}
+        assert st == [0] * len(jpegs) and "huff_write" in names and "h2d_coef" not in names, (st, sorted(names))
+        pri = synth.gen_priors(640, 480)
+        for j, r in zip(jpegs, res):
+            x = oracle_lib.normalize_nchw(oracle_lib.resize_triangle(oracle_lib.jpeg_decode_rgb(j), 640, 480))
+            scores, _ = oracle_lib.forward(x, weights, pri)
+            assert_dets_match(dets_array(r), oracle_lib.infer_jpeg(j, 640, 480, weights, pri, 0.5, 0.5), scores=scores)
+    finally:
+        m.close()
+
+
+def test_layouts_libjpeg_refuses_are_decode_errors_on_the_gpu_path(model320_auto):
+    """Fractional expansion and more than 10 blocks per MCU: libjpeg-turbo fails, the reference panics (inferer.rs:35-36);
+    the product skips the frame with a status and the frames beside it are untouched."""
+    from infercam_onnx_amd import nn, synth
+    from test_oracle_jpeg import _patch_sof
+
+    good = synth.encode_jpeg(synth.synth_frame(3, 0, 64, 48), subsampling="4:4:4")
+    bad = [_patch_sof(_patch_sof(good, 0, 0x31), 1, 0x21), _patch_sof(_patch_sof(good, 0, 0x42), 1, 0x21)]
+    res, status = model320_auto.infer_jpeg_batch([good, bad[0], bad[1], good])
+    assert status[0] == 0 and status[3] == 0 and res[0] == res[3]
+    assert status[1] in (nn.UFD_E_UNSUPPORTED, nn.UFD_E_DECODE) and status[2] == nn.UFD_E_DECODE and res[1] is None and res[2] is None

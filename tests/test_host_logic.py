@@ -131,6 +131,33 @@ def test_variant_mirror_and_loud_failure_without_gpu(weights):
         assert e.value.code == nn.UFD_E_DEVICE and "no CPU fallback" in str(e.value)
 
 
+def test_experiment_knobs_in_the_environment_are_refused_not_obeyed(weights):
+    """The measurement knobs of docs/EXPERIMENTS.md (UFD_ABLATE_LAYERS skips layers, UFD_REPEAT_ENTROPY / UFD_EXTEND_ROUNDS
+    change the decode chain ...) exist only in the `make EXPERIMENTS=1` build; the library that ships refuses to create a
+    handle while one is set -- it used to obey them silently, so a variable left in a server's environment changed results
+    with every call still returning UFD_OK (round-5 advisor finding)."""
+    import ctypes
+    from infercam_onnx_amd import nn
+
+    L = nn.load_library()
+    for knob in ("UFD_ABLATE_LAYERS", "UFD_REPEAT_ENTROPY", "UFD_EXTEND_ROUNDS", "UFD_SUB_SMALL_BYTES", "UFD_TEST_DUPLICATE_DEVICES"):
+        os.environ[knob] = "1"
+        try:
+            with pytest.raises(nn.UfdError) as e:
+                nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights)
+            assert e.value.code == nn.UFD_E_ARG and knob in str(e.value) and "EXPERIMENTS=1" in str(e.value)
+            cfg, keep = nn.UltrafaceModel._config(nn.UltrafaceVariant.W320H240, 0.5, 0.5, weights=weights)
+            out = (ctypes.c_void_p * 2)()
+            assert L.ufd_create_replicas(ctypes.byref(cfg), (ctypes.c_int32 * 1)(0), 1, out) == nn.UFD_E_ARG
+            assert knob in (L.ufd_last_error(None) or b"").decode() and out[0] is None
+        finally:
+            del os.environ[knob]
+    src = "".join(open(os.path.join(ROOT, "infercam_onnx_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "infercam_onnx_amd", "csrc"))
+                  if f.endswith((".cpp", ".hip", ".hpp")) and f != "experiments.hpp")
+    import re
+    assert set(re.findall(r'getenv\("(\w+)"\)', src)) <= {"XDG_CACHE_HOME", "HOME"}, "a knob outside experiments.hpp"
+
+
 def test_synthetic_inputs_are_deterministic():
     from infercam_onnx_amd import synth
 

@@ -72,3 +72,82 @@ def test_mjpg_without_dht(oracle_lib, subsampling):
         c0, w0, h0 = nn.jpeg_coefficients(jpeg)
         c1, w1, h1 = nn.jpeg_coefficients(bare)
         assert (w0, h0) == (w1, h1) == (320, 240) and np.array_equal(c0, c1)
+
+
+# ---------------------------------------------------------------- every layout libjpeg-turbo decodes (tests/golden/jpeg_layouts.npz)
+def layout_fixtures():
+    """{name: ({kind: jpeg bytes}, rgb array or None, sha256 hex or None)} from tools/make_layout_golden.py: streams libjpeg-turbo
+    2.1.2 WROTE (sampling factors / colour space set in comp_info: 4:4:0, 4:1:1, 4:1:0, 4:4:1, 3x, chroma finer than luma,
+    RGB colour space ...) and the pixels libjpeg-turbo 3.1.x DECODES them to."""
+    z = np.load(os.path.join(G, "jpeg_layouts.npz"))
+    out = {}
+    for k in z.files:
+        name, kind = k.split("/")
+        e = out.setdefault(name, [{}, None, None])
+        if kind == "rgb":
+            e[1] = z[k]
+        elif kind == "sha256":
+            e[2] = z[k].tobytes().hex()
+        else:
+            e[0][kind] = z[k].tobytes()
+    return out
+
+
+def check_pixels(name, kind, got, rgb, sha):
+    if rgb is not None:
+        assert got.shape == rgb.shape and np.array_equal(got, rgb), "%s/%s: %d samples differ" % (name, kind, (got != rgb).sum())
+    else:
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == sha, "%s/%s" % (name, kind)
+
+
+def test_every_libjpeg_layout_bit_exact(oracle_lib):
+    """4:4:0 (h1v2 fancy), 4:1:1 / 4:1:0 / 4:4:1 and the other integral expansions (plain replication, jdsample.c
+    int_upsample), luma coarser than chroma, RGB-colourspace streams by libjpeg's marker rules -- as baseline, with two
+    restart layouts, progressive and with optimised tables: the oracle gives libjpeg-turbo's pixels on all 237 streams."""
+    fx = layout_fixtures()
+    assert len(fx) == 53 and sum(len(v[0]) for v in fx.values()) == 237
+    for name, (streams, rgb, sha) in sorted(fx.items()):
+        for kind, jpeg in streams.items():
+            check_pixels(name, kind, oracle_lib.jpeg_decode_rgb(jpeg), rgb, sha)
+
+
+def test_product_host_decoder_takes_every_layout():
+    """The product's host entropy decoder (no GPU needed) no longer refuses expansion factors above 2: every fixture
+    stream parses, and the five entropy codings of one layout give the SAME coefficient slab (that is what makes their
+    pixels equal)."""
+    from infercam_onnx_amd import nn
+
+    for name, (streams, _, _) in sorted(layout_fixtures().items()):
+        ref = None
+        for kind, jpeg in streams.items():
+            coef, w, h = nn.jpeg_coefficients(jpeg)
+            assert "%dx%d" % (w, h) == name.rsplit("_", 1)[1]
+            assert ref is None or np.array_equal(coef, ref), "%s/%s" % (name, kind)
+            ref = coef
+
+
+def _patch_sof(jpeg, comp, hv):
+    i = 2
+    while jpeg[i + 1] not in (0xC0, 0xC1, 0xC2):
+        i += 2 + ((jpeg[i + 2] << 8) | jpeg[i + 3])
+    b = bytearray(jpeg)
+    b[i + 11 + 3 * comp] = hv
+    return bytes(b)
+
+
+def test_layouts_libjpeg_refuses_are_errors(oracle_lib):
+    """Fractional expansion (hmax not a multiple of a component's factor: jdsample.c JERR_FRACT_SAMPLE_NOTIMPL) and more
+    than 10 blocks in an interleaved MCU (jdinput.c JERR_BAD_MCU_SIZE) fail in libjpeg-turbo, so `decompress_image`'s
+    `expect` panics (inferer.rs:35-36): the oracle and the product's host decoder return an error, never pixels."""
+    from PIL import Image
+    from infercam_onnx_amd import nn, synth
+
+    jpeg = synth.encode_jpeg(synth.synth_frame(3, 0, 64, 48), subsampling="4:4:4")
+    for bad in (_patch_sof(_patch_sof(jpeg, 0, 0x31), 1, 0x21),   # hmax 3, chroma 2: fractional
+                _patch_sof(_patch_sof(jpeg, 0, 0x42), 1, 0x21)):  # 8 + 2 + 1 = 11 blocks
+        with pytest.raises(Exception):
+            Image.open(io.BytesIO(bad)).convert("RGB")
+        with pytest.raises(oracle_lib.OracleError):
+            oracle_lib.jpeg_decode_rgb(bad)
+        with pytest.raises(nn.UfdError):
+            nn.jpeg_coefficients(bad)

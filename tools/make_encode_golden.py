@@ -32,9 +32,13 @@ STRUCT_SIZE = 584        # sizeof(struct jpeg_compress_struct), v8 ABI, LP64 (jp
 OFF_IMAGE_WIDTH = 48     # image_width, image_height, input_components, in_color_space
 OFF_INPUT_GAMMA = 64
 OFF_COMP_INFO = 104
+OFF_NUM_COMPONENTS = 92
+OFF_OPTIMIZE_CODING = 296
 OFF_DCT_METHOD = 312
+OFF_RESTART_INTERVAL = 316   # unsigned restart_interval (MCUs), int restart_in_rows
 OFF_WRITE_JFIF = 324
-JCS_RGB = 2
+OFF_WRITE_ADOBE = 336
+JCS_GRAYSCALE, JCS_RGB, JCS_YCBCR = 1, 2, 3
 JDCT_ISLOW, JDCT_IFAST = 0, 1
 
 
@@ -49,12 +53,18 @@ class TurboEncoder:
         for f in ("jpeg_set_defaults", "jpeg_finish_compress", "jpeg_destroy_compress"):
             getattr(L, f).argtypes = [vp]
         L.jpeg_set_quality.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.jpeg_set_colorspace.argtypes = [vp, ctypes.c_int]
+        L.jpeg_simple_progression.argtypes = [vp]
         L.jpeg_start_compress.argtypes = [vp, ctypes.c_int]
         L.jpeg_write_scanlines.argtypes = [vp, vp, ctypes.c_uint]
         L.jpeg_write_scanlines.restype = ctypes.c_uint
         self.L = L
 
-    def encode(self, rgb, quality=95, dct=JDCT_IFAST):
+    def encode(self, rgb, quality=95, dct=JDCT_IFAST, samp=None, colorspace=None, restart_mcus=0, restart_rows=0,
+               progressive=False, optimize=False, write_jfif=None, write_adobe=None):
+        """samp: [(h, v)] * 3 sampling factors written into comp_info (any layout libjpeg accepts, not only tjCompress2's
+        five); colorspace: JCS_* of the stream (None = YCbCr; JCS_RGB writes component ids R, G, B and an Adobe marker
+        with transform 0 instead of JFIF); write_jfif / write_adobe override which of the two markers is written."""
         L = self.L
         h, w, _ = rgb.shape
         rgb = np.ascontiguousarray(rgb, np.uint8)
@@ -72,10 +82,28 @@ class TurboEncoder:
         assert struct.unpack_from("i", cinfo, OFF_DCT_METHOD)[0] == JDCT_ISLOW
         assert cinfo.raw[OFF_WRITE_JFIF:OFF_WRITE_JFIF + 12] == bytes([1, 0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 0])
         comp = struct.unpack_from("Q", cinfo, OFF_COMP_INFO)[0]
-        samp = [tuple(ctypes.cast(comp + 96 * c + 8, ctypes.POINTER(ctypes.c_int))[0:2]) for c in range(3)]
-        assert samp == [(2, 2), (1, 1), (1, 1)], samp  # jpeg_set_colorspace(YCbCr) default = 4:2:0 = TJSAMP_420
+        dflt = [tuple(ctypes.cast(comp + 96 * c + 8, ctypes.POINTER(ctypes.c_int))[0:2]) for c in range(3)]
+        assert dflt == [(2, 2), (1, 1), (1, 1)], dflt  # jpeg_set_colorspace(YCbCr) default = 4:2:0 = TJSAMP_420
+        if colorspace is not None:
+            L.jpeg_set_colorspace(cinfo, colorspace)  # (resets the sampling factors to 1x1 for RGB)
+        assert struct.unpack_from("i", cinfo, OFF_NUM_COMPONENTS)[0] == 3
+        assert struct.unpack_from("Ii", cinfo, OFF_RESTART_INTERVAL) == (0, 0) and struct.unpack_from("i", cinfo, OFF_OPTIMIZE_CODING)[0] == 0
+        assert struct.unpack_from("i", cinfo, OFF_WRITE_ADOBE)[0] == (1 if colorspace == JCS_RGB else 0)
+        if samp is not None:
+            for c, (sh, sv) in enumerate(samp):
+                p = ctypes.cast(comp + 96 * c + 8, ctypes.POINTER(ctypes.c_int))
+                p[0], p[1] = sh, sv
         L.jpeg_set_quality(cinfo, quality, 1)
         struct.pack_into("i", cinfo, OFF_DCT_METHOD, dct)
+        struct.pack_into("Ii", cinfo, OFF_RESTART_INTERVAL, restart_mcus, restart_rows)
+        if optimize:
+            struct.pack_into("i", cinfo, OFF_OPTIMIZE_CODING, 1)
+        if write_jfif is not None:
+            struct.pack_into("i", cinfo, OFF_WRITE_JFIF, int(write_jfif))
+        if write_adobe is not None:
+            struct.pack_into("i", cinfo, OFF_WRITE_ADOBE, int(write_adobe))
+        if progressive:
+            L.jpeg_simple_progression(cinfo)
         L.jpeg_start_compress(cinfo, 1)
         rows = (ctypes.c_void_p * h)(*[rgb.ctypes.data + y * 3 * w for y in range(h)])
         done = 0
