@@ -70,3 +70,37 @@ def test_forward_per_layer_against_live_torch(oracle_lib, weights, blob):
         acts[i] = y
         ref = y[0].numpy()
         assert np.abs(outs[i] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0), "layer %d %s" % (i, s.name)
+
+
+def test_reference_boxes_if_pinned(oracle_lib):
+    """tools/pin_reference.py writes tests/golden/reference_boxes.npz the day the zoo files (nn.rs:21-22) can be had: the
+    oracle's detections on the reference's eight pictures with the REAL weights, after asserting the reference's own face
+    counts (integration_tests.rs:20-29).  With that file and the .onnx in the cache path, every later oracle build must
+    reproduce them; without them the test reports that the pin is still open."""
+    import json
+    from helpers import REFERENCE_PINS
+    from infercam_onnx_amd import nn, synth
+
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    npz = os.path.join(G, "reference_boxes.npz")
+    if not os.path.exists(npz):
+        REFERENCE_PINS["reference_boxes"] = "NOT CHECKED (tests/golden/reference_boxes.npz not written yet: tools/pin_reference.py)"
+        pytest.skip("no zoo weights have been seen yet")
+    z = np.load(npz)
+    meta = json.load(open(os.path.join(G, "test_pics.json")))
+    checked = 0
+    for variant, (W, H) in ((640, (640, 480)), (320, (320, 240))):
+        path = os.path.join(os.environ.get("XDG_CACHE_HOME", os.path.expanduser("~/.cache")), "infercam_onnx", "ultraface-RFB-%d.onnx" % variant)
+        if "sha256_%d" % variant not in z.files or not os.path.exists(path):
+            continue
+        w, pri = nn.load_onnx(path, variant)
+        pri = pri if pri is not None else synth.gen_priors(W, H)
+        for f, info in meta.items():
+            got = np.asarray(oracle_lib.infer_jpeg(open(os.path.join(G, "test_pics", f), "rb").read(), W, H, w, pri, 0.5, 0.5), np.float32).reshape(-1, 5)
+            if variant == 640:
+                assert len(got) == info["reference_face_count"], f
+            assert got.shape == z["%d/%s" % (variant, f)].shape and np.allclose(got, z["%d/%s" % (variant, f)], atol=1e-6), f
+            checked += 1
+    if not checked:
+        pytest.skip("reference_boxes.npz is there but the .onnx files are not in the cache path")
+    REFERENCE_PINS["reference_boxes"] = "checked: %d pictures" % checked

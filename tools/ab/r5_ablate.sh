@@ -6,6 +6,8 @@
 set -u
 name=$1; shift
 cd $GRAFT_REPO_ROOT
+# (round 6: the knob exists only in the measurement build)
+make -s -C infercam_onnx_amd/csrc EXPERIMENTS=1 -j16 && export UFD_LIBRARY=$PWD/infercam_onnx_amd/libufacehip_exp.so || exit 1
 mkdir -p gpurun_out/$name
 for r in 1 2; do
   for s in "$@"; do
