@@ -88,6 +88,7 @@ typedef struct ufd_config {
 #define UFD_FLAG_NO_RFB_TAIL 2048u /* the RFB's dilated convs and its summed 1x1 as two launches (concat tensor in memory) instead of k_rfb_tail */
 #define UFD_FLAG_SUBSEQ_32 4096u   /* device entropy decoder: 32-byte subsequences whatever the batch holds (the host plan picks 32 for a */
 #define UFD_FLAG_SUBSEQ_64 8192u   /* frame or a few, 64 otherwise; same coefficients either way) ... or 64-byte ones */
+#define UFD_FLAG_NO_GATE 32768u    /* no cross-context order of the network's GPU-filling stretch (csrc/pipeline_gate.cpp); same results */
 #define UFD_FLAG_TEST_DUPLICATE_DEVICES 16384u /* ufd_create_replicas only: let one device be listed twice (a one-GPU box rehearsing n = 2) */
 /* Host placement: by default the handle's issue workers and pool threads are pinned to the CPUs of the NUMA node the GPU
  * hangs off (/sys/bus/pci/devices/<bdf>/numa_node), inside the process's affinity mask -- eight handles on a two-socket

@@ -9,7 +9,7 @@ namespace ufd {
 
 inline const char* const* experiment_knobs() {
   static const char* const k[] = {"UFD_ABLATE_LAYERS", "UFD_REPEAT_ENTROPY", "UFD_EXTEND_ROUNDS", "UFD_SUB_SMALL_BYTES", "UFD_PLAN_PARALLEL",
-                                  "UFD_NO_DUAL",       "UFD_BAND_SMALL",     "UFD_TEST_DUPLICATE_DEVICES", nullptr};
+                                  "UFD_NO_DUAL",       "UFD_BAND_SMALL",     "UFD_TEST_DUPLICATE_DEVICES", "UFD_GATE_LAYER", nullptr};
   return k;
 }
 

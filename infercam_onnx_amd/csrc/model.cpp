@@ -176,8 +176,12 @@ int get_taps(ufd_model* m, int sw, int sh, ResizeTaps* vert, ResizeTaps* horz) {
 
 // ---------------------------------------------------------------- GPU stages
 // [count][3][H][W] in d_input (or the sample planes, fused stem) -> every conv output the heads need.
-void enqueue_forward(ufd_model* m, uint32_t count) {
-  for (int i = 0; i < kNumConv; i++) enqueue_layer(m, i, count);
+void enqueue_forward(ufd_model* m, uint32_t count, Slot* s = nullptr) {
+  if (s) gate_wait_for_previous(m, *s, tl_cur->stream);
+  for (int i = 0; i < kNumConv; i++) {
+    enqueue_layer(m, i, count);
+    if (s) gate_pass(m, *s, i, tl_cur->stream);
+  }
   tl_cur->last_forward_count = count;
 }
 
@@ -320,6 +324,7 @@ Slot* find_free_slot(ufd_model* m) {
       s.job_jpegs = nullptr, s.job_lens = nullptr, s.job_staged = nullptr;
       s.annot = false, s.annot_ran = false;
       s.state = 0;
+      s.seq = 0, s.gate_published = false;
       s.span_idx = -1;
       s.relaxed_wait = false;
       return &s;
@@ -801,7 +806,7 @@ int run_decoded(ufd_model* m, Slot& s, uint32_t count, bool any_ok, const JpegFr
         }
       }
     }
-    enqueue_forward(m, count);
+    enqueue_forward(m, count, &s);
     if (fused_stem) tl_cur->stem_descs = nullptr;  // (the stem was the last reader of the descriptors / planes of this buffer)
     enqueue_heads(m, count);
     enqueue_nms(m, s, count);
@@ -939,6 +944,7 @@ void worker_main(ufd_model* m, Worker* w) {
     } catch (...) {
       rc = m->fail(UFD_E_DEVICE, "unknown exception");
     }
+    gate_close(m, *s);
     w->ns_busy.fetch_add(now_ns() - t_busy0, std::memory_order_relaxed);
     w->launches.fetch_add(tl_launches - launches0, std::memory_order_relaxed);
     w->batches.fetch_add(1, std::memory_order_relaxed);
@@ -1034,6 +1040,7 @@ void destroy(ufd_model* m) {
     if (s.h_enc_meta) (void)hipHostFree(s.h_enc_meta);
     if (s.enc_copied) (void)hipEventDestroy(s.enc_copied);
   }
+  gate_destroy(m);
   for (auto& pe : m->prof_pending) m->prof_free.push_back(pe.e0), m->prof_free.push_back(pe.e1);
   for (auto e : m->prof_free) (void)hipEventDestroy(e);
   for (Ctx& c : m->ctx) {
@@ -1109,6 +1116,10 @@ int create(const ufd_config* cfg, ufd_model** out) {
   // Four contexts = four streams = the runtime's four hardware queues, one each (a fifth stream would share a queue with
   // a context and serialise with its kernels: no copy stream, see k_stage_in above).
   for (int ci = 0; ci < m->num_ctx; ci++) HIPB(hipStreamCreateWithFlags(&m->ctx[ci].stream, hipStreamNonBlocking));
+  if (gate_init(m) != UFD_OK) {
+    m->err = "hipEventCreate failed (pipeline gate)";
+    return bail(UFD_E_DEVICE);
+  }
 
   // ---- weights + priors
   std::vector<float> blob, priors;
@@ -1370,6 +1381,7 @@ static int submit_common(ufd_model* m, const uint8_t* const* jpegs, const size_t
     if (annot) s->annot_args = *annot;
     s->ctx = w.ctx;
     s->busy = true;
+    s->seq = m->next_seq++, s->gate_published = false;
     s->ticket = m->next_ticket++;
     if (!m->next_ticket) m->next_ticket = 1;
     *ticket = s->ticket;

@@ -15,6 +15,12 @@ int ensure_encoder(ufd_model* m, Ctx& c, uint32_t quality, bool multipart, uint3
 int ensure_slot_encoder(ufd_model* m, Slot& s, uint32_t mw, uint32_t mh);
 int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32_t mw, uint32_t mh, uint32_t count);
 int fetch_streams(ufd_model* m, Slot& s);
+// pipeline_gate.cpp: batch n + 1 starts its network behind batch n's GPU-filling stretch
+int gate_init(ufd_model* m);
+void gate_destroy(ufd_model* m);
+void gate_wait_for_previous(ufd_model* m, const Slot& s, hipStream_t st);
+void gate_pass(ufd_model* m, Slot& s, int layer, hipStream_t st);
+void gate_close(ufd_model* m, Slot& s);
 // model.cpp: an event that marks a copy (an empty kernel between the two: ROCm 7.2 keeps ~2 KB per event recorded directly behind a copy)
 hipError_t record_behind_copy(hipEvent_t ev, hipStream_t stream);
 

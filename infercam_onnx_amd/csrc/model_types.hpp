@@ -157,6 +157,18 @@ struct Slot {
   int issue_rc = 0;          // result of the worker's entropy stage + enqueue
   std::string issue_err;
   int state = 0;             // 0 free, 1 queued for the worker, 2 issued to the GPU (guarded by Worker::mu)
+  uint64_t seq = 0;          // submission order over the whole handle (0: a synchronous call) -- pipeline_gate.cpp
+  bool gate_published = false;
+};
+
+// Cross-context order of the GPU-filling stretch (pipeline_gate.cpp).
+constexpr int kGateDefaultLayer = 8;  // m4.pw, the end of the m3->m4 launch: measured, tools/ab/r6_gate.py
+struct PipelineGate {
+  static constexpr int kRing = 64;  // > batches in flight (slots) by a wide margin
+  int layer = -1;                   // < 0: off
+  hipEvent_t ev[kRing] = {};
+  std::atomic<uint64_t> published[kRing];
+  std::atomic<uint64_t> waits{0}, timeouts{0};
 };
 
 struct Worker {
@@ -322,6 +334,8 @@ struct ufd_model {
 
   Slot slots[UFD_MAX_SLOTS];
   uint32_t next_ticket = 1;
+  uint64_t next_seq = 1;   // Slot::seq of the next asynchronous batch
+  PipelineGate gate;
 
   std::map<std::pair<int, int>, std::pair<TapsDev, TapsDev>> taps;
 

@@ -25,7 +25,7 @@ UFD_FLAG_NO_NUMA_PIN = 256
 UFD_FLAG_SPIN_WAIT = 1024
 UFD_FLAG_NO_RFB_TAIL = 2048
 UFD_FLAG_NO_DUAL = 512
-UFD_FLAG_SUBSEQ_32, UFD_FLAG_SUBSEQ_64, UFD_FLAG_TEST_DUPLICATE_DEVICES = 4096, 8192, 16384
+UFD_FLAG_SUBSEQ_32, UFD_FLAG_SUBSEQ_64, UFD_FLAG_TEST_DUPLICATE_DEVICES, UFD_FLAG_NO_GATE = 4096, 8192, 16384, 32768
 UFD_MAX_REPLICAS = 64
 UFD_SCHED_NO_WAIT = 0xFFFFFFFF
 UFD_PARITY_EXACT, UFD_PARITY_LABELS_UNPINNED = 0, 1
