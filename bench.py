@@ -35,7 +35,7 @@ ROOF_STEPS = 48             # steps of the fully sampled roofline pass (every la
 # bench kernel label -> device function name (as rocprofv3 --kernel-trace --stats prints it)
 KERNEL_FUNCS = {
     "conv_pw_mfma": "k_pw_mfma",
-    "conv_dwpw_mfma": "k_dwpw_mfma",
+    "conv_dwpw_mfma": "k_dwpw_mfma", "conv_dwpw_mfma_sk8": "k_dwpw_mfma_sk8",
     "conv_dwpw2_mfma": "k_dwpw2_mfma",
     "conv3x3_mfma": "k_conv3x3_mfma",
     "conv3x3_rows_mfma": "k_conv3x3_rows_mfma",
@@ -53,7 +53,7 @@ KERNEL_FUNCS = {
     "sort_nms": "k_sort_nms", "conv_dual_coop": "k_dual_dwpw_coop", "conv_dual_pw": "k_dual_dwpw_pw",
     "nms_matrix": "k_nms_matrix", "nms_scan": "k_nms_scan", "rfb_tail": "k_rfb_tail",
 }
-MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual_coop", "conv_dual_pw",
+MFMA_KERNELS = ("conv_pw_mfma", "conv_dwpw_mfma", "conv_dwpw_mfma_sk8", "conv_dwpw2_mfma", "conv_dwpw_coop", "conv_dual_coop", "conv_dual_pw",
                 "stem_planes_mfma", "conv3x3_mfma", "conv3x3_rows_mfma", "rfb_tail")
 
 
@@ -600,6 +600,7 @@ def main():
         model.profile_reset()
         run_steps(ROOF_STEPS, primary_staged)
         extras["kernel_stats_loaded"] = model.profile_read()
+        extras["launch_shapes"] = model.profile_shapes()
         model.profile_sampling(1 << 30)
     if world == 1 and not args.no_extras and not host_only:
         # ---- the same workload over the other boundary
@@ -874,6 +875,10 @@ def main():
             gpu_ms = sum(v["ms"] for v in kern.values())
             out["gpu_ms_per_step"] = round(gpu_ms / ksteps, 3)
             out["kernels_ms_per_step"] = {k: round(v["ms"] / ksteps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if extras.get("launch_shapes"):
+            # how every launch of a batch sits on the GPU: workgroups as issued, workgroups a CU holds at once (registers, LDS:
+            # the runtime's occupancy query), rounds over the 256 CUs and how full the last one is (ufd_profile_shapes)
+            out["launch_shapes"] = {s.pop("name"): s for s in extras["launch_shapes"]}
         dump = os.environ.get("UFD_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:

@@ -407,6 +407,15 @@ int ufd_profile_reset(ufd_model* m);
  * (~100 timestamp packets per batch) out of a timed run while still sampling it. */
 int ufd_profile_sampling(ufd_model* m, uint32_t every_n);
 int ufd_profile_read(ufd_model* m, ufd_kernel_stat* stats, uint32_t cap, uint32_t* n);
+/* How each profiled launch sits on the GPU (DESIGN.md's kernel table, tools/design_table.py): the shape of the label's
+ * last launch as the library issued it, the kernel's registers per lane and LDS per workgroup (static + dynamic), and the
+ * workgroups one compute unit holds at once by the runtime's own occupancy query -- so
+ *   slots = compute_units * resident_per_cu,  rounds = workgroups / slots. */
+typedef struct ufd_launch_shape {
+  char name[48];
+  uint32_t workgroups, threads, lds_bytes, registers, resident_per_cu, compute_units;
+} ufd_launch_shape;
+int ufd_profile_shapes(ufd_model* m, ufd_launch_shape* shapes, uint32_t cap, uint32_t* n);
 
 /* ---- measurement (bench.py `host` object): what the HOST side of the asynchronous pipeline costs, always on (a handful
  * of clock reads and two event records per batch; no UFD_FLAG_PROFILE needed).  The reference has one blocking task

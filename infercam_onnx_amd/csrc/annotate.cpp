@@ -202,7 +202,7 @@ int enqueue_annotate(ufd_model* m, Slot& s, const JpegFrameDesc* d_descs, uint32
         ((at.allocationFlags & hipHostMallocPortable) || at.device == m->cfg.device_id)) {
       const uint32_t cap16 = (uint32_t)std::min<size_t>(s.annot_args.jpeg_cap >> 4, 0xFFFFFFFFu);
       ProfScope ps(m, "d2h_streams", 0, 0);
-      hipLaunchKernelGGL(k_fetch_streams, dim3(256), dim3(256), 0, c.stream, reinterpret_cast<const uint4*>(s.d_enc_out),
+      ufd_launch(k_fetch_streams, dim3(256), dim3(256), 0, c.stream, reinterpret_cast<const uint4*>(s.d_enc_out),
                          s.d_enc_meta + 2 * m->B, static_cast<uint4*>(at.devicePointer), cap16);
       s.annot_fetched = true;
     } else {

@@ -171,7 +171,7 @@ __device__ __forceinline__ void put_bias_lds(float* s_bias, float b) {
 // a conditional source (`i < nA ? a[i] : b[i - nA]`) a branch with a wait of its own per piece: the prologue of every block
 // was 5-11 dependent memory round trips (~1 us each under load) on waves that live 17-30 us.  Loads past the end repeat
 // the last piece (no branch around a load: behind one the wait counters are not statically known and every wait is for all).
-template <int U, typename PutA, typename PutB>
+template <int U, int NTHR = 256, typename PutA, typename PutB>
 __device__ __forceinline__ void copy_tables16(const float* __restrict__ srcA, int nA, PutA&& putA, const float* __restrict__ srcB, int nB, PutB&& putB) {
   const float4* a4 = reinterpret_cast<const float4*>(srcA);
   const float4* b4 = reinterpret_cast<const float4*>(srcB);
@@ -180,12 +180,12 @@ __device__ __forceinline__ void copy_tables16(const float* __restrict__ srcA, in
     float4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int i = min(i0 + 256 * u, n - 1);
+      const int i = min(i0 + NTHR * u, n - 1);
       v[u] = *(i < nA ? a4 + i : b4 + (i - nA));
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int i = i0 + 256 * u;
+      const int i = i0 + NTHR * u;
       if (i < nA) putA(i, v[u]);
       else if (i < n) putB(i - nA, v[u]);
     }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void copy_tables16(const float* __restrict__ srcA, in
   // (the first trip -- the only one for most tables -- outside the loop: in front of a loop hipcc waits for every load in
   // flight, the caller's prefetched input windows included, before the loop's own loads are even requested)
   trip((int)threadIdx.x);
-  for (int i0 = threadIdx.x + 256 * U; i0 < n + (int)threadIdx.x; i0 += 256 * U) trip(i0);  // (block-uniform trip count)
+  for (int i0 = threadIdx.x + NTHR * U; i0 < n + (int)threadIdx.x; i0 += NTHR * U) trip(i0);  // (block-uniform trip count)
 }
 template <int U>
 __device__ __forceinline__ void copy_table16(float* dst, const float* __restrict__ src, int n4) {
@@ -221,8 +221,38 @@ __device__ __forceinline__ void init_acc(const float* s_bias, floatx16 (&acc)[CT
 // the input channels; partial accumulators of waves 1..3 go through LDS and wave 0 adds them in
 // fixed order (deterministic) before the epilogue.  Used where a launch has too few wave tiles to
 // fill the chip (feature maps <= 30x40), so the serial k-chain per wave is 4x shorter.
-template <int CT>
+// SK = 8 (round 6, a frame or a few at a time: eight waves per tile, the chain an eighth): a tree in fixed order -- wave w adds
+// wave w + 4's partial tile (w = 0..3), then w + 2's (w = 0, 1), then wave 0 adds wave 1's -- through four tile buffers (64 KB):
+// three barrier pairs instead of seven.  The sum's order differs from SK = 4's (fp32 rounding, as between SK = 1 and 4).
+template <int CT, int SK = 4>
 __device__ __forceinline__ void splitk_reduce(floatx16 (&acc)[CT][4], float* red, int wave, int lane) {
+  if (SK == 8) {
+    constexpr int kTile = CT * 4 * 16 * 64;  // floats of one partial tile
+#pragma unroll 1
+    for (int half = SK / 2; half >= 1; half >>= 1) {
+      if (wave >= half && wave < 2 * half) {
+        float* dst = red + (wave - half) * kTile;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[((ct * 4 + j) * 16 + r) * 64 + lane] = acc[ct][j][r];
+      }
+      __syncthreads();
+      if (wave < half) {
+        const float* src = red + wave * kTile;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ct][j][r] += src[((ct * 4 + j) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // one partial tile at a time through a single 16 KiB buffer: fixed order w = 1, 2, 3
   // (deterministic), barriers keep the compiler from hoisting 192 LDS reads into registers
 #pragma unroll 1
@@ -486,8 +516,8 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
     float4* wdst = reinterpret_cast<float4*>(s_w);
     const int n4 = a.cin * 3;
     const float bv = bias_for_lds<CT>(a, ct0);
-    copy_tables16<3>(a.w2, n4, [&](int i, float4 v) { put_dw_variants(ddst, n4, i, v); },
-                     a.w + (size_t)ct0 * ksteps * 64, CT * ksteps * 16, [&](int i, float4 v) { wdst[i] = v; });
+    copy_tables16<3, (SK == 8 ? 512 : 256)>(a.w2, n4, [&](int i, float4 v) { put_dw_variants(ddst, n4, i, v); },
+                                            a.w + (size_t)ct0 * ksteps * 64, CT * ksteps * 16, [&](int i, float4 v) { wdst[i] = v; });
     put_bias_lds<CT>(s_bias, bv);
   }
   __syncthreads();
@@ -532,7 +562,7 @@ __device__ __forceinline__ void dwpw_mfma_body(const ConvArgs& a, int bx) {
     }
   }
   if (SK > 1) {
-    splitk_reduce<CT>(acc, s_red, wave, lane);
+    splitk_reduce<CT, SK>(acc, s_red, wave, lane);
     if (wave > 0) return;
   }
   if (live) store_tiles<CT>(a, acc, ct0, half, frame, oy * a.ow + ox, ohw);
@@ -541,6 +571,14 @@ template <int CT, int S, int D, int SK>
 __global__ __launch_bounds__(256) void k_dwpw_mfma(ConvArgs3 p3) {
   const ConvArgs a = p3.a[blockIdx.y];  // (a copy: every field the body reads is requested in one go at the top)
   dwpw_mfma_body<CT, S, D, SK>(a, (int)blockIdx.x);
+}
+// Split-K over EIGHT waves (512 threads) for launches of a few dozen blocks -- a frame or a few at a time, where a launch
+// lasts as long as one wave's walk of its chain (0.45 us per k-step: issue of 4 MFMAs + the depthwise arithmetic on a
+// SIMD the wave has to itself) and most CUs are empty anyway.  One conv per launch (n = 1).
+template <int S>
+__global__ __launch_bounds__(512) void k_dwpw_mfma_sk8(ConvArgs3 p3) {
+  const ConvArgs a = p3.a[0];
+  dwpw_mfma_body<1, S, 2, 8>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2171,7 +2209,7 @@ void launch_stem_planes_mfma(const StemArgs& sa0, hipStream_t s) {
   a.band = band;
   const long groups = (long)a.B * ((a.oh / band) * a.ow / 4);
   const size_t shmem = (9 * 64 + 768 + 256 + 4 * 512) * sizeof(float);  // weights, normalisation table, a row of zeros, exchange buffers
-  hipLaunchKernelGGL(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
+  ufd_launch(k_stem_planes_mfma, dim3((unsigned)((groups + 4L * 14 - 1) / (4L * 14))), dim3(256), shmem, s, sa);
 }
 
 void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
@@ -2190,19 +2228,19 @@ void launch_conv3x3_rows_mfma(const ConvArgs* args, int n, hipStream_t s) {
   bool mixed = false;
   for (int i = 1; i < n; i++) mixed = mixed || args[i].dil != a.dil;
   if (mixed) {  // (stride 1, dilations <= 8: conv3x3_rows_supported)
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 0>), grid(2), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<1, 0>), grid(2), dim3(256), shmem, s, p);
     return;
   }
   if (a.stride == 2) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<2, 1>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 1) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 1>), grid(1), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<1, 1>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 2) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 2>), grid(1), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<1, 2>), grid(1), dim3(256), shmem, s, p);
   } else if (a.dil == 3) {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 3>), grid(1), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<1, 3>), grid(1), dim3(256), shmem, s, p);
   } else {
-    hipLaunchKernelGGL((k_conv3x3_rows_mfma<1, 5>), grid(2), dim3(256), shmem, s, p);
+    ufd_launch((k_conv3x3_rows_mfma<1, 5>), grid(2), dim3(256), shmem, s, p);
   }
 }
 
@@ -2258,7 +2296,7 @@ void launch_rfb_tail(const ConvArgs* dil3, const ConvArgs& fin, hipStream_t s) {
   const long groups = (long)fin.B * (fin.oh * fin.ow / 4);
   const unsigned blocks = (unsigned)(((groups + 4L * kTailNG - 1) / (4L * kTailNG) + 7) / 8 * 8);
   const size_t lds = rfb_tail_packed_floats() * sizeof(float);  // 28 KB
-  hipLaunchKernelGGL(k_rfb_tail, dim3(blocks), dim3(256), lds, s, t);
+  ufd_launch(k_rfb_tail, dim3(blocks), dim3(256), lds, s, t);
 }
 
 bool dwpw_supported(const ConvArgs& a, int stride) {
@@ -2326,13 +2364,13 @@ static PwConfig pw_config(const ConvArgs* args, int n) {
 void launch_conv_pointwise_mfma(const ConvArgs* args, int n, hipStream_t s) {
   const PwConfig c = pw_config(args, n);
   if (c.sk && c.ksteps % 16 != 0)  // (a quarter of the chain is not a multiple of four k-steps: ring depth 2)
-    hipLaunchKernelGGL((k_pw_mfma<1, 2, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+    ufd_launch((k_pw_mfma<1, 2, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
   else if (c.sk)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+    ufd_launch((k_pw_mfma<1, 4, 4>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
   else if (c.ksteps % 4 == 0)
-    hipLaunchKernelGGL((k_pw_mfma<1, 4, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+    ufd_launch((k_pw_mfma<1, 4, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
   else
-    hipLaunchKernelGGL((k_pw_mfma<1, 1, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
+    ufd_launch((k_pw_mfma<1, 1, 1>), dim3(c.gx, c.gy), dim3(256), c.lds, s, c.p);
 }
 
 // Template instance the launchers above / below pick for a launch, as rocprofv3 prints it behind the kernel name
@@ -2369,8 +2407,16 @@ struct DwpwConfig {
   unsigned gx, gy;
   size_t lds;
   bool sk, deep;
+  bool sk8;  // the split over eight waves (k_dwpw_mfma_sk8): one conv, at most kSk8MaxBlocks blocks
 };
-static DwpwConfig dwpw_config(const ConvArgs* args, int n) {
+constexpr long kSk8MaxBlocks = 128;  // half the CUs: beyond that the 64 KB of reduction LDS per block starts to cost other work its place
+// Measured, one 640x480 frame (profiles/r6c/batch1_timeline_640.txt against r5d's): chains of 64 and 128 k-steps gain -- m9 / m10
+// 12.1 -> 10.7 us, m12 18.3 -> 15.4 -- chains of 32 (m5, m6: 9.0 -> 9.3) and the stride-2 blocks (m8 9.4 -> 10.0, m11 12.7 -> 13.3)
+// do not: below ~8 k-steps per wave a launch is its 4.6 us floor, its table copy and the reduction.  Hence: stride 1, >= 64 k-steps.
+static bool want_sk8(bool sk, int n, long blocks, int ksteps, int stride) {
+  return sk && n == 1 && stride == 1 && ksteps >= 64 && blocks <= kSk8MaxBlocks;
+}
+static DwpwConfig dwpw_config(const ConvArgs* args, int n, int sk8_stride = 0 /* the depthwise stride of a launch that may take the eight-wave split; 0: it may not */) {
   DwpwConfig c{};
   const ConvArgs& r = args[0];
   const long groups = (long)r.B * (r.oh * r.ow / 4);
@@ -2379,8 +2425,9 @@ static DwpwConfig dwpw_config(const ConvArgs* args, int n) {
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
   c.sk = want_splitk(wave_tiles, max_cts * n, ksteps);
+  c.sk8 = sk8_stride > 0 && want_sk8(c.sk, n, wave_tiles * max_cts, ksteps, sk8_stride);
   c.deep = ksteps % 4 == 0;
-  c.lds = ((size_t)kBiasLds + (size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float) + (c.sk ? kSplitKBytes : 0);
+  c.lds = ((size_t)kBiasLds + (size_t)r.cin * 36 + (size_t)ksteps * 64) * sizeof(float) + (c.sk8 ? 4 * kSplitKBytes : (c.sk ? kSplitKBytes : 0));
   unsigned grid = 1;
   for (int i = 0; i < n; i++) {
     c.p.a[i] = args[i];
@@ -2421,17 +2468,23 @@ void launch_conv_dwpw_mfma(const ConvArgs* args, int n, int stride, hipStream_t 
     void (*kernel)(ConvArgs3) = stride == 1 ? (c.ctw == 4 ? k_dwpw_coop<1, 4> : k_dwpw_coop<1, 2>)
                                              : (c.ctw == 4 ? k_dwpw_coop<2, 4> : k_dwpw_coop<2, 2>);
     if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, dim3(c.blocks, 1), dim3(256), c.lds, s, c.p);
+    ufd_launch(kernel, dim3(c.blocks, 1), dim3(256), c.lds, s, c.p);
     return;
   }
-  const DwpwConfig c = dwpw_config(args, n);
+  const DwpwConfig c = dwpw_config(args, n, stride);
   const dim3 g(c.gx, c.gy);
   // (the three copies of the depthwise table of a 256-channel layer need more than the default
   // 64 KB of dynamic LDS: raised once per instantiation)
   auto launch = [&](void (*kernel)(ConvArgs3)) {
     if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, g, dim3(256), c.lds, s, c.p);
+    ufd_launch(kernel, g, dim3(256), c.lds, s, c.p);
   };
+  if (c.sk8) {
+    void (*kernel)(ConvArgs3) = k_dwpw_mfma_sk8<1>;
+    if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
+    ufd_launch(kernel, dim3(c.gx, 1), dim3(512), c.lds, s, c.p);
+    return;
+  }
   if (c.sk) {
     if (stride == 1) launch(k_dwpw_mfma<1, 1, 2, 4>);
     else launch(k_dwpw_mfma<1, 2, 2, 4>);
@@ -2509,7 +2562,7 @@ bool launch_conv_dual(const ConvArgs* a, int na, int a_stride, const ConvArgs* b
   DualChoice c;
   if (!choose_dual(a, na, a_stride, b, b_stride, &c)) return false;
   if (c.lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(c.kernel));
-  hipLaunchKernelGGL(c.kernel, dim3(c.blocks), dim3(256), c.lds, s, c.q);
+  ufd_launch(c.kernel, dim3(c.blocks), dim3(256), c.lds, s, c.q);
   return true;
 }
 
@@ -2527,7 +2580,10 @@ const char* conv_dwpw_instance(const ConvArgs* args, int n, int stride) {
   int max_cts = 1;
   for (int i = 0; i < n; i++) max_cts = std::max(max_cts, (args[i].cout + 31) / 32);
   if (dwpw_uses_coop(args, n)) return stride == 1 ? (max_cts % 4 == 0 ? "<1, 4>" : "<1, 2>") : (max_cts % 4 == 0 ? "<2, 4>" : "<2, 2>");
-  if (want_splitk(wave_tiles, max_cts * n, ksteps)) return stride == 1 ? "<1, 1, 2, 4>" : "<1, 2, 2, 4>";
+  if (want_splitk(wave_tiles, max_cts * n, ksteps)) {
+    if (want_sk8(true, n, wave_tiles * max_cts, ksteps, stride)) return "_sk8<1>";  // (dwpw_config's sk8)
+    return stride == 1 ? "<1, 1, 2, 4>" : "<1, 2, 2, 4>";
+  }
   const bool deep = ksteps % 4 == 0;
   return stride == 1 ? (deep ? "<1, 1, 2, 1>" : "<1, 1, 1, 1>") : (deep ? "<1, 2, 2, 1>" : "<1, 2, 1, 1>");
 }
@@ -2585,7 +2641,7 @@ void launch_conv_dwpw2_mfma(const ConvArgs& first, const ConvArgs& second, hipSt
   auto launch = [&](void (*kernel)(ConvArgs3), bool ring) {
     if (ring) lds += (size_t)4 * 2 * (first.cin / 2) * 64 * sizeof(float4);
     if (lds > 64 * 1024) allow_large_lds(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, p);
+    ufd_launch(kernel, grid, dim3(256), lds, s, p);
   };
   if (first.cin == 16 && ct2 == 1) launch(k_dwpw2_mfma<16, 1, true>, true);
   else if (first.cin == 16) launch(k_dwpw2_mfma<16, 2, true>, true);
@@ -2601,29 +2657,29 @@ void launch_conv3x3_mfma(const ConvArgs* args, int n, hipStream_t s) {
   const unsigned ny = (unsigned)n;
   if (total >= 64L * 4 * 1024) {  // enough pixels to fill the chip with 4 groups per wave
     if (a.cin % 2 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<4, 2>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<4, 2>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<4, 1>), dim3((unsigned)((total + 255) / 256), ny), dim3(256), 0, s, p);
   } else {
     if (a.cin % 32 == 0 && a.cin >= 128 && total < 16384)  // few pixels, long channel chain: split-K
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8, 4>), dim3((unsigned)((total + 15) / 16), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<1, 8, 4>), dim3((unsigned)((total + 15) / 16), ny), dim3(256), 0, s, p);
     else if (a.cin % 8 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<1, 8>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
     else if (a.cin % 4 == 0)
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<1, 4>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL((k_conv3x3_mfma<1, 1>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
+      ufd_launch((k_conv3x3_mfma<1, 1>), dim3((unsigned)((total + 63) / 64), ny), dim3(256), 0, s, p);
   }
 }
 
 void launch_conv_direct(const ConvArgs& a, hipStream_t s) {
   const unsigned gx = (a.oh * a.ow + 255) / 256;
   if (a.depthwise) {
-    hipLaunchKernelGGL((k_conv_direct<1, true>), dim3(gx, a.cout, a.B), dim3(256), 0, s, a);
+    ufd_launch((k_conv_direct<1, true>), dim3(gx, a.cout, a.B), dim3(256), 0, s, a);
   } else if (a.cout >= 16) {
-    hipLaunchKernelGGL((k_conv_direct<16, false>), dim3(gx, (a.cout + 15) / 16, a.B), dim3(256), 0, s, a);
+    ufd_launch((k_conv_direct<16, false>), dim3(gx, (a.cout + 15) / 16, a.B), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_conv_direct<4, false>), dim3(gx, (a.cout + 3) / 4, a.B), dim3(256), 0, s, a);
+    ufd_launch((k_conv_direct<4, false>), dim3(gx, (a.cout + 3) / 4, a.B), dim3(256), 0, s, a);
   }
 }
 

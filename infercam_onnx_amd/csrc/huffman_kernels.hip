@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ufd {
 namespace {
@@ -50,12 +51,18 @@ struct SyncState {
   uint32_t cz;  // block inside the MCU | zigzag position << 8
 };
 
+struct SyncStepTabs {       // state-only passes (SyncLutImage::step_dc, step_ac): bits consumed (code + magnitude) | zigzag advance << 5
+  uint16_t dc[2][1024];
+  uint32_t ac[2][1024];     // low half: the symbol; high half: the symbol and the one behind it, or 0
+};
+struct SyncSymTabs {        // write pass (SyncLutImage::fast): (code length << 8) | symbol; 0 = code longer than 10 bits
+  uint16_t tab[4][1024];
+};
 template <bool kWrite>
 struct SyncTablesT {
   // (head and table: copied from the prebuilt per-table-set image, load_sync_tables)
   HuffSlow slow[4];
-  uint16_t tab[4][1024];   // state-only passes: bits consumed (code + magnitude) | zigzag advance << 5 (SyncLutImage::step);
-                           // write pass: (code length << 8) | symbol (SyncLutImage::fast); 0 = code longer than 10 bits
+  typename std::conditional<kWrite, SyncSymTabs, SyncStepTabs>::type t;
   uint32_t blk[12];        // per block of the MCU: comp | bx << 8 | by << 12 | dc << 16 | ac << 20
   uint32_t dc_bits, ac_bits;  // bit c = table slot (0/1) of block c of the MCU
   // coefficient offset of block c of MCU (mx, my): blk_base[c] + mx * blk_dx[c] + my * blk_dy[c]
@@ -141,18 +148,24 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
   int cur_t = z == 0 ? (int)((dc_bits >> c) & 1) : 2 + (int)((ac_bits >> c) & 1);
   int k = 1;                                                    // next boundary
   uint32_t next_cp = cp ? sub_start + part_bits : 0xFFFFFFFFu;  // (no checkpoints: never reached)
+  // Two symbols per look-up (round 6): an AC entry's high half covers the symbol AND the one behind it.  It is taken when the
+  // first of the two cannot end the block (zigzag index below 48: a run is at most 16) and both START in front of the
+  // walk's limit and of the next checkpoint boundary -- so every state the walk is asked for (exit state, checkpoints, MCU
+  // counts) is the one single steps give; pos + bits of both <= lim2 is sufficient for that.
+  uint32_t lim2 = min(limit, next_cp);
   // tables of the candidates: AC table of block c, DC table of the block behind it (and that block's index)
   int cn = c + 1 == bpm ? 0 : c + 1;
-  const uint16_t* tab_ac = T.tab[2 + (int)((ac_bits >> c) & 1)];
-  const uint16_t* tab_dcn = T.tab[(int)((dc_bits >> cn) & 1)];
+  const uint32_t* tab_ac = T.t.ac[(int)((ac_bits >> c) & 1)];
+  const uint16_t* tab_dcn = T.t.dc[(int)((dc_bits >> cn) & 1)];
   uint32_t top = bw.top();  // (init leaves >= 33 valid bits)
-  uint32_t e = T.tab[cur_t][top >> 22];
+  uint32_t e = cur_t < 2 ? (uint32_t)T.t.dc[cur_t][top >> 22] : (T.t.ac[cur_t - 2][top >> 22] & 0xFFFFu);
   while (pos < limit) {
     if (__builtin_expect(pos >= next_cp, 0)) {  // the symbol about to be decoded is the first one at / behind boundary k
       cp[k - 1] = make_uint2(pos, (uint32_t)c | ((uint32_t)z << 8));
       cpn[k - 1] = nmcu;
       k++;
       next_cp = k < kWriteParts ? next_cp + part_bits : 0xFFFFFFFFu;
+      lim2 = min(limit, next_cp);
       continue;  // (the entry may lie behind several boundaries)
     }
     if (__builtin_expect(e == 0, 0)) {
@@ -170,14 +183,16 @@ __device__ __forceinline__ int sync_span(const uint32_t* words, SyncState& st, u
     z += (int)(e >> 5);
     const bool be = z >= 64;  // block finished (some lane of the wave is here in almost every iteration: selects, no branch)
     nmcu += (be && cn == 0) ? 1 : 0;
-    e = be ? e_dc : e_ac;
+    const uint32_t e_two = e_ac >> 16;
+    const bool two = e_two != 0 && z < 48 && pos + (e_two & 31) <= lim2;
+    e = be ? e_dc : (two ? e_two : (e_ac & 0xFFFFu));
     cur_t = be ? (int)((dc_bits >> cn) & 1) : 2 + (int)((ac_bits >> c) & 1);
     c = be ? cn : c;
     z = be ? 0 : z;
     // the candidates of the symbol after that (they change at a block end only)
     cn = c + 1 == bpm ? 0 : c + 1;
-    tab_ac = T.tab[2 + (int)((ac_bits >> c) & 1)];
-    tab_dcn = T.tab[(int)((dc_bits >> cn) & 1)];
+    tab_ac = T.t.ac[(int)((ac_bits >> c) & 1)];
+    tab_dcn = T.t.dc[(int)((dc_bits >> cn) & 1)];
   }
   if (cp)
     for (; k < kWriteParts; k++) {  // boundaries behind the end of the walk
@@ -206,7 +221,7 @@ __device__ __forceinline__ void write_span(const uint32_t* words, SyncState st, 
   while (pos < limit) {
     bw.refill();
     const uint32_t top = bw.top();
-    int e = T.tab[cur_t][top >> 22];
+    int e = T.t.tab[cur_t][top >> 22];
     if (__builtin_expect(e == 0, 0)) {
       e = slow_symbol(T.slow[cur_t], top);
       if (!e) e = 1 << 8, *bad = true;
@@ -301,9 +316,12 @@ constexpr int kSyncLaneThreads = 256;  // seed / extend / write: one lane per (s
 constexpr int kHypSlots = 16;          // cached (entry -> exit) pairs per subsequence; nibble 15 = "not cached"
 constexpr int kHypAppendMax = 14;      // the speculation rounds fill slots 0..13, k_huff_resolve may use 14
 
-static_assert(sizeof(HuffSlow) % 16 == 0 && offsetof(SyncLutImage, step) == 4 * sizeof(HuffSlow) &&
-                  offsetof(SyncLutImage, fast) == offsetof(SyncLutImage, step) + sizeof(SyncLutImage::step) &&
-                  offsetof(SyncTables, tab) == offsetof(SyncLutImage, step) && offsetof(SyncTables, blk) == offsetof(SyncLutImage, fast),
+static_assert(sizeof(HuffSlow) % 16 == 0 && offsetof(SyncLutImage, step_dc) == 4 * sizeof(HuffSlow) &&
+                  offsetof(SyncLutImage, step_ac) == offsetof(SyncLutImage, step_dc) + sizeof(SyncLutImage::step_dc) &&
+                  offsetof(SyncLutImage, fast) == offsetof(SyncLutImage, step_ac) + sizeof(SyncLutImage::step_ac) &&
+                  offsetof(SyncTables, t) == offsetof(SyncLutImage, step_dc) && offsetof(SyncTables, blk) == offsetof(SyncLutImage, fast) &&
+                  offsetof(WriteTables, t) == offsetof(SyncLutImage, step_dc) &&
+                  offsetof(WriteTables, blk) == offsetof(WriteTables, t) + sizeof(SyncLutImage::fast) && sizeof(SyncStepTabs) % 16 == 0,
               "image layout");
 
 // Fills the block's tables: the head of the table-set image and its step (or symbol) tables with
@@ -312,8 +330,9 @@ static_assert(sizeof(HuffSlow) % 16 == 0 && offsetof(SyncLutImage, step) == 4 * 
 template <bool kWrite>
 __device__ __forceinline__ void load_sync_tables(SyncTablesT<kWrite>& T, const HuffScan& sc, const SyncLutImage* __restrict__ images,
                                                  const JpegFrameDesc* d, int tid, int nthreads) {
-  constexpr int kHead = (int)(offsetof(SyncLutImage, step) / 16), kVec = (int)(offsetof(SyncLutImage, fast) / 16);
-  constexpr int kSkip = kWrite ? (int)(sizeof(SyncLutImage::step) / 16) : 0;  // the write pass takes `fast` in place of `step`
+  constexpr int kHead = (int)(offsetof(SyncLutImage, step_dc) / 16);
+  constexpr int kSkip = kWrite ? (int)(sizeof(SyncStepTabs) / 16) : 0;  // the write pass takes `fast` in place of the step tables
+  constexpr int kVec = kHead + (int)((kWrite ? sizeof(SyncLutImage::fast) : sizeof(SyncStepTabs)) / 16);
   const uint4* src = reinterpret_cast<const uint4*>(images + sc.lut_base / 4);
   uint4* dst = reinterpret_cast<uint4*>(&T);
   if (nthreads == kSyncLaneThreads) {
@@ -1064,10 +1083,10 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
     if (hook && *hook) (*hook)(name, false);
   };
   stage("huff_unstuff", [&] {
-    hipLaunchKernelGGL(k_huff_unstuff, dim3(frames, 1 + zero_rows), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb, za);
+    ufd_launch(k_huff_unstuff, dim3(frames, 1 + zero_rows), dim3(kSyncThreads), 0, s, d_blob, d_scans, d_ivs, sb, za);
   });
   stage("huff_seed", [&] {
-    hipLaunchKernelGGL(k_huff_seed, dim3((nsub * max_blocks_per_mcu + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s,
+    ufd_launch(k_huff_seed, dim3((nsub * max_blocks_per_mcu + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s,
                        d_scans, d_luts, sb, cnt_a);
   });
   const dim3 gext((nsub * kHypSlots + kSyncLaneThreads - 1) / kSyncLaneThreads, frames);  // k_huff_link: 16 subsequences per block
@@ -1077,18 +1096,18 @@ void launch_huffman_sync(const uint8_t* d_blob, const HuffScan* d_scans, const H
   static const int rounds = experiment_env("UFD_EXTEND_ROUNDS") ? std::max(0, std::min(4, std::atoi(experiment_env("UFD_EXTEND_ROUNDS")))) : 2;
   uint8_t *cnt_in = cnt_a, *cnt_out = cnt_b;
   for (int r = 0; r < rounds; r++) {
-    stage("huff_extend", [&] { hipLaunchKernelGGL(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_in, cnt_out); });
+    stage("huff_extend", [&] { ufd_launch(k_huff_extend, gext2, ext_threads, 0, s, d_scans, d_luts, sb, (const uint8_t*)cnt_in, cnt_out); });
     std::swap(cnt_in, cnt_out);
   }
-  stage("huff_link", [&] { hipLaunchKernelGGL(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_in); });
+  stage("huff_link", [&] { ufd_launch(k_huff_link, gext, lanes, 0, s, sb, (const uint8_t*)cnt_in); });
   stage("huff_resolve", [&] {
-    hipLaunchKernelGGL(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_in, d_status);
+    ufd_launch(k_huff_resolve, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_ivs, d_luts, sb, cnt_in, d_status);
   });
   stage("huff_write", [&] {
-    hipLaunchKernelGGL(k_huff_write, dim3((nsub * kWriteParts + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
+    ufd_launch(k_huff_write, dim3((nsub * kWriteParts + kSyncLaneThreads - 1) / kSyncLaneThreads, frames), lanes, 0, s, d_scans, d_ivs,
                        d_luts, d_descs, sb, d_coef, coef_stride, d_status);
   });
-  stage("dc_prefix", [&] { hipLaunchKernelGGL(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, sb.dc, sb.dc_stride); });
+  stage("dc_prefix", [&] { ufd_launch(k_dc_prefix, dim3(frames), dim3(kSyncThreads), 0, s, d_scans, d_descs, sb.dc, sb.dc_stride); });
 }
 
 }  // namespace ufd

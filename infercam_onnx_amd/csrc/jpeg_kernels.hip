@@ -437,7 +437,7 @@ void launch_upsample_rgb_420(const JpegFrameDesc* d_descs, const uint8_t* d_plan
                              size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s) {
   if (!count) return;
   dim3 grid(((max_w / 8) * max_h + 255) / 256, count);
-  hipLaunchKernelGGL(k_upsample_rgb_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
+  ufd_launch(k_upsample_rgb_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
 }
 
 void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coef_stride, uint8_t* d_planes,
@@ -446,16 +446,16 @@ void launch_idct(const JpegFrameDesc* d_descs, const int16_t* d_coef, size_t coe
   if (!count || !max_blocks) return;
   dim3 grid((max_blocks + kBlocksPerWG - 1) / kBlocksPerWG, count);
   if (zigzag)
-    hipLaunchKernelGGL(k_idct<true>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
+    ufd_launch(k_idct<true>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
   else
-    hipLaunchKernelGGL(k_idct<false>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
+    ufd_launch(k_idct<false>, grid, dim3(256), 0, s, d_descs, d_coef, coef_stride, d_planes, plane_stride, d_dc, dc_stride);
 }
 
 void launch_upsample_rgb(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride, uint8_t* d_rgb,
                          size_t rgb_stride, uint32_t max_w, uint32_t max_h, uint32_t count, hipStream_t s) {
   if (!count) return;
   dim3 grid((max_w + 1023) / 1024, max_h, count);
-  hipLaunchKernelGGL(k_upsample_rgb, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
+  ufd_launch(k_upsample_rgb, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_rgb, rgb_stride);
 }
 
 void launch_upsample_norm_420(const JpegFrameDesc* d_descs, const uint8_t* d_planes, size_t plane_stride,
@@ -463,7 +463,7 @@ void launch_upsample_norm_420(const JpegFrameDesc* d_descs, const uint8_t* d_pla
                               hipStream_t s) {
   if (!count) return;
   dim3 grid(((W / 8) * H + 255) / 256, count);
-  hipLaunchKernelGGL(k_upsample_norm_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
+  ufd_launch(k_upsample_norm_420, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
                      (int)W, (int)H);
 }
 
@@ -472,7 +472,7 @@ void launch_upsample_norm(const JpegFrameDesc* d_descs, const uint8_t* d_planes,
                           hipStream_t s) {
   if (!count) return;
   dim3 grid((W + 1023) / 1024, H, count);
-  hipLaunchKernelGGL(k_upsample_norm, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
+  ufd_launch(k_upsample_norm, grid, dim3(256), 0, s, d_descs, d_planes, plane_stride, d_norm_lut, d_out,
                      (int)W, (int)H);
 }
 

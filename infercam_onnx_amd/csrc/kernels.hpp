@@ -12,6 +12,24 @@
 
 namespace ufd {
 
+// Every kernel launch of the library goes through ufd_launch: it notes the launch's shape (function, workgroups, threads,
+// dynamic LDS) in a thread-local that the profiling scope around it reads -- ufd_profile_shapes then reports, per profiled
+// label, how the launch sits on the GPU (registers and resident workgroups per CU from the runtime's own occupancy query).
+struct LaunchShape {
+  const void* fn = nullptr;
+  uint32_t blocks = 0, threads = 0, lds = 0;
+  uint32_t launches = 0;  // launches since the enclosing profiling scope opened
+};
+extern thread_local LaunchShape tl_launch_shape;
+template <typename... KArgs, typename... Args>
+inline void ufd_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+  LaunchShape& sh = tl_launch_shape;
+  sh.fn = reinterpret_cast<const void*>(kernel);
+  sh.blocks = grid.x * grid.y * grid.z, sh.threads = block.x * block.y * block.z, sh.lds = (uint32_t)lds;
+  sh.launches++;
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
+}
+
 // ---------------- A1: JPEG reconstruction (jpeg_kernels.hip) ----------------
 // Dequantise + ISLOW IDCT of every 8x8 block of `count` frames into u8 sample planes.
 // d_dc (device entropy decoder): DC term of block g of frame f at d_dc[f * dc_stride + g], overriding the slab's; or null.
@@ -48,7 +66,13 @@ struct HuffSlow {
 };
 struct SyncLutImage {
   HuffSlow slow[4];
-  uint16_t step[4][1024];
+  uint16_t step_dc[2][1024];  // state-only passes, DC tables: sync_step of the symbol behind this 10-bit window (0: code longer than 10 bits)
+  // ... AC tables: low half = the same for the AC symbol; high half (round 6) = the entry of this symbol AND THE NEXT ONE
+  // taken together -- bits consumed by both, zigzag advance of both -- when the first does not end the block and the
+  // second's CODE lies inside the window behind the first's code and magnitude bits (a state-only walk never looks at
+  // magnitude bits, so the second's may lie outside); 0: no such pair.  1.49 symbols per dependent look-up on the bench's
+  // frames instead of 1 (tools/huff_pair_sim.py).
+  uint32_t step_ac[2][1024];
   uint16_t fast[4][1024];
 };
 // State-only step of a symbol.  A DC symbol advances the zigzag index 0 -> 1, an AC coefficient by
@@ -67,7 +91,21 @@ inline void build_sync_lut_image(const HuffLut* luts /*[4]: dc0 dc1 ac0 ac1*/, S
     for (int i = 0; i < 1024; i++) {
       const int e = luts[t].fast[i];
       out->fast[t][i] = (uint16_t)e;
-      out->step[t][i] = e ? sync_step(e >> 8, e & 0xFF, t < 2) : (uint16_t)0;
+      const uint16_t one = e ? sync_step(e >> 8, e & 0xFF, t < 2) : (uint16_t)0;
+      if (t < 2) {
+        out->step_dc[t][i] = one;
+        continue;
+      }
+      uint32_t two = 0;
+      const int l1 = (one & 31), dz1 = one >> 5;  // code + magnitude bits, zigzag advance of the first symbol
+      if (one && dz1 < 64 && l1 < 10) {           // (an EOB ends the block: the symbol behind it is a DC symbol of another table)
+        const int e2 = luts[t].fast[(i << l1) & 1023];
+        if (e2 && (e2 >> 8) <= 10 - l1) {         // the second CODE is fully inside the window's known bits
+          const uint16_t s2 = sync_step(e2 >> 8, e2 & 0xFF, false);
+          two = (uint32_t)(l1 + (s2 & 31)) | ((uint32_t)(dz1 + (s2 >> 5)) << 5);
+        }
+      }
+      out->step_ac[t - 2][i] = (uint32_t)one | (two << 16);
     }
   }
 }
@@ -233,9 +271,19 @@ struct Det {
 // Frames with more than 256 (and at most 2048) candidates are finished by two more launches: their
 // suppression matrix over the whole GPU, then one wave per frame (d_mat: nms_matrix_bytes(B) of
 // scratch; nullptr keeps everything inside the first kernel).
+// host_out (a frame or a few at a time, round 6): the kernel also hands the frame's results to the slot's pinned host arrays
+// -- decode status, detection count, the first max_rows detections -- which was a launch of its own (k_results_out); with
+// d_mat == nullptr beside it the whole of A7-A10 is ONE launch instead of four.
+struct NmsHostOut {
+  const uint32_t* d_status = nullptr;  // device entropy decoder's per-frame flags, or null
+  uint32_t* h_status = nullptr;
+  uint32_t* h_ndet = nullptr;          // null: no host output from the kernel
+  float* h_dets = nullptr;
+  uint32_t max_rows = 0;
+};
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
-                     unsigned long long* d_mat, uint32_t B, hipStream_t s);
+                     unsigned long long* d_mat, uint32_t B, hipStream_t s, const NmsHostOut& host_out = NmsHostOut());
 size_t nms_matrix_bytes(uint32_t B, uint32_t K);
 
 // ---------------- N1: rectangles + JPEG re-encode (encode_kernels.hip, encode_host.cpp) ----------------

@@ -33,7 +33,7 @@ namespace {
 __global__ void k_copy_fence() {}
 }  // namespace
 hipError_t ufd::record_behind_copy(hipEvent_t ev, hipStream_t stream) {
-  hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, stream);
+  ufd_launch(k_copy_fence, dim3(1), dim3(64), 0, stream);
   return hipEventRecord(ev, stream);
 }
 namespace {
@@ -206,6 +206,20 @@ void enqueue_heads(ufd_model* m, uint32_t count, bool raw_outputs = false) {
 
 void enqueue_nms(ufd_model* m, Slot& s, uint32_t count) {
   ProfScope ps(m, "sort_nms", 0, 0);
+  // A frame or a few at a time (the batch goes in and out by kernels): ONE launch for A7-A10 and the way out -- every frame
+  // is finished inside k_sort_nms (a frame with more than 256 candidates by its in-kernel block loop instead of the
+  // matrix path's two extra launches, which a lone frame pays 4.6 us each for whether it needs them or not: 3 % of the
+  // bench's frames do), and the kernel writes statuses, counts and detections to the slot's pinned arrays itself.
+  if (s.small_batch && s.h_status_dev && s.h_dets_dev) {
+    NmsHostOut ho;
+    ho.d_status = s.gpu_entropy ? tl_cur->d_status : nullptr;
+    ho.h_status = s.h_status_dev, ho.h_ndet = s.h_status_dev + m->B;
+    ho.h_dets = reinterpret_cast<float*>(s.h_dets_dev), ho.max_rows = kDetCopy;
+    launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, s.d_dets, m->K, tl_cur->d_ndet,
+                    tl_cur->d_spill, nullptr, count, tl_cur->stream, ho);
+    s.results_in_nms = true;
+    return;
+  }
   launch_sort_nms(tl_cur->d_keys, m->key_stride, tl_cur->d_counts, tl_cur->d_boxes, m->K, m->cfg.max_iou, s.d_dets, m->K, tl_cur->d_ndet,
                   tl_cur->d_spill, tl_cur->d_nms_mat, count, tl_cur->stream);
 }
@@ -213,9 +227,11 @@ void enqueue_nms(ufd_model* m, Slot& s, uint32_t count) {
 int enqueue_results_copy(ufd_model* m, Slot& s, uint32_t count) {
   // [B decode statuses][B detection counts] are one allocation on both sides: one copy of B + count words (statuses past
   // `count` are stale and never read), or the counts alone when the host decoded the entropy stage
-  if (s.small_batch && s.h_status_dev && s.h_dets_dev) {
+  if (s.results_in_nms) {
+    s.results_in_nms = false;  // (k_sort_nms wrote them: enqueue_nms)
+  } else if (s.small_batch && s.h_status_dev && s.h_dets_dev) {
     static_assert(sizeof(Det) % 4 == 0, "Det is copied as words");
-    hipLaunchKernelGGL(k_results_out, dim3(count), dim3(256), 0, tl_cur->stream, s.gpu_entropy ? tl_cur->d_status : nullptr, tl_cur->d_ndet,
+    ufd_launch(k_results_out, dim3(count), dim3(256), 0, tl_cur->stream, s.gpu_entropy ? tl_cur->d_status : nullptr, tl_cur->d_ndet,
                        reinterpret_cast<const float*>(s.d_dets), (uint32_t)(sizeof(Det) / 4 * m->K), s.h_status_dev, s.h_status_dev + m->B,
                        reinterpret_cast<float*>(s.h_dets_dev), kDetCopy);
     tl_launches++;
@@ -325,6 +341,7 @@ Slot* find_free_slot(ufd_model* m) {
       s.annot = false, s.annot_ran = false;
       s.state = 0;
       s.seq = 0, s.gate_published = false;
+      s.results_in_nms = false;
       s.span_idx = -1;
       s.relaxed_wait = false;
       return &s;
@@ -603,7 +620,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
         ProfScope ps(m, "h2d_jpeg", (double)p.stage_bytes, 0, c.stream);
         if (s.h_stage_dev) {
           const uint32_t n16 = (uint32_t)((p.stage_bytes + 15) / 16);
-          hipLaunchKernelGGL(k_stage_in, dim3(std::min(256u, (n16 + 255) / 256)), dim3(256), 0, c.stream,
+          ufd_launch(k_stage_in, dim3(std::min(256u, (n16 + 255) / 256)), dim3(256), 0, c.stream,
                              reinterpret_cast<const uint4*>(s.h_stage_dev), reinterpret_cast<uint4*>(c.d_stage_buf[buf]), n16);
         } else {
           HIPC(m, hipMemcpyAsync(c.d_stage_buf[buf], s.h_stage, p.stage_bytes, hipMemcpyHostToDevice, c.stream));
@@ -650,7 +667,7 @@ int entropy_stage(ufd_model* m, Slot& s, const uint8_t* const* jpegs, const size
                              hipMemcpyHostToDevice, c.stream));
     // (span_begin records an event: never directly behind an asynchronous copy -- ROCm 7.2's runtime keeps ~2 KB of host memory
     // per such event, record_behind_copy above)
-    hipLaunchKernelGGL(k_copy_fence, dim3(1), dim3(64), 0, c.stream);
+    ufd_launch(k_copy_fence, dim3(1), dim3(64), 0, c.stream);
   }
   span_begin(s);
   return UFD_OK;

@@ -122,6 +122,7 @@ struct Slot {
   uint32_t* h_status_dev = nullptr;  // h_gpu_status / h_dets as device addresses (k_results_out)
   Det* h_dets_dev = nullptr;
   bool small_batch = false;         // this batch: staging block in and results out by kernels on the context's stream
+  bool results_in_nms = false;      // ... and the results were written by k_sort_nms itself (no k_results_out launch)
   uint8_t* h_stage_dev = nullptr;   // h_stage as a device address (pinned host memory the GPU reads directly: k_stage_in)
   uint8_t* h_blob = nullptr;        // = h_stage + blob_base of the batch (set by plan_device_entropy)
   HuffScan* h_scans = nullptr;
@@ -344,6 +345,7 @@ struct ufd_model {
   uint32_t prof_every = 1, prof_batch = 0;
   std::vector<std::string> prof_names;
   std::vector<ufd_kernel_stat> prof_stats;
+  std::vector<LaunchShape> prof_shapes;  // by name id: shape of the label's last launch (ufd_profile_shapes)
   std::vector<ProfEntry> prof_pending;
   std::vector<hipEvent_t> prof_free;
 
@@ -405,6 +407,7 @@ struct ProfScope {
       : m(mm), on(mm->profile && tl_prof), st(stream ? stream : tl_cur->stream) {
     tl_launches++;
     if (!on) return;
+    tl_launch_shape.launches = 0;
     {
       std::lock_guard<std::mutex> lk(m->shared_mu);
       pe.name_id = prof_name_id(m, name);
@@ -428,6 +431,10 @@ struct ProfScope {
     (void)hipEventRecord(pe.e1, st);
     std::lock_guard<std::mutex> lk(m->shared_mu);
     m->prof_pending.push_back(pe);
+    if (tl_launch_shape.launches) {  // shape of the (last) launch inside this scope: ufd_profile_shapes
+      if (m->prof_shapes.size() <= (size_t)pe.name_id) m->prof_shapes.resize(pe.name_id + 1);
+      m->prof_shapes[pe.name_id] = tl_launch_shape;
+    }
   }
 };
 

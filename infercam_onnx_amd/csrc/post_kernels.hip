@@ -178,7 +178,8 @@ __device__ __forceinline__ bool iou_exceeds(const float4 c, float area_c, const 
 __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restrict__ gkeys, size_t key_stride,
                                                   uint32_t* __restrict__ counts, const float* __restrict__ boxes,
                                                   int K, float max_iou, Det* __restrict__ dets, uint32_t det_stride,
-                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min, int mat_max) {
+                                                  uint32_t* __restrict__ ndet, float4* __restrict__ spill, int mat_min, int mat_max,
+                                                  NmsHostOut ho) {
   // One 40 KB block of LDS, carved twice.  Greedy path (frames the kernel finishes itself): 2048 sort keys | selected
   // boxes | the block's candidates | gathered boxes | block rows.  A frame with 2049..4096 candidates only sorts here
   // (it leaves for the matrix path): its 4096 key slots lie over the first four pieces, which it never uses.
@@ -441,6 +442,19 @@ __global__ __launch_bounds__(1024) void k_sort_nms(unsigned long long* __restric
     __syncthreads();
   }
   if (tid == 0) ndet[frame] = (uint32_t)s_nsel;
+  if (ho.h_ndet) {  // (launch-uniform) the frame's results straight into the slot's pinned host arrays: what k_results_out did
+    // (s_nsel and the detections in fd are complete: the barrier at the end of the last block, or the one behind the sort)
+    const uint32_t nd = (uint32_t)s_nsel;
+    if (tid == 0) {
+      ho.h_ndet[frame] = nd;
+      if (ho.d_status) ho.h_status[frame] = ho.d_status[frame];
+    }
+    constexpr uint32_t kW = (uint32_t)(sizeof(Det) / 4);
+    const uint32_t words = min(nd, ho.max_rows) * kW;
+    const float* src = reinterpret_cast<const float*>(fd);
+    float* dst = ho.h_dets + (size_t)frame * ho.max_rows * kW;
+    for (uint32_t i = tid; i < words; i += (uint32_t)nthr) dst[i] = src[i];
+  }
 }
 
 // Suppression matrix of a heavy frame: bit j of row i (i < j, sorted order) = "i, once selected,
@@ -664,28 +678,29 @@ void launch_head_decode(const HeadArgs& h, const float* d_priors, uint32_t B, fl
                         float* d_boxes, unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts,
                         hipStream_t s) {
   const int K = h.base[4];
-  hipLaunchKernelGGL(k_head_decode, dim3((K + 255) / 256, B), dim3(256), 0, s, h, d_priors, K, min_conf, d_scores,
+  ufd_launch(k_head_decode, dim3((K + 255) / 256, B), dim3(256), 0, s, h, d_priors, K, min_conf, d_scores,
                      d_boxes, d_keys, key_stride, d_counts);
 }
 
 void launch_threshold(const float* d_scores, uint32_t K, uint32_t B, float min_conf, unsigned long long* d_keys,
                       size_t key_stride, uint32_t* d_counts, hipStream_t s) {
-  hipLaunchKernelGGL(k_threshold, dim3((K + 255) / 256, B), dim3(256), 0, s, d_scores, (int)K, min_conf, d_keys,
+  ufd_launch(k_threshold, dim3((K + 255) / 256, B), dim3(256), 0, s, d_scores, (int)K, min_conf, d_keys,
                      key_stride, d_counts);
 }
 
 void launch_sort_nms(unsigned long long* d_keys, size_t key_stride, uint32_t* d_counts, const float* d_boxes,
                      uint32_t K, float max_iou, Det* d_dets, uint32_t det_stride, uint32_t* d_ndet, float4* d_sel_spill,
-                     unsigned long long* d_mat, uint32_t B, hipStream_t s) {
+                     unsigned long long* d_mat, uint32_t B, hipStream_t s, const NmsHostOut& host_out) {
   const int knob = kMatMin;
   const bool use_matrix = d_mat != nullptr && K > (uint32_t)knob;
   // (without the matrix scratch no frame is "heavy": mat_min = mat_max = 0 keeps everything in the first kernel)
-  hipLaunchKernelGGL(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
-                     d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : 0, use_matrix ? kMatMax : 0);
+  ufd_launch(k_sort_nms, dim3(B), dim3(1024), 0, s, d_keys, key_stride, d_counts, d_boxes, (int)K, max_iou,
+                     d_dets, det_stride, d_ndet, d_sel_spill, use_matrix ? knob : 0, use_matrix ? kMatMax : 0,
+                     use_matrix ? NmsHostOut() : host_out);  // (a frame the matrix path finishes has no results yet)
   if (!use_matrix) return;
   // (both return at once for frames the first kernel finished itself)
-  hipLaunchKernelGGL(k_nms_matrix, dim3(kMatGridRows, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
-  hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
+  ufd_launch(k_nms_matrix, dim3(kMatGridRows, kMatColGroups, B), dim3(256), 0, s, d_ndet, d_sel_spill, (int)K, max_iou, d_mat);
+  ufd_launch(k_nms_scan, dim3(B), dim3(256), 0, s, d_keys, key_stride, d_sel_spill, (int)K, d_mat, d_dets, det_stride,
                      d_ndet);
 }
 size_t nms_matrix_bytes(uint32_t B, uint32_t K) { return (size_t)B * mat_rows((int)K) * kMatWords * sizeof(unsigned long long); }

@@ -184,12 +184,12 @@ void launch_resize_norm(const uint8_t* d_src, uint32_t sw, uint32_t sh, uint32_t
   const size_t lds = ((size_t)max_rows * row_words + 4 * (size_t)row_words) * 4;
   if (max_rows <= kTileMaxRows && max_cols <= kTileMaxCols && vert.stride <= kTileMaxRows && lds <= 56 * 1024) {
     dim3 grid((dw + tw - 1) / tw, (dh + kTileRows - 1) / kTileRows, count);
-    hipLaunchKernelGGL(k_resize_norm_tiled<tw>, grid, dim3(tw), lds, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
+    ufd_launch(k_resize_norm_tiled<tw>, grid, dim3(tw), lds, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
                        d_norm_lut, d_out, (int)dw, (int)dh, row_words, max_rows);
     return;
   }
   dim3 grid((dw + 255) / 256, dh, count);
-  hipLaunchKernelGGL(k_resize_norm, grid, dim3(256), 0, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
+  ufd_launch(k_resize_norm, grid, dim3(256), 0, s, d_src, (int)sw, (int)sh, (int)pitch, src_stride, vert, horz,
                      d_norm_lut, d_out, (int)dw, (int)dh);
 }
 
@@ -197,7 +197,7 @@ void launch_norm_only(const uint8_t* d_src, uint32_t w, uint32_t h, uint32_t pit
                       const float* d_norm_lut, float* d_out, uint32_t count, hipStream_t s) {
   if (!count) return;
   dim3 grid((w + 255) / 256, h, count);
-  hipLaunchKernelGGL(k_norm_only, grid, dim3(256), 0, s, d_src, (int)w, (int)h, (int)pitch, src_stride, d_norm_lut,
+  ufd_launch(k_norm_only, grid, dim3(256), 0, s, d_src, (int)w, (int)h, (int)pitch, src_stride, d_norm_lut,
                      d_out);
 }
 

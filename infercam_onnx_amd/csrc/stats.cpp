@@ -8,6 +8,8 @@
 
 // ---------------------------------------------------------------- profiling
 namespace ufd {
+thread_local LaunchShape tl_launch_shape;
+
 int prof_name_id(ufd_model* m, const std::string& name) {
   for (size_t i = 0; i < m->prof_names.size(); i++)
     if (m->prof_names[i] == name) return (int)i;
@@ -141,6 +143,44 @@ int ufd_profile_sampling(ufd_model* m, uint32_t every_n) {
     if (!every_n) return m->fail(UFD_E_ARG, "every_n must be >= 1");
     m->prof_every = every_n;
     m->prof_batch = 0;
+    return UFD_OK;
+  });
+}
+
+int ufd_profile_shapes(ufd_model* m, ufd_launch_shape* shapes, uint32_t cap, uint32_t* n) {
+  return guarded(m, [&]() -> int {
+    if (!n) return m->fail(UFD_E_ARG, "null argument");
+    std::vector<LaunchShape> sh;
+    std::vector<std::string> names;
+    {
+      std::lock_guard<std::mutex> lk(m->shared_mu);
+      sh = m->prof_shapes;
+      names = m->prof_names;
+    }
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->cfg.device_id);
+    uint32_t k = 0;
+    for (size_t i = 0; i < sh.size(); i++) {
+      if (!sh[i].fn || !sh[i].threads) continue;
+      if (k < cap) {
+        ufd_launch_shape& o = shapes[k];
+        std::memset(&o, 0, sizeof(o));
+        std::snprintf(o.name, sizeof(o.name), "%s", names[i].c_str());
+        o.workgroups = sh[i].blocks, o.threads = sh[i].threads, o.compute_units = (uint32_t)cus;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, sh[i].fn) == hipSuccess) {
+          o.registers = (uint32_t)fa.numRegs;
+          o.lds_bytes = (uint32_t)fa.sharedSizeBytes + sh[i].lds;
+        } else {
+          o.lds_bytes = sh[i].lds;
+        }
+        int res = 0;  // the runtime's own occupancy rule: registers, LDS, waves and workgroup slots of a CU
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, sh[i].fn, (int)sh[i].threads, sh[i].lds) == hipSuccess)
+          o.resident_per_cu = (uint32_t)res;
+      }
+      k++;
+    }
+    *n = k;
     return UFD_OK;
   });
 }

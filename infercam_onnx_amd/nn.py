@@ -101,6 +101,11 @@ class UfdKernelStat(ctypes.Structure):
                 ("bytes", ctypes.c_double), ("flops", ctypes.c_double)]
 
 
+class UfdLaunchShape(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48)] + [(n, ctypes.c_uint32) for n in (
+        "workgroups", "threads", "lds_bytes", "registers", "resident_per_cu", "compute_units")]
+
+
 class UfdPlanLayer(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 24)] + [(n, ctypes.c_int32) for n in (
         "kind", "leader", "ride", "chain_first", "fused_dw", "chained", "materialize", "launches", "rfb_tail", "in_tensor",
@@ -125,7 +130,7 @@ ABI_SYMBOLS = (
     "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
     "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
-    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read",
+    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read", "ufd_profile_shapes",
     "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
     "ufd_submit_annotate_batch", "ufd_annotate_jpeg_batch", "ufd_encode_bound", "ufd_host_alloc", "ufd_host_free",
     "ufd_debug_draw_labels", "ufd_debug_encode_rgb", "ufd_model_limits",
@@ -212,6 +217,7 @@ def load_library():
     L.ufd_profile_reset.argtypes = [vp]
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
+    L.ufd_profile_shapes.argtypes = [vp, vp, u32, pu32]
     L.ufd_debug_plan.argtypes = [u32, u32, u32, ctypes.POINTER(UfdPlanLayer), u32, pu32, ctypes.POINTER(UfdPlanTensor), u32, pu32,
                                  ctypes.POINTER(ctypes.c_uint64)]
     L.ufd_host_stats_reset.argtypes = [vp]
@@ -694,6 +700,25 @@ class UltrafaceModel(InferModel):
         self._check(self._lib.ufd_profile_read(self._h, arr, cap, ctypes.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=arr[i].total_ms,
                      bytes=arr[i].bytes, flops=arr[i].flops) for i in range(min(n.value, cap))]
+
+
+    def profile_shapes(self):
+        """-> [dict] per profiled label: workgroups, threads, lds_bytes, registers of its last launch, workgroups a CU holds
+        at once (the runtime's occupancy query), and from them slots / rounds / last-round fill on this GPU's CUs."""
+        cap = 256
+        arr = (UfdLaunchShape * cap)()
+        n = ctypes.c_uint32()
+        self._check(self._lib.ufd_profile_shapes(self._h, arr, cap, ctypes.byref(n)))
+        out = []
+        for i in range(min(n.value, cap)):
+            a = arr[i]
+            slots = a.compute_units * max(a.resident_per_cu, 1)
+            full, rem = divmod(a.workgroups, slots)
+            out.append(dict(name=a.name.decode(), workgroups=int(a.workgroups), threads=int(a.threads), lds_bytes=int(a.lds_bytes),
+                            registers=int(a.registers), resident_per_cu=int(a.resident_per_cu), slots=int(slots),
+                            rounds=round(a.workgroups / slots, 3),
+                            last_round_fill=round((rem if rem else (slots if full else 0)) / slots, 3)))
+        return out
 
 
 def jpeg_coefficients_header(jpeg):

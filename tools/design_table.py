@@ -21,12 +21,24 @@ pmc = json.load(open(os.path.join(d, "pmc_traffic.json"))).get("instances", {})
 isa = json.load(open(os.path.join(d, "isa_mix.json"))).get("instances", {}) if os.path.exists(os.path.join(d, "isa_mix.json")) else {}
 bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
 loaded = bench.get("kernels_ms_per_step", {})
+shapes = {}  # device kernel name -> {shape text: [layers]} from the bench line's launch_shapes (ufd_profile_shapes: as issued)
+
+
+def shape_text(sh):
+    """workgroups / slots = rounds (last-round fill); mean -> max workgroups per CU"""
+    cus = max(1, sh["slots"] // max(sh["resident_per_cu"], 1))
+    per_cu = sh["workgroups"] / cus
+    mx = -(-sh["workgroups"] // cus)
+    return "%d / %d = %.2f (%.0f %%); %.2f → %d per CU" % (sh["workgroups"], sh["slots"], sh["rounds"], 100 * sh["last_round_fill"], per_cu, mx)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B  # noqa: E402
 
 loaded_by_dev = {}
 for k, v in loaded.items():
     loaded_by_dev[B.device_name(k)] = loaded_by_dev.get(B.device_name(k), 0.0) + v * 1e3
+for label, sh in bench.get("launch_shapes", {}).items():
+    base, _, layers = label.partition(":")
+    shapes.setdefault(B.device_name(base), {}).setdefault(shape_text(sh), []).append(layers.split(".")[0] if layers else "")
 out_lines = []
 _print = print
 
@@ -37,8 +49,8 @@ def print(*a):  # noqa: A001  (collect what is printed: --update writes it into 
 
 
 print("Source: `%s/` (kernel_times_alone.txt, bench.json, sq_counters.json, pmc_traffic.json, isa_mix.json); regenerate with `python tools/design_table.py %s --update`.\n" % (d.rstrip("/"), d.rstrip("/")))
-print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | LDS conflicts | traffic MB / launch (fetch + write) | hot loop: vector instr. / MFMA (not fp32 arithmetic) |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+print("| kernel instance | launches / batch | alone µs / launch | loaded µs / batch | MFMA busy | VALU busy | waves / SIMD | waiting | LDS conflicts | traffic MB / launch (fetch + write) | hot loop: vector instr. / MFMA (not fp32 arithmetic) | workgroups / resident slots = rounds (last-round fill); workgroups per CU, mean → max |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 tot = 0.0
 pct = lambda x: "%.0f %%" % (100 * x) if x is not None else "–"
 for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
@@ -55,9 +67,10 @@ for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1])
     if h and h.get("MFMA"):
         valu = sum(h.get(c, 0) for c in ("FMA", "mov", "cndmask", "maxmin", "cmp", "int", "cvt"))
         mix = "%.1f (%.1f)" % (valu / h["MFMA"], (valu - h.get("FMA", 0)) / h["MFMA"])
-    print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+    shp = "; ".join(t + (" [" + ", ".join(x for x in ls if x) + "]" if len(shapes.get(k, {})) > 1 and any(ls) else "") for t, ls in shapes.get(k, {}).items()) or "–"
+    print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         k, per, us, "%.0f" % ld if ld else "–", pct(s.get("mfma_busy")), pct(s.get("valu_busy")),
-        "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), pct(s.get("lds_conflict_share")), tr, mix))
+        "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), pct(s.get("lds_conflict_share")), tr, mix, shp))
 print("\nkernels alone per batch: %.0f µs; delivered: %.3f ms per batch (steady state %.0f frames/s)" % (
     tot, bench["host"]["ms_per_batch"] if "host" in bench else bench["ms_per_step"], bench.get("steady_state_fps", 0)))
 

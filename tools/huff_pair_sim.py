@@ -11,7 +11,11 @@ import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from infercam_onnx_amd import synth  # noqa: E402
+sys.argv = sys.argv[:1]
 from huff_sync_sim import build, parse  # noqa: E402
+
+
+CODE_ONLY = True
 
 
 def walk(jpeg, W, with_dc):
@@ -49,7 +53,7 @@ def walk(jpeg, W, with_dc):
         if z < 64 and first_ok and L1 <= W:
             ln2, s2 = sym_at(p, luts[(1, ta)])
             sz2, run2 = s2 & 15, s2 >> 4
-            if L1 + ln2 + sz2 <= W:
+            if L1 + (ln2 if CODE_ONLY else ln2 + sz2) <= W:  # (state-only walks never look at magnitude bits)
                 nsym += 1
                 npair += 1
                 p += ln2 + sz2

@@ -175,4 +175,5 @@ def multi(span, nsub, sub_bits, total_bits, bpm, mode):
         print("round", rounds, "decodes", work, "max per sub", maxw, "truth reached", true_i, "of", nsub)
 
 
-main()
+if __name__ == "__main__":
+    main()
