@@ -999,3 +999,83 @@ def test_layouts_libjpeg_refuses_are_decode_errors_on_the_gpu_path(model320_auto
     res, status = model320_auto.infer_jpeg_batch([good, bad[0], bad[1], good])
     assert status[0] == 0 and status[3] == 0 and res[0] == res[3]
     assert status[1] in (nn.UFD_E_UNSUPPORTED, nn.UFD_E_DECODE) and status[2] == nn.UFD_E_DECODE and res[1] is None and res[2] is None
+
+
+# ---------------------------------------------------------------- round 6: one launch for A7-A10, the gate, launch shapes
+def test_small_batch_single_launch_nms_with_many_candidates(weights, oracle_lib):
+    """A frame or a few at a time go in and out by kernels, and since round 6 A7-A10 plus the results' way out are ONE launch
+    (k_sort_nms finishes every frame itself and writes statuses, counts and detections to the slot's pinned arrays).  With a
+    low confidence threshold a frame has thousands of candidates -- the in-kernel block loop instead of the matrix path's
+    two extra launches: same detections as the oracle, one frame and three at a time, and the profile shows neither
+    k_nms_matrix, k_nms_scan nor a result copy."""
+    from infercam_onnx_amd import nn, synth
+
+    pri = synth.gen_priors(320, 240)
+    jpegs = [synth.encode_jpeg(synth.synth_frame(61, i, 320, 240)) for i in range(3)]
+    for min_conf, lo in ((0.5, 0), (0.2, 257), (0.03, 1000)):
+        m = nn.UltrafaceModel(nn.UltrafaceVariant.W320H240, 0.5, min_conf, weights=weights, priors=pri, max_batch=4, max_src=(320, 240),
+                              det_cap=4420, profile=True)
+        try:
+            refs = [oracle_lib.infer_jpeg(j, 320, 240, weights, pri, min_conf, 0.5) for j in jpegs]
+            x = [oracle_lib.normalize_nchw(oracle_lib.jpeg_decode_rgb(j)) for j in jpegs]
+            ncand = [int((oracle_lib.forward(xi, weights, pri)[0][..., 1] > min_conf).sum()) for xi in x]
+            assert max(ncand) >= lo, ncand
+            for j, r in zip(jpegs, refs):
+                assert_dets_match(dets_array(m.infer_jpeg(j)), r, min_conf=min_conf, what="one frame, min_conf %g" % min_conf)
+            t = m.submit_jpeg_batch(jpegs)
+            got, st = m.wait(t)
+            assert st == [0, 0, 0]
+            for g, r in zip(got, refs):
+                assert_dets_match(dets_array(g), r, min_conf=min_conf, what="three frames, min_conf %g" % min_conf)
+            names = {p["name"].split(":")[0] for p in m.profile_read() if p["launches"] > 0}
+            assert "sort_nms" in names and not names & {"nms_matrix", "nms_scan"}, sorted(names)
+        finally:
+            m.close()
+
+
+def test_gate_orders_batches_without_changing_a_result(weights, oracle_lib):
+    """csrc/pipeline_gate.cpp: batch n + 1's network waits for batch n's m3->m4 on another stream.  Twelve batches in flight
+    six at a time, with and without UFD_FLAG_NO_GATE: identical detections (bit for bit: the same kernels on the same data),
+    a batch with nothing decodable in the middle of the chain holds nobody up."""
+    from infercam_onnx_amd import nn, synth
+
+    pri = synth.gen_priors(640, 480)
+    pool = [synth.encode_jpeg(synth.synth_frame(71, i, 640, 480)) for i in range(16)]
+    batches = [pool[(4 * i) % 16:(4 * i) % 16 + 8] if i != 5 else [b"junk"] * 8 for i in range(12)]
+    out = {}
+    for flags in (0, nn.UFD_FLAG_NO_GATE):
+        with nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=pri, max_batch=8, max_src=(640, 480),
+                               det_cap=1024, extra_flags=flags) as m:
+            res, infl = [], []
+            for b in batches:
+                if len(infl) >= 6:
+                    res.append(m.wait(infl.pop(0)))
+                infl.append(m.submit_jpeg_batch(b))
+            res += [m.wait(t) for t in infl]
+            out[flags] = res
+    assert len(out[0]) == 12
+    for (ra, sa), (rb, sb) in zip(out[0], out[nn.UFD_FLAG_NO_GATE]):
+        assert sa == sb and ra == rb
+    assert out[0][5][1] == [nn.UFD_E_DECODE] * 8 and out[0][6][1] == [0] * 8
+    ref = oracle_lib.infer_jpeg(pool[0], 640, 480, weights, pri, 0.5, 0.5)
+    assert_dets_match(dets_array(out[0][0][0][0]), ref)
+
+
+def test_profile_shapes_report_how_launches_sit_on_the_gpu(weights):
+    """ufd_profile_shapes: per profiled label the launch as issued (workgroups, threads), the kernel's registers and LDS and
+    the workgroups a CU holds at once by the runtime's occupancy query -- DESIGN's kernel table is generated from it."""
+    from infercam_onnx_amd import nn, synth
+
+    with nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=weights, priors=synth.gen_priors(640, 480), max_batch=32,
+                           max_src=(640, 480), det_cap=256, profile=True) as m:
+        jpegs = [synth.encode_jpeg(synth.synth_frame(81, i, 640, 480)) for i in range(32)]
+        m.wait(m.submit_jpeg_batch(jpegs))
+        shapes = {s["name"]: s for s in m.profile_shapes()}
+    assert len(shapes) >= 25
+    for name, s in shapes.items():
+        assert s["workgroups"] >= 1 and s["threads"] in (64, 128, 256, 512, 1024) and 1 <= s["resident_per_cu"] <= 32, (name, s)
+        assert s["slots"] == 256 * s["resident_per_cu"] and s["registers"] > 0, (name, s)
+    chained = [s for n, s in shapes.items() if n.startswith("conv_dwpw2_mfma<16")]
+    assert chained and chained[0]["resident_per_cu"] == 2 and chained[0]["lds_bytes"] > 64 * 1024  # 80 KB of LDS, 256 registers: a CU whole
+    coop = [s for n, s in shapes.items() if n.startswith("conv_dwpw_coop<1, 4>")]
+    assert sorted(s["workgroups"] for s in coop) == [160, 320, 320]  # m12, m9, m10 at batch 32 (DESIGN 7: 1.25 and 0.63 per CU)
