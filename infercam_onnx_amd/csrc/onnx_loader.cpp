@@ -348,4 +348,19 @@ bool load_ultraface_onnx(const std::string& path, int width, int height, std::ve
   return true;
 }
 
+
+// ---- get_model's choice of source (nn.rs:143-175): the caller's blob, the caller's path, or the reference's cache path
+std::string default_weights_path(int variant) {
+  // dirs::cache_dir()/infercam_onnx/ultraface-RFB-{640,320}.onnx (nn.rs:144-156)
+  const char* xdg = std::getenv("XDG_CACHE_HOME");
+  std::string base;
+  if (xdg && *xdg) {
+    base = xdg;
+  } else {
+    const char* home = std::getenv("HOME");
+    base = std::string(home ? home : ".") + "/.cache";
+  }
+  return base + "/infercam_onnx/ultraface-RFB-" + std::to_string(variant) + ".onnx";
+}
+
 }  // namespace ufd

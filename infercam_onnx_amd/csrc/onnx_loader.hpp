@@ -13,4 +13,7 @@ namespace ufd {
 bool load_ultraface_onnx(const std::string& path, int width, int height, std::vector<float>* blob,
                          std::vector<float>* priors, std::string* why);
 
+// dirs::cache_dir()/infercam_onnx/ultraface-RFB-{640,320}.onnx (nn.rs:144-156)
+std::string default_weights_path(int variant);
+
 }  // namespace ufd

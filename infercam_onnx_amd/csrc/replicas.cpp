@@ -28,6 +28,32 @@
 #include "../../include/ufd.h"
 #include "experiments.hpp"
 #include "model_internal.hpp"
+#include "onnx_loader.hpp"
+#include "topology.hpp"
+
+namespace ufd {
+// get_model's parsing step on the host, once for all replicas (nn.rs:143-175): the caller's blob, the caller's path, or the
+// reference's cache path
+bool load_weights_once(const ufd_config* cfg, std::vector<float>* blob, std::vector<float>* priors, std::string* why) {
+  const int W = cfg->variant == 640 ? 640 : 320, H = cfg->variant == 640 ? 480 : 240;
+  if (cfg->weights) {
+    if (cfg->weights_floats != total_weight_floats()) {
+      *why = "weights blob must hold " + std::to_string(total_weight_floats()) + " floats";
+      return false;
+    }
+    blob->assign(cfg->weights, cfg->weights + cfg->weights_floats);
+    if (cfg->priors) priors->assign(cfg->priors, cfg->priors + cfg->priors_floats);
+  } else {
+    const std::string path = cfg->weights_path ? cfg->weights_path : default_weights_path(cfg->variant);
+    if (!load_ultraface_onnx(path, W, H, blob, priors, why)) {
+      *why = "cannot load " + path + ": " + *why;
+      return false;
+    }
+  }
+  if (priors->empty()) gen_priors(W, H, *priors);
+  return true;
+}
+}  // namespace ufd
 
 namespace {
 
