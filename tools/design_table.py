@@ -74,11 +74,38 @@ for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1])
 print("\nkernels alone per batch: %.0f µs; delivered: %.3f ms per batch (steady state %.0f frames/s)" % (
     tot, bench["host"]["ms_per_batch"] if "host" in bench else bench["ms_per_step"], bench.get("steady_state_fps", 0)))
 
+# ---- the paragraph of DESIGN section 5 about the dominant kernel, from the SAME bench line (so that it cannot drift from the table)
+r = bench.get("roofline", {})
+dom_lines = []
+if r.get("kernel"):
+    al = r.get("alone", {})
+    fl, by = r.get("algorithmic_flops_per_launch", 0), r.get("algorithmic_bytes_per_launch", 0)
+    t = "  Dominant: `%s` (%.2f GFLOP, %.0f MB algorithmic per launch): **%.1f µs alone = %.2f of the fp32-MFMA roof; loaded %.0f µs = %.3f** " \
+        "(the launch shares the GPU with three other contexts' kernels)" % (
+            r["kernel"], fl / 1e9, by / 1e6, al.get("avg_launch_us", 0), al.get("mfma_frac", 0), r.get("avg_launch_us", 0), r.get("frac", 0))
+    if r.get("traffic"):
+        t += "; traffic %.0f MB = %.2f× the algorithmic bytes" % (r["traffic"] / 1e6, r.get("traffic_ratio") or 0)
+        if r.get("dram_bytes"):
+            t += " (%.0f MB addressed to local memory, fabric read latency %.0f L2 clocks)" % (r["dram_bytes"] / 1e6, r.get("ea_read_latency_clk") or 0)
+    if r.get("mfma_busy") is not None:
+        t += "; MFMA pipe busy %.0f %% and vector ALU %.0f %% of its SIMD-cycles alone at %.1f waves per SIMD" % (
+            100 * r["mfma_busy"], 100 * r["valu_busy"], r["waves_per_simd"])
+    t += ".  `whole_net_mfma_frac` = frames/s × 798.3 MFLOP ÷ 157.3 TFLOP/s = %.2f (timed region) / %.2f (steady state)." % (
+        bench.get("whole_net_mfma_frac", 0), bench.get("steady_state_fps", 0) * 798315520 / 157.3e12)
+    t += "  (Generated by `tools/design_table.py` from `%s/bench.json`.)" % d.rstrip("/")
+    dom_lines = [t]
+    _print("\n" + t)
+
 if "--update" in sys.argv:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "DESIGN.md")
     text = open(path).read()
     a, b = "<!-- KERNEL_TABLE_BEGIN -->", "<!-- KERNEL_TABLE_END -->"
     i, j = text.index(a) + len(a), text.index(b)
-    open(path, "w").write(text[:i] + "\n" + "\n".join(out_lines) + "\n" + text[j:])
+    text = text[:i] + "\n" + "\n".join(out_lines) + "\n" + text[j:]
+    a, b = "<!-- DOMINANT_BEGIN -->", "<!-- DOMINANT_END -->"
+    if dom_lines and a in text:
+        i, j = text.index(a) + len(a), text.index(b)
+        text = text[:i] + "\n" + "\n".join(dom_lines) + "\n" + text[j:]
+    open(path, "w").write(text)
     _print("DESIGN.md updated")
