@@ -950,18 +950,21 @@ def _check_layout_stream(m, oracle_lib, name, kind, jpeg, rgb, sha):
 
 @pytest.mark.parametrize("path", ["host_entropy", "device_entropy", "default"])
 def test_every_libjpeg_layout_on_the_gpu(model320, model320_dev, model320_auto, oracle_lib, path):
-    """`turbojpeg::decompress_image` (inferer.rs:35) is libjpeg-turbo: it takes any integral sampling layout.  The 237
+    """`turbojpeg::decompress_image` (inferer.rs:35) is libjpeg-turbo: it takes any integral sampling layout.  The 329
     libjpeg-turbo-written streams of tests/golden/jpeg_layouts.npz (4:4:0, 4:1:1, 4:1:0, 4:4:1, 3x1 ..., luma coarser
     than chroma, a rate per chroma plane, RGB colour space by marker rules, grey with a 2x2 SOF; baseline / two restart
     layouts / progressive / optimised tables) decode on the GPU to the oracle's and to libjpeg-turbo's pixels, with the
-    entropy stage on the host workers, on the device, and wherever the product's default routing sends it."""
+    entropy stage on the host workers, on the device, and wherever the product's default routing sends it; round 6 added the
+    NON-INTERLEAVED files (a scan per component, luma + chroma pair with restart intervals: the host workers' multi-scan path)."""
     m = {"host_entropy": model320, "device_entropy": model320_dev, "default": model320_auto}[path]
     n = 0
     for name, (streams, rgb, sha) in sorted(_layout_fixtures().items()):
         for kind, jpeg in streams.items():
             _check_layout_stream(m, oracle_lib, name, kind, jpeg, rgb, sha)
             n += 1
-    assert n == 237
+    from test_oracle_jpeg import N_LAYOUT_STREAMS
+
+    assert n == N_LAYOUT_STREAMS
 
 
 def test_layouts_take_the_device_entropy_decoder(weights, oracle_lib):

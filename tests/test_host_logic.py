@@ -82,6 +82,22 @@ def test_corrupt_jpeg_status_codes():
     with pytest.raises(nn.UfdError) as e:
         nn.jpeg_coefficients(sof9)
     assert e.value.code == nn.UFD_E_UNSUPPORTED
+    # four components (CMYK / YCCK): libjpeg-turbo decodes them, but not to RGB -- tjDecompress2 into TJPF_RGB fails and the
+    # reference's `expect` panics (inferer.rs:35-36); here: a status, and the oracle refuses too
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    import oracle
+
+    buf = io.BytesIO()
+    Image.fromarray(np.random.default_rng(0).integers(0, 255, (24, 40, 4), dtype=np.uint8), "CMYK").save(buf, "JPEG")
+    with pytest.raises(nn.UfdError) as e:
+        nn.jpeg_coefficients(buf.getvalue())
+    assert e.value.code == nn.UFD_E_UNSUPPORTED
+    with pytest.raises(oracle.OracleError):
+        oracle.jpeg_decode_rgb(buf.getvalue())
 
 
 def test_onnx_loader_roundtrip_and_bn_folding(tmp_path, weights):

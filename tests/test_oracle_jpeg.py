@@ -93,6 +93,9 @@ def layout_fixtures():
     return out
 
 
+N_LAYOUT_STREAMS = 329
+
+
 def check_pixels(name, kind, got, rgb, sha):
     if rgb is not None:
         assert got.shape == rgb.shape and np.array_equal(got, rgb), "%s/%s: %d samples differ" % (name, kind, (got != rgb).sum())
@@ -103,9 +106,10 @@ def check_pixels(name, kind, got, rgb, sha):
 def test_every_libjpeg_layout_bit_exact(oracle_lib):
     """4:4:0 (h1v2 fancy), 4:1:1 / 4:1:0 / 4:4:1 and the other integral expansions (plain replication, jdsample.c
     int_upsample), luma coarser than chroma, RGB-colourspace streams by libjpeg's marker rules -- as baseline, with two
-    restart layouts, progressive and with optimised tables: the oracle gives libjpeg-turbo's pixels on all 237 streams."""
+    restart layouts, progressive, with optimised tables and non-interleaved (a scan per component): the oracle gives
+    libjpeg-turbo's pixels on all of the streams."""
     fx = layout_fixtures()
-    assert len(fx) == 53 and sum(len(v[0]) for v in fx.values()) == 237
+    assert len(fx) == 53 and sum(len(v[0]) for v in fx.values()) == N_LAYOUT_STREAMS
     for name, (streams, rgb, sha) in sorted(fx.items()):
         for kind, jpeg in streams.items():
             check_pixels(name, kind, oracle_lib.jpeg_decode_rgb(jpeg), rgb, sha)
@@ -122,6 +126,8 @@ def test_product_host_decoder_takes_every_layout():
         for kind, jpeg in streams.items():
             coef, w, h = nn.jpeg_coefficients(jpeg)
             assert "%dx%d" % (w, h) == name.rsplit("_", 1)[1]
+            if kind.startswith("nonint"):
+                continue  # (a component's own scan does not code the MCU-padding blocks: those stay zero in the slab)
             assert ref is None or np.array_equal(coef, ref), "%s/%s" % (name, kind)
             ref = coef
 

@@ -33,6 +33,7 @@ OFF_IMAGE_WIDTH = 48     # image_width, image_height, input_components, in_color
 OFF_INPUT_GAMMA = 64
 OFF_COMP_INFO = 104
 OFF_NUM_COMPONENTS = 92
+OFF_NUM_SCANS = 272        # int num_scans; const jpeg_scan_info *scan_info at 280
 OFF_OPTIMIZE_CODING = 296
 OFF_DCT_METHOD = 312
 OFF_RESTART_INTERVAL = 316   # unsigned restart_interval (MCUs), int restart_in_rows
@@ -61,7 +62,7 @@ class TurboEncoder:
         self.L = L
 
     def encode(self, rgb, quality=95, dct=JDCT_IFAST, samp=None, colorspace=None, restart_mcus=0, restart_rows=0,
-               progressive=False, optimize=False, write_jfif=None, write_adobe=None):
+               progressive=False, optimize=False, write_jfif=None, write_adobe=None, scans=None):
         """samp: [(h, v)] * 3 sampling factors written into comp_info (any layout libjpeg accepts, not only tjCompress2's
         five); colorspace: JCS_* of the stream (None = YCbCr; JCS_RGB writes component ids R, G, B and an Adobe marker
         with transform 0 instead of JFIF); write_jfif / write_adobe override which of the two markers is written."""
@@ -104,6 +105,19 @@ class TurboEncoder:
             struct.pack_into("i", cinfo, OFF_WRITE_ADOBE, int(write_adobe))
         if progressive:
             L.jpeg_simple_progression(cinfo)
+        if scans is not None:
+            # a scan script (jpeg_scan_info: comps_in_scan, component_index[4], Ss, Se, Ah, Al), e.g. one sequential scan per
+            # component: a NON-INTERLEAVED baseline file -- its scans run over ceil(width / 8) blocks of the component, not over MCUs
+            assert struct.unpack_from("i", cinfo, OFF_NUM_SCANS)[0] == 0 and struct.unpack_from("Q", cinfo, OFF_NUM_SCANS + 8)[0] == 0
+            arr = (ctypes.c_int * (9 * len(scans)))()
+            for k, (comps, ss, se, ah, al) in enumerate(scans):
+                arr[9 * k] = len(comps)
+                for q, c in enumerate(comps):
+                    arr[9 * k + 1 + q] = c
+                arr[9 * k + 5:9 * k + 9] = [ss, se, ah, al]
+            self._keep = arr
+            struct.pack_into("i", cinfo, OFF_NUM_SCANS, len(scans))
+            struct.pack_into("Q", cinfo, OFF_NUM_SCANS + 8, ctypes.addressof(arr))
         L.jpeg_start_compress(cinfo, 1)
         rows = (ctypes.c_void_p * h)(*[rgb.ctypes.data + y * 3 * w for y in range(h)])
         done = 0

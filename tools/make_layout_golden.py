@@ -9,8 +9,9 @@ Layouts: 4:4:0, 4:1:1, 4:1:0, 4:4:1 and the less common legal ones (luma 3x1 / 1
 chroma at half the luma rate of a 4-wide MCU, a different rate per chroma plane), RGB-colourspace streams (component
 ids R G B with an Adobe transform-0 marker, with no marker at all, with a JFIF marker that overrides the ids, subsampled),
 YCbCr with an Adobe transform-1 marker or no marker, a one-component stream whose SOF says 2x2.  Each as baseline, with
-restart intervals (one MCU row; 3 MCUs), progressive, and with optimised tables: the entropy coding differs, the
-coefficients and so the pixels do not -- one pixel array per (layout, size).
+restart intervals (one MCU row; 3 MCUs), progressive, with optimised tables, and NON-INTERLEAVED (one sequential scan per
+component; luma alone + the chroma planes together, with a restart interval): the entropy coding differs, the coefficients
+of the visible blocks and so the pixels do not -- one pixel array per (layout, size).
 
 Run in the build container:  python tools/make_layout_golden.py   ->  tests/golden/jpeg_layouts.npz
 """
@@ -54,7 +55,11 @@ COLOURS = {
     "ycc_adobe1": dict(write_jfif=False, write_adobe=True),                     # Adobe transform 1 => YCbCr
 }
 KINDS = {"base": {}, "dri_row": {"restart_rows": 1}, "dri_3": {"restart_mcus": 3}, "prog": {"progressive": True},
-         "opt": {"optimize": True}}
+         "opt": {"optimize": True},
+         # NON-INTERLEAVED sequential files: one scan per component (its blocks are ceil(w / 8) x ceil(h / 8) of the component, not
+         # MCU-padded), and luma alone + the two chroma planes interleaved; the second with a restart interval
+         "nonint": {"scans": [((0,), 0, 63, 0, 0), ((1,), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)]},
+         "nonint_y_cc_dri": {"scans": [((0,), 0, 63, 0, 0), ((1, 2), 0, 63, 0, 0)], "restart_mcus": 3}}
 SIZES_ALL = [(150, 100), (37, 29)]
 SIZES_FEW = {(5, 3): ("440", "411", "410", "y11c22"), (640, 480): ("440", "411", "410"), (321, 243): ("411", "440", "y22c21")}
 PIXEL_LIMIT = 5000   # larger frames are committed as the sha256 of their pixels
@@ -83,8 +88,8 @@ def main():
     def add(name, rgb, w, h, **kw):
         ref = None
         for kind, kkw in KINDS.items():
-            if w * h > 20000 and kind in ("dri_3", "opt"):
-                continue  # (large frames: three kinds are enough)
+            if w * h > 20000 and kind in ("dri_3", "opt", "nonint_y_cc_dri"):
+                continue  # (large frames: four kinds are enough)
             jpeg = enc.encode(rgb, 85, JDCT_ISLOW, **kw, **kkw)
             px = pil_decode(jpeg)
             assert px.shape == (h, w, 3)
