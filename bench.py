@@ -94,7 +94,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pool", type=int, default=256, help="distinct frames per stream")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight (async submit/wait)")
-    ap.add_argument("--repeats", type=int, default=3,
+    ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions (each: --warmup untimed steps, then exactly --steps timed ones) run back to back; `value` is the median one")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 script rehearsal on a one-GPU box: all ranks on cuda:0, exchanges over gloo (not a measurement)")

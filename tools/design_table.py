@@ -67,7 +67,10 @@ for k, (calls, us) in sorted(alone.items(), key=lambda kv: -kv[1][0] * kv[1][1])
     if h and h.get("MFMA"):
         valu = sum(h.get(c, 0) for c in ("FMA", "mov", "cndmask", "maxmin", "cmp", "int", "cvt"))
         mix = "%.1f (%.1f)" % (valu / h["MFMA"], (valu - h.get("FMA", 0)) / h["MFMA"])
-    shp = "; ".join(t + (" [" + ", ".join(x for x in ls if x) + "]" if len(shapes.get(k, {})) > 1 and any(ls) else "") for t, ls in shapes.get(k, {}).items()) or "–"
+    sk = shapes.get(k)
+    if sk is None:  # (a label without its template instance: "idct" for k_idct<true>)
+        sk = next((v for n, v in shapes.items() if k.startswith(n + "<")), {})
+    shp = "; ".join(t + (" [" + ", ".join(x for x in ls if x) + "]" if len(sk) > 1 and any(ls) else "") for t, ls in sk.items()) or "–"
     print("| `%s` | %.0f | %.1f | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         k, per, us, "%.0f" % ld if ld else "–", pct(s.get("mfma_busy")), pct(s.get("valu_busy")),
         "%.2f" % s["waves_per_simd"] if s else "–", pct(s.get("wait_share")), pct(s.get("lds_conflict_share")), tr, mix, shp))
