@@ -148,7 +148,9 @@ def test_whole_file_fuzz_never_faults():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # thumbnails through UltraFace-320; 640x480-class frames through UltraFace-640; all frames exactly 640x480 (round 5: the
     # 4:2:0 and 4:2:2 ones take the fused stem in the same damaged batch)
-    for extra in (["40"], ["30", "big"], ["30", "model"]):
+    # ... and (round 6) the libjpeg-turbo-written layout fixtures as seeds: damaged 4:1:1 / 4:1:0 (ten blocks per MCU) / 4:4:0 / RGB /
+    # non-interleaved streams meet the device entropy decoder and the generic upsampler
+    for extra in (["40"], ["30", "big"], ["30", "model"], ["60", "layouts"]):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py")] + extra, cwd=root, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

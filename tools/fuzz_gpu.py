@@ -3,9 +3,12 @@ through ufd_infer_jpeg_batch and, every other round, ufd_annotate_jpeg_batch (re
 whatever the damaged frame decodes to) in mixed batches.  Every frame must end as OK / UFD_E_TRUNCATED / UFD_E_DECODE /
 UFD_E_UNSUPPORTED / UFD_E_TOO_LARGE, every annotated stream must be a framed JPEG, and a clean batch must still decode
 bit-exactly afterwards.
-Usage: python tools/fuzz_gpu.py [rounds] [big|model]   (exits non-zero on any violation; "big": 640x480-class frames through
+Usage: python tools/fuzz_gpu.py [rounds] [big|model|layouts]   (exits non-zero on any violation; "big": 640x480-class frames through
 UltraFace-640 instead of thumbnail-sized ones through UltraFace-320; "model": every frame exactly 640x480, so that the 4:2:0 and
-4:2:2 ones take the fused stem -- sample planes straight into the first convolution -- in mixed, damaged batches)"""
+4:2:2 ones take the fused stem -- sample planes straight into the first convolution -- in mixed, damaged batches; "layouts"
+(round 6): the libjpeg-turbo-written streams of tests/golden/jpeg_layouts.npz as seeds -- 4:1:1, 4:1:0 with its ten blocks per
+MCU, 4:4:0, RGB colour space, luma coarser than chroma, non-interleaved scans -- so that damaged sampling factors, scan scripts
+and ten-block MCUs meet the device entropy decoder and the generic upsampler)"""
 import sys
 import numpy as np
 
@@ -42,6 +45,7 @@ def main():
     w = synth.synthetic_weights()
     model_size = len(sys.argv) > 2 and sys.argv[2] == "model"
     big = model_size or (len(sys.argv) > 2 and sys.argv[2] == "big")
+    layouts = len(sys.argv) > 2 and sys.argv[2] == "layouts"
     if big:
         m = nn.UltrafaceModel(nn.UltrafaceVariant.W640H480, 0.5, 0.5, weights=w, priors=synth.gen_priors(640, 480), max_batch=8,
                               max_src=(704, 544), det_cap=17640)
@@ -53,6 +57,12 @@ def main():
     base = [synth.encode_jpeg(synth.synth_frame(5, i, w0 + step * i, h0 + step * i), **kw) for i, kw in enumerate((
         {}, {"restart_rows": 1}, {"subsampling": "4:2:2"}, {"progressive": True}, {"optimize": True, "quality": 30},
         {"subsampling": "4:4:4", "restart_rows": 2}, {"quality": 100}, {"subsampling": "4:2:2", "restart_rows": 1}))]
+    if layouts:
+        import os
+
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "jpeg_layouts.npz"))
+        base = [z[k].tobytes() for k in ("411_150x100/base", "410_640x480/dri_row", "440_150x100/dri_3", "rgb_adobe0_150x100/base",
+                                         "y11c22_150x100/base", "cb11cr22_150x100/nonint", "gray_sof22_67x45/base", "410_37x29/nonint_y_cc_dri")]
     ref, st = m.infer_jpeg_batch(base)
     assert st == [0] * len(base), st
     allowed = (0, nn.UFD_E_TRUNCATED, nn.UFD_E_DECODE, nn.UFD_E_UNSUPPORTED, nn.UFD_E_TOO_LARGE)
