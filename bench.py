@@ -299,7 +299,8 @@ def main_one_process(args):
     priors = synth.gen_priors(Wd, Hd)
     SW, SH = (int(v) for v in args.src.lower().split("x")) if args.src else (Wd, Hd)
     host_threads = args.host_threads or max(2, min(32, usable_cpus() // N))
-    kw = dict(max_batch=B, weights=weights, priors=priors, max_src=(SW, SH), host_threads=host_threads, det_cap=256)
+    kw = dict(max_batch=B, weights=weights, priors=priors, max_src=(SW, SH), host_threads=host_threads, det_cap=256,
+              extra_flags=nn.UFD_FLAG_NO_GATE if args.no_gate else 0)
     if args.rehearse_one_gpu:  # N handles on cuda:0: the script path on a one-GPU box, not a measurement
         models = [nn.UltrafaceModel(variant, 0.5, 0.5, device_id=0, **kw) for _ in range(N)]
     else:

@@ -59,6 +59,7 @@ void gate_wait_for_previous(ufd_model* m, const Slot& s, hipStream_t st) {
   // published[i] = 2 * seq + (1: an event was recorded | 0: nothing to wait for).  Bounded: a worker that died on an
   // exception never publishes, and an ordering hint must never hang a handle.
   const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
   for (;;) {
     const uint64_t p = g.published[i].load(std::memory_order_acquire);
     if ((p >> 1) == prev) {
@@ -70,7 +71,10 @@ void gate_wait_for_previous(ufd_model* m, const Slot& s, hipStream_t st) {
       g.timeouts.fetch_add(1, std::memory_order_relaxed);
       return;
     }
-    std::this_thread::yield();
+    // (the other worker is a few launches away from its gate layer: yield first; if it is busy for longer -- a host-entropy
+    // batch decoding on the pool -- sleep, so that a rank with two CPUs does not lose one of them to this loop)
+    if (++spins < 200) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
 }
 
