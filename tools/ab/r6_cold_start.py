@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Round 6: why is bench.py's 20-step sample 0.86 of steady state when the same loop inside a busy process is 0.92-0.95?
-One handle; the driver's sample (W warm-up steps, drain, 20 timed steps, drain) after: an idle pause of S seconds, W = 5 or
-50, with / without UFD_FLAG_PROFILE armed.  Prints frames/s per case (three repeats each, in rotation)."""
+One handle; the driver's sample (W warm-up steps, drain, 20 timed steps, drain) after: an idle pause of S seconds, W = 1, 5, 20 or
+50.  Prints frames/s per case (three repeats each, in rotation): profiles/r6b/cold_start.txt.
+With the argument `who`: also tells GPU from host -- the 0.5 s in front of the region spent sleeping, spinning on the CPU, or
+keeping the GPU busy with a torch matmul loop (profiles/r6b/cold_start2.txt; the 64 MB torch tensor and its BLAS kernels in the
+process cost the handle 20 % of its rate by themselves -- compare the steady-state lines of the two files -- so the three
+cases are comparable with one another, not with the first file)."""
 import os
 import sys
 import time
@@ -27,7 +31,8 @@ def run_steps(m, bts, k):
         m.wait(t, collect=False)
 
 
-X = torch.randn(4096, 4096, device="cuda")
+WHO = len(sys.argv) > 1 and sys.argv[1] == "who"
+X = torch.randn(4096, 4096, device="cuda") if WHO else None
 
 
 def sample(m, bts, warm, idle, how="sleep"):
@@ -60,7 +65,7 @@ for profile in (False,):
     for rnd in range(3):
         for warm, idle in ((5, 0), (5, 0.05), (5, 0.5), (5, 3.0), (50, 3.0), (1, 3.0), (20, 0)):
             print("profile armed %s  idle %.2f s  warm-up %2d steps: %.0f" % (profile, idle, warm, sample(m, bts, warm, idle)), flush=True)
-        for how in ("sleep", "cpu-spin", "gpu-busy"):
+        for how in (("sleep", "cpu-spin", "gpu-busy") if WHO else ()):
             print("  %-8s 0.5 s, then warm-up 5 steps: %.0f" % (how, sample(m, bts, 5, 0.5, how)), flush=True)
     t0 = time.perf_counter()
     run_steps(m, bts, 300)
