@@ -412,7 +412,19 @@ def main():
     if args.cpus > 0:  # before torch / HIP start their threads: they inherit the mask
         cur = sorted(os.sched_getaffinity(0))
         os.sched_setaffinity(0, cur[:max(1, min(args.cpus, len(cur)))])
+    # The library's hardware queues FIRST: torch brings its own copy of the HIP runtime, and a handle created behind that
+    # runtime's first touch of the device (one 32-byte copy is enough; at N > 1 the weight broadcast is one) runs 21 % slower
+    # for the life of the process -- 65.4 k -> 51.5 k frames/s (round 6: tools/ab/r6_torch_queue.py, profiles/r6e/).
+    # (Order: torch's runtime INITIALISED first -- is_available / set_device open no queue --, then the library's queues, then
+    # whatever torch does on the device.  The other way round torch's runtime no longer finds the device.)
     import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(0 if args.rehearse_one_gpu else local_rank)
+    from infercam_onnx_amd import nn as _nn
+
+    _nn.prime_device(0 if args.rehearse_one_gpu else local_rank)
 
     dist = None
     if world > 1:

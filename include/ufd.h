@@ -102,6 +102,15 @@ typedef struct ufd_config {
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
+/* For processes that hold ANOTHER copy of the HIP runtime (a Python host with torch: its wheels bundle one): call this before
+ * that runtime first touches the device.  A handle's four streams are this runtime's four hardware queues; when the other
+ * runtime opens its queue FIRST -- one 32-byte copy by torch is enough -- every handle created afterwards runs 21 % slower
+ * for the life of the process (65.4 k -> 51.5 k frames/s at batch 32), while the same activity after this call, or after a
+ * handle exists, costs nothing (round 6: tools/ab/r6_torch_queue.py, profiles/r6e/torch_queue*.txt).  Opens four streams on
+ * the device, runs an empty kernel on each, closes them.  (The other runtime must have been INITIALISED before -- for torch:
+ * torch.cuda.set_device(), which opens no queue --; initialised behind this call it no longer finds the device.)  No
+ * reference counterpart (a Rust host links one runtime). */
+int ufd_prime_device(int32_t device_id);
 void ufd_destroy(ufd_model* m);
 /* Multi-GPU start-up in ONE process -- the reference server is one process whose tasks share one model
  * (infer_server.rs:39-68; the single Inferer is spawned at :48-50).  Streams shard one-per-GPU (independent: run(&self)

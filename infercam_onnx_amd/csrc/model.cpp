@@ -918,6 +918,34 @@ int ufd_model_placement(const ufd_model* m, int32_t* device_id, int32_t* numa_no
   return UFD_OK;
 }
 
+int ufd_prime_device(int32_t device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device: libufacehip needs a gfx950 GPU (there is no CPU fallback)";
+    return UFD_E_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    g_create_error = "ufd_prime_device: device_id out of range";
+    return UFD_E_ARG;
+  }
+  int saved = -1;
+  if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+  int rc = UFD_OK;
+  if (hipSetDevice(device_id) != hipSuccess) rc = UFD_E_DEVICE;
+  hipStream_t st[4] = {};
+  for (int i = 0; i < 4 && rc == UFD_OK; i++)
+    if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) rc = UFD_E_DEVICE;
+  for (int i = 0; i < 4 && rc == UFD_OK; i++) launch_copy_fence(st[i]);
+  for (int i = 0; i < 4; i++)
+    if (st[i]) {
+      if (hipStreamSynchronize(st[i]) != hipSuccess) rc = UFD_E_DEVICE;
+      (void)hipStreamDestroy(st[i]);
+    }
+  if (saved >= 0) (void)hipSetDevice(saved);
+  if (rc != UFD_OK) g_create_error = "ufd_prime_device: the HIP runtime refused a stream or a launch";
+  return rc;
+}
+
 int ufd_model_limits(const ufd_model* m, uint32_t* max_batch, uint32_t* max_src_width, uint32_t* max_src_height) {
   if (!m) return UFD_E_ARG;
   if (max_batch) *max_batch = m->B;

@@ -130,7 +130,7 @@ ABI_SYMBOLS = (
     "ufd_create", "ufd_destroy", "ufd_last_error", "ufd_model_info", "ufd_infer_rgb", "ufd_infer_jpeg",
     "ufd_infer_jpeg_batch", "ufd_infer_rgb_batch", "ufd_submit_jpeg_batch", "ufd_wait", "ufd_debug_decode_jpeg",
     "ufd_debug_preproc_rgb", "ufd_debug_forward", "ufd_debug_layer_output", "ufd_debug_postproc",
-    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read", "ufd_profile_shapes",
+    "ufd_debug_jpeg_coefficients", "ufd_debug_load_onnx", "ufd_profile_reset", "ufd_profile_sampling", "ufd_profile_read", "ufd_profile_shapes", "ufd_prime_device",
     "ufd_stage_jpeg_batch", "ufd_submit_staged", "ufd_staged_free",
     "ufd_submit_annotate_batch", "ufd_annotate_jpeg_batch", "ufd_encode_bound", "ufd_host_alloc", "ufd_host_free",
     "ufd_debug_draw_labels", "ufd_debug_encode_rgb", "ufd_model_limits",
@@ -218,6 +218,7 @@ def load_library():
     L.ufd_profile_sampling.argtypes = [vp, u32]
     L.ufd_profile_read.argtypes = [vp, vp, u32, pu32]
     L.ufd_profile_shapes.argtypes = [vp, vp, u32, pu32]
+    L.ufd_prime_device.argtypes = [i32]
     L.ufd_debug_plan.argtypes = [u32, u32, u32, ctypes.POINTER(UfdPlanLayer), u32, pu32, ctypes.POINTER(UfdPlanTensor), u32, pu32,
                                  ctypes.POINTER(ctypes.c_uint64)]
     L.ufd_host_stats_reset.argtypes = [vp]
@@ -238,6 +239,17 @@ def debug_plan(variant, max_batch, flags=0):
     ls = [dict(name=layers[i].name.decode(), **{f: getattr(layers[i], f) for f, _ in UfdPlanLayer._fields_[1:]}) for i in range(nl.value)]
     ts = [{f: getattr(tensors[i], f) for f, _ in UfdPlanTensor._fields_} for i in range(nt.value)]
     return ls, ts, arena.value
+
+
+def prime_device(device_id=0):
+    """ufd_prime_device: opens this library's hardware queues on the device BEFORE another copy of the HIP runtime in the
+    process (torch's) touches it -- a handle created behind torch's first copy or kernel runs 21 % slower for good
+    (include/ufd.h).  In a Python host that also uses torch on the GPU: `torch.cuda.set_device(d)` (initialises torch's
+    runtime without opening a queue), then this, then everything else -- with the two the other way round torch's runtime no
+    longer finds the device."""
+    rc = load_library().ufd_prime_device(int(device_id))
+    if rc:
+        raise UfdError(rc, (load_library().ufd_last_error(None) or b"").decode())
 
 
 def jpeg_coefficients(jpeg):

@@ -174,6 +174,21 @@ def test_experiment_knobs_in_the_environment_are_refused_not_obeyed(weights):
     assert set(re.findall(r'getenv\("(\w+)"\)', src)) <= {"XDG_CACHE_HOME", "HOME"}, "a knob outside experiments.hpp"
 
 
+def test_prime_device_argument_and_error_paths():
+    """ufd_prime_device (a Python host with torch calls it before torch touches the GPU: include/ufd.h): without a GPU it
+    says so like ufd_create does; with one, a bad device id is UFD_E_ARG."""
+    import torch
+    from infercam_onnx_amd import nn
+
+    L = nn.load_library()
+    if torch.cuda.device_count() == 0:
+        assert L.ufd_prime_device(0) == nn.UFD_E_DEVICE and b"no CPU fallback" in (L.ufd_last_error(None) or b"")
+        with pytest.raises(nn.UfdError):
+            nn.prime_device(0)
+    else:
+        assert L.ufd_prime_device(0) == 0 and L.ufd_prime_device(99) == nn.UFD_E_ARG and L.ufd_prime_device(-1) == nn.UFD_E_ARG
+
+
 def test_synthetic_inputs_are_deterministic():
     from infercam_onnx_amd import synth
 
