@@ -102,7 +102,9 @@ typedef struct ufd_config {
 
 /* UltrafaceModel::new (nn.rs:55-67) + get_model (nn.rs:143-175): load + pack weights into HBM. */
 int ufd_create(const ufd_config* cfg, ufd_model** out);
-/* For processes that hold ANOTHER copy of the HIP runtime (a Python host with torch: its wheels bundle one): call this before
+/* (Since round 6 a handle's streams are created at the highest stream priority, which by itself makes the order described here
+ * irrelevant -- 65.5 k frames/s either way; this call remains for hosts that want the order right as well.)
+ * For processes that hold ANOTHER copy of the HIP runtime (a Python host with torch: its wheels bundle one): call this before
  * that runtime first touches the device.  A handle's four streams are this runtime's four hardware queues; when the other
  * runtime opens its queue FIRST -- one 32-byte copy by torch is enough -- every handle created afterwards runs 21 % slower
  * for the life of the process (65.4 k -> 51.5 k frames/s at batch 32), while the same activity after this call, or after a

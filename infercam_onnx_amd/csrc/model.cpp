@@ -718,7 +718,13 @@ int create(const ufd_config* cfg, ufd_model** out) {
   m->pool.reset(new ThreadPool(std::min(threads, 8u), [m] { pin_this_thread(m); }));  // synchronous entry points and taps
   // Four contexts = four streams = the runtime's four hardware queues, one each (a fifth stream would share a queue with
   // a context and serialise with its kernels: no copy stream, see k_stage_in above).
-  for (int ci = 0; ci < m->num_ctx; ci++) HIPB(hipStreamCreateWithFlags(&m->ctx[ci].stream, hipStreamNonBlocking));
+  // HIGHEST stream priority (round 6): a process may hold another copy of the HIP runtime (torch's wheels bundle one), and with
+  // default-priority streams a handle created behind that runtime's first touch of the device -- one 32-byte copy -- ran 21 %
+  // slower for the life of the process (65.4 k -> 51.5 k frames/s); at the highest priority the order does not matter (65.6 k
+  // either way, and unchanged without the other runtime): tools/ab/r6_torch_queue.py, profiles/r6e/torch_queue4.txt.
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  for (int ci = 0; ci < m->num_ctx; ci++) HIPB(hipStreamCreateWithPriority(&m->ctx[ci].stream, hipStreamNonBlocking, prio_hi));
   if (gate_init(m) != UFD_OK) {
     m->err = "hipEventCreate failed (pipeline gate)";
     return bail(UFD_E_DEVICE);

@@ -53,7 +53,30 @@ def gpu_used_mb():
 inflight, n, t0, last = [], 0, time.time(), time.time()
 first = None
 samples = []
-while time.time() - t0 < secs:
+interval = min(10, secs / 16)
+
+
+def late_jump():
+    """The largest step of the second half so far sits in its last two intervals: nothing measured behind it yet."""
+    if len(samples) < 8:
+        return False
+    half_ = samples[len(samples) // 2:]
+    st = [b_[1] - a_[1] for a_, b_ in zip(half_, half_[1:])]
+    i_ = max(range(len(st)), key=lambda k_: st[k_])
+    return st[i_] > 8.0 and i_ >= len(st) - 2
+
+
+deadline, extensions = secs, 0
+while True:
+    if time.time() - t0 >= deadline:
+        # a one-off jump (the runtime enlarging a pool: +190 MB in one interval) at the very end looks like the start of a leak:
+        # run four more intervals, at most twice, so that there IS something measured behind it
+        if extensions < 2 and late_jump():
+            extensions += 1
+            deadline += 4 * interval
+            print("late step in the resident set: running %.1f s longer (extension %d)" % (4 * interval, extensions), flush=True)
+        else:
+            break
     if len(inflight) >= 6:
         m.wait(inflight.pop(0), collect=False)
     k = 6 if n % 50 == 49 and not any(b is batches[6] for b in [m._pending[t] for t in inflight]) else n % 6
@@ -67,7 +90,7 @@ while time.time() - t0 < secs:
             continue
     inflight.append(submit(batches[k]))
     n += 1
-    if time.time() - last > min(10, secs / 16):
+    if time.time() - last > interval:
         last = time.time()
         rec = (n, rss_mb(), gpu_used_mb())
         first = first or rec
@@ -85,7 +108,7 @@ m.close()
 # samples of one run, between the last two of another -- flat before and after) does not.  So the slope is taken over the
 # SECOND HALF of the run (round 4's runtime leak was 2.1 KB per batch, in every interval: 45 MB in 12 s), and the largest
 # single step between two samples is taken out ONLY when it is an isolated one: the run is long enough that one interval
-# cannot hold all of a leak's growth (8 or more second-half steps) and the steps on both sides of it are flat (below the
+# cannot hold all of a leak's growth (eight or more second-half samples) and the steps on both sides of it are flat (below the
 # per-batch bar).  A leak that arrives in bursts -- a pool enlarged every N batches -- has more than one such step and stays in;
 # a late jump with nothing measured behind it stays in too.  The excluded step is printed and reported.
 samples.append(end)
@@ -100,7 +123,7 @@ def flat(i):
 
 
 excluded = None
-if len(steps) >= 8:
+if len(steps) >= 7:  # (eight or more second-half samples)
     i = max(range(len(steps)), key=lambda k: steps[k])
     if steps[i] > 0 and flat(i - 1) and flat(i + 1):
         excluded = (half[i][0], half[i + 1][0], steps[i])
