@@ -7,6 +7,7 @@ confidences in descending order, boxes as relative `[x_tl, y_tl, x_br, y_br]` (n
 fallback: if the library or a GPU is missing, construction raises.
 """
 import ctypes
+import threading
 import enum
 import os
 
@@ -148,6 +149,33 @@ class UfdError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s (%d): %s" % (_STATUS_NAMES.get(code, "?"), code, msg))
         self.code = code
+
+
+# Pinned output buffers of annotate batches (ufd_host_alloc), reused across batches: size class (power of two) -> addresses.
+_pinned_free = {}
+_pinned_lock = threading.Lock()
+_PINNED_KEEP = 8  # buffers kept per size class
+
+
+def _pinned_acquire(lib, cap):
+    size = 1 << max(12, (int(cap) - 1).bit_length())
+    with _pinned_lock:
+        lst = _pinned_free.get(size)
+        if lst:
+            return lst.pop(), size
+    mem = lib.ufd_host_alloc(size)
+    if not mem:
+        raise MemoryError("ufd_host_alloc(%d)" % size)
+    return mem, size
+
+
+def _pinned_release(lib, mem, size):
+    with _pinned_lock:
+        lst = _pinned_free.setdefault(size, [])
+        if size and len(lst) < _PINNED_KEEP:
+            lst.append(mem)
+            return
+    lib.ufd_host_free(mem)
 
 
 def load_library():
@@ -528,12 +556,12 @@ class UltrafaceModel(InferModel):
 
     # -- N1: the rest of the Inferer::run iteration (inferer.rs:38-46): rectangles + JPEG re-encode on the GPU
     class _AnnotBatch(_Batch):
-        __slots__ = ("annot", "jpeg_buf", "jpeg_mem", "jpeg_off", "jpeg_len", "owner")
+        __slots__ = ("annot", "jpeg_buf", "jpeg_mem", "jpeg_off", "jpeg_len", "owner", "jpeg_alloc")
 
         def __del__(self):
             mem, owner = getattr(self, "jpeg_mem", None), getattr(self, "owner", None)
             if mem and owner is not None:
-                owner.ufd_host_free(mem)
+                _pinned_release(owner, mem, getattr(self, "jpeg_alloc", 0))
                 self.jpeg_mem = None
 
     def prep_annotate_batch(self, jpegs, label_size, quality=95, multipart=False, out_bytes_per_frame=None, text=True, pinned=True,
@@ -557,9 +585,8 @@ class UltrafaceModel(InferModel):
         cap = max(int(out_bytes_per_frame), 1024) * b.count if cap_bytes is None else int(cap_bytes)  # (cap_bytes: the exact size, tests)
         b.owner = self._lib
         if pinned:
-            b.jpeg_mem = self._lib.ufd_host_alloc(cap)
-            if not b.jpeg_mem:
-                raise MemoryError("ufd_host_alloc(%d)" % cap)
+            # (from a small pool: pinning memory costs a millisecond, and the reference's ring slots are reused too, lib.rs:32-37)
+            b.jpeg_mem, b.jpeg_alloc = _pinned_acquire(self._lib, cap)
             b.jpeg_buf = (ctypes.c_ubyte * cap).from_address(b.jpeg_mem)
         else:
             b.jpeg_mem = None
